@@ -1,0 +1,106 @@
+"""ctypes binding of libnrx.so (include/nrx.h).  No fallback: if the HIP library is missing this raises.
+
+The wrappers in this package hand torch device tensors to the C ABI through ``tensor.data_ptr()`` and the
+current HIP stream; PyTorch is only used for device memory, streams and torch.distributed.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libnrx.so')
+
+i32, i64, u64, vp = C.c_int32, C.c_int64, C.c_size_t, C.c_void_p
+
+
+class LdpcCfg(C.Structure):
+    """nrx_ldpc_cfg (include/nrx.h)."""
+    _fields_ = [(n, i32) for n in ('bg', 'B', 'C', 'Zc', 'iLS', 'K', 'N', 'F', 'cb_len')]
+
+    def __repr__(self):
+        return 'LdpcCfg(' + ', '.join(f'{n}={getattr(self, n)}' for n, _ in self._fields_) + ')'
+
+
+class NrxError(RuntimeError):
+    pass
+
+
+_cfgp = C.POINTER(LdpcCfg)
+
+# name -> (restype, argtypes); every symbol declared in include/nrx.h
+SIGNATURES = {
+    'nrx_version': (i32, []),
+    'nrx_last_error': (i32, [C.c_char_p, i32]),
+    'nrx_crc': (i32, [vp, i32, i64, i64, i32, vp, vp]),
+    'nrx_ldpc_config': (i32, [i32, i32, _cfgp]),
+    'nrx_ldpc_cb_lens': (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
+    'nrx_ldpc_segment': (i32, [vp, i32, i32, i32, _cfgp, vp, vp]),
+    'nrx_ldpc_encode': (i32, [vp, i32, _cfgp, i32, vp, vp]),
+    'nrx_ldpc_rate_match': (i32, [vp, i32, _cfgp, i32, i32, i32, i32, i32, vp, vp]),
+    'nrx_ldpc_rate_recover_f32': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp]),
+    'nrx_ldpc_rate_recover_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp]),
+    'nrx_ldpc_decode_ws_bytes': (u64, [_cfgp, i32]),
+    'nrx_ldpc_decode_f32': (i32, [vp, i32, _cfgp, i32, i32, vp, vp, vp, u64, vp]),
+    'nrx_ldpc_decode_f64': (i32, [vp, i32, _cfgp, i32, i32, vp, vp, vp, u64, vp]),
+    'nrx_ldpc_crc_merge': (i32, [vp, i32, _cfgp, vp, vp, vp, vp]),
+    'nrx_count_errors': (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libnrx.so (once).  Fails loudly when it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NrxError(f"{_LIB_PATH} not found -- build it with `python -m neoradium_amd.build` "
+                           "(hipcc --offload-arch=gfx950).  neoradium_amd has no CPU fallback.")
+        l = C.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().nrx_last_error(buf, 512)
+    return buf.value.decode(errors='replace')
+
+
+def check(rc):
+    """Map an NRX_E_* return code to the exception type the reference raises for the same mistake."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc in (-1, -2):      # NRX_E_ARG / NRX_E_SHAPE: the reference raises ValueError for bad arguments
+        raise ValueError(msg)
+    if rc == -3:
+        raise NotImplementedError(msg)
+    raise NrxError(f"libnrx error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a (contiguous) torch tensor, or NULL for None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "nrx buffers must be contiguous"
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ldpc_config(bg, B):
+    cfg = LdpcCfg()
+    check(lib().nrx_ldpc_config(int(bg), int(B), C.byref(cfg)))
+    return cfg
+
+
+def ldpc_cb_lens(G, Cn, nl, qm):
+    arr = (i32 * Cn)()
+    check(lib().nrx_ldpc_cb_lens(int(G), int(Cn), int(nl), int(qm), arr))
+    return list(arr)

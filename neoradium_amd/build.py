@@ -1,0 +1,57 @@
+"""Build libnrx.so (the C-ABI HIP library) in-tree for gfx950 with hipcc.
+
+    python -m neoradium_amd.build [--force]
+
+One translation unit per csrc/*.hip, linked into neoradium_amd/libnrx.so.  No torch, no cmake: plain hipcc.
+`-ffp-contract=off` keeps float64 paths bit-identical to the NumPy reference (no FMA contraction).
+"""
+import os
+import subprocess
+import sys
+import glob
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'obj')
+LIB = os.path.join(HERE, 'libnrx.so')
+FLAGS = ['-std=c++20', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-Wno-comment',
+         '-Wno-unused-value']
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(d) > t for d in [src] + deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    deps = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + '.o')
+        objs.append(o)
+        if force or _newer(s, o, deps):
+            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print('[nrx build]', ' '.join(os.path.relpath(c) if os.path.exists(c) else c for c in cmd[-3:]), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,72 @@
+// Host-only entry points of libnrx.so: version, error text, LDPC size derivation.
+#include <stdarg.h>
+#include <math.h>
+#include "nrx_common.h"
+
+namespace nrx {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace nrx
+
+extern "C" int32_t nrx_version(void) { return 100; }  // 0.1.0
+
+extern "C" int32_t nrx_last_error(char* buf, int32_t buf_len) {
+  if (!buf || buf_len <= 0) return NRX_E_ARG;
+  strncpy(buf, nrx::g_err, (size_t)buf_len - 1);
+  buf[buf_len - 1] = 0;
+  return NRX_OK;
+}
+
+// Lifting sizes a * 2^j <= 384, a in {2,3,5,7,9,11,13,15}  (TS 38.212 Table 5.3.2-1; reference ldpc.py:657-666).
+extern "C" int32_t nrx_ldpc_config(int32_t bg, int32_t B, nrx_ldpc_cfg* cfg) {
+  NRX_REQUIRE(cfg, NRX_E_ARG, "nrx_ldpc_config: NULL cfg");
+  NRX_REQUIRE(bg == 1 || bg == 2, NRX_E_ARG, "nrx_ldpc_config: bg must be 1|2 (got %d)", bg);
+  NRX_REQUIRE(B > 0, NRX_E_ARG, "nrx_ldpc_config: B must be positive (got %d)", B);
+  const int kcb = bg == 1 ? 8448 : 3840;
+  int C = 1;
+  long tot = B;
+  if (B > kcb) {  // ldpc.py:864-871
+    C = (B + (kcb - 24) - 1) / (kcb - 24);
+    tot = (long)B + (long)C * 24;
+  }
+  int kb;  // ldpc.py:875-879 (BG2 thresholds are keyed on B)
+  if (bg == 1) kb = 22;
+  else if (B > 640) kb = 10;
+  else if (B > 560) kb = 9;
+  else if (B > 192) kb = 8;
+  else kb = 6;
+  // smallest Z over all sets with kb*Z >= K' = tot/C (K' may be fractional): kb*Z*C >= tot
+  static const int base[8] = {2, 3, 5, 7, 9, 11, 13, 15};
+  int best = 10000, ils = -1;
+  for (int i = 0; i < 8; ++i)
+    for (int z = base[i]; z <= 384; z *= 2)
+      if ((long)kb * z * C >= tot && z < best) {
+        best = z;
+        ils = i;
+      }
+  NRX_REQUIRE(ils >= 0, NRX_E_UNSUPPORTED, "nrx_ldpc_config: no lifting size for B=%d", B);
+  cfg->bg = bg;
+  cfg->B = B;
+  cfg->C = C;
+  cfg->Zc = best;
+  cfg->iLS = ils;
+  cfg->K = (bg == 1 ? 22 : 10) * best;
+  cfg->N = (bg == 1 ? 66 : 50) * best;
+  cfg->cb_len = (B + C - 1) / C + (C > 1 ? 24 : 0);  // ldpc.py:1014,1367-1368
+  cfg->F = cfg->K - cfg->cb_len;
+  NRX_REQUIRE(cfg->F >= 0, NRX_E_UNSUPPORTED, "nrx_ldpc_config: negative filler count");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_ldpc_cb_lens(int32_t G, int32_t C, int32_t nl, int32_t qm, int32_t* e_out) {
+  NRX_REQUIRE(e_out && C > 0 && nl > 0 && qm > 0 && G >= 0, NRX_E_ARG, "nrx_ldpc_cb_lens: bad argument");
+  const int f = nl * qm;
+  const int gb = (G + f - 1) / f;  // ldpc.py:852
+  for (int r = 0; r < C; ++r) e_out[r] = (gb / C) * f + ((gb % C) && r >= C - gb % C ? f : 0);
+  return NRX_OK;
+}

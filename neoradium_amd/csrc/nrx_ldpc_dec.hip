@@ -1,0 +1,385 @@
+// Layered normalised min-sum LDPC decoder for gfx950 (MI355X).
+//
+// Replaces reference ldpc.py:1495-1581 (LdpcDecoder.decode).  Mapping (DESIGN.md "LDPC decoder"):
+//   * one workgroup = one code block, lane z = check row z of EVERY layer (Zc <= 384 lanes = up to 6 wave64s);
+//   * posterior LLRs of the "core" columns (22 info + 4 core parity for BG1, 10 + 4 for BG2 -- the only
+//     columns shared between layers) live in LDS, read/written at (z + shift) mod Zc: consecutive lanes hit
+//     consecutive banks, so every ds_read/ds_write is conflict free;
+//   * the check-node state is kept compressed per (layer, lane): 0.75*min1, 0.75*min2, argmin and the sign
+//     bits.  f32 variant: 3 VGPRs x 46 layers, never leaves the register file.  f64 variant (bit-exact with the
+//     reference's float64 arithmetic): state + the degree-1 extension-column posteriors live in an L2/MALL
+//     resident workspace, because 209 KB of float64 posteriors do not fit the 160 KB LDS;
+//   * layers are fully unrolled (the base-graph structure is constexpr, shifts come from the kernarg segment
+//     via scalar loads), one s_barrier per layer.
+// Reference quirks reproduced literally: clip to +-1e10, punctured columns start at 0, sign(0)=+1 through
+// (v < 0), first-index argmin, second minimum = min(|v_argmin + 1e5|, other |v|), 0.75 scaling, no early stop.
+#include <utility>
+#include "gen_ldpc_bg.h"
+#include "nrx_common.h"
+
+namespace {
+
+constexpr int ZMAX = 384;
+
+// All 51 lifting sizes (TS 38.212 Table 5.3.2-1), ascending, and for each the set index iLS.
+struct ZList {
+  int16_t z[51];
+  int8_t ils[51];
+};
+constexpr ZList make_zlist() {
+  ZList l{};
+  int n = 0;
+  for (int z = 2; z <= 384; ++z) {
+    const int base[8] = {2, 3, 5, 7, 9, 11, 13, 15};
+    for (int i = 0; i < 8; ++i)
+      for (int v = base[i]; v <= 384; v *= 2)
+        if (v == z) {
+          l.z[n] = (int16_t)z;
+          l.ils[n] = (int8_t)i;
+          ++n;
+        }
+  }
+  return l;
+}
+constexpr ZList kZList = make_zlist();
+
+// (shift mod Zc) for every lifting size and edge, resident in the constant address space so that the per-edge
+// shifts are scalar loads (s_load_dword) with compile-time offsets.
+constexpr int SHIFT_STRIDE = 320;
+struct ModTab {
+  int32_t v[51 * SHIFT_STRIDE];
+};
+template <int BG> constexpr ModTab make_modtab() {
+  ModTab t{};
+  for (int zi = 0; zi < 51; ++zi) {
+    const int z = kZList.z[zi], ils = kZList.ils[zi];
+    if constexpr (BG == 1) {
+      for (int e = 0; e < NRX_BG1_EDGES; ++e) t.v[zi * SHIFT_STRIDE + e] = kBg1Shift[ils][e] % z;
+    } else {
+      for (int e = 0; e < NRX_BG2_EDGES; ++e) t.v[zi * SHIFT_STRIDE + e] = kBg2Shift[ils][e] % z;
+    }
+  }
+  return t;
+}
+__constant__ ModTab kModTab1 = make_modtab<1>();
+__constant__ ModTab kModTab2 = make_modtab<2>();
+
+template <int BG> struct BgT;
+template <> struct BgT<1> {
+  static constexpr int ROWS = NRX_BG1_ROWS, COLS = NRX_BG1_COLS, EDGES = NRX_BG1_EDGES, KB = 22, CORE = 26;
+  static constexpr int row_start(int r) { return kBg1RowStart[r]; }
+  static constexpr int col(int e) { return kBg1Col[e]; }
+  static __device__ __forceinline__ int shift(int i) { return kModTab1.v[i]; }
+};
+template <> struct BgT<2> {
+  static constexpr int ROWS = NRX_BG2_ROWS, COLS = NRX_BG2_COLS, EDGES = NRX_BG2_EDGES, KB = 10, CORE = 14;
+  static constexpr int row_start(int r) { return kBg2RowStart[r]; }
+  static constexpr int col(int e) { return kBg2Col[e]; }
+  static __device__ __forceinline__ int shift(int i) { return kModTab2.v[i]; }
+};
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+    (f(std::integral_constant<int, I>{}), ...);
+  }(std::make_integer_sequence<int, N>{});
+}
+
+template <typename T> struct FpBits;
+template <> struct FpBits<float> {
+  static __device__ __forceinline__ float with_sign(float mag, uint32_t bit) {  // mag >= 0; bit in {0,1}
+    return __uint_as_float(__float_as_uint(mag) | (bit << 31));
+  }
+};
+template <> struct FpBits<double> {
+  static __device__ __forceinline__ double with_sign(double mag, uint32_t bit) {
+    return __longlong_as_double(__double_as_longlong(mag) | ((long long)bit << 63));
+  }
+};
+
+template <typename T> __device__ __forceinline__ T clip10(T x) {
+  const T c = (T)1e10;
+  return x < -c ? -c : (x > c ? c : x);
+}
+
+__device__ __forceinline__ float absT(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double absT(double x) { return __builtin_fabs(x); }
+
+__device__ __forceinline__ int wrap(int z, int s, int zc) {
+  unsigned a = (unsigned)(z + s);
+  unsigned b = a - (unsigned)zc;
+  return (int)(a < b ? a : b);  // unsigned min: picks a-zc when a >= zc
+}
+
+// Per-workgroup workspace of the f64 variant, [row][ZMAX] each.
+template <typename T> struct ExactWs {
+  T* m1;
+  T* m2;
+  uint32_t* sg;
+  T* rext;
+  static constexpr size_t bytes(int rows) { return (size_t)rows * ZMAX * (3 * sizeof(T) + sizeof(uint32_t)); }
+  __device__ void bind(char* base, int rows) {
+    m1 = (T*)base;
+    m2 = m1 + (size_t)rows * ZMAX;
+    rext = m2 + (size_t)rows * ZMAX;
+    sg = (uint32_t*)(rext + (size_t)rows * ZMAX);
+  }
+};
+
+template <typename T, int BG, bool EXACT>
+__global__ void __launch_bounds__(ZMAX)
+ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out_cols, int n_cols_in,
+                uint8_t* __restrict__ hard, T* __restrict__ belief, char* __restrict__ ws, int tab_off) {
+  using G = BgT<BG>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* P = (T*)smem;  // [CORE][ZMAX]
+  const int z = threadIdx.x;
+  const bool active = z < zc;
+  const int N = n_cols_in * zc;  // (COLS-2)*zc
+
+  // register-resident check-node state (f32 variant)
+  T m1[EXACT ? 1 : G::ROWS];
+  T m2[EXACT ? 1 : G::ROWS];
+  uint32_t sg[EXACT ? 1 : G::ROWS];
+  T ech[EXACT ? 1 : G::ROWS];  // channel LLR of the layer's degree-1 extension column, at (z+shift) mod Zc
+  ExactWs<T> W;
+  if (EXACT) W.bind(ws + (size_t)blockIdx.x * ExactWs<T>::bytes(G::ROWS), G::ROWS);
+
+  for (int cb = blockIdx.x; cb < n_cb; cb += gridDim.x) {
+    const T* in = llr + (size_t)cb * N;
+    // ---- load: clip, prepend the two punctured columns as zeros (ldpc.py:1536-1538)
+    if (active) {
+      static_for<G::CORE>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        P[c * ZMAX + z] = (c < 2) ? (T)0 : clip10<T>(in[(c - 2) * zc + z]);
+      });
+      static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(lc)::value;
+        if constexpr (EXACT) {
+          W.m1[L * ZMAX + z] = (T)0;
+          W.m2[L * ZMAX + z] = (T)0;
+          W.sg[L * ZMAX + z] = 0u;
+          constexpr int e_last = G::row_start(L + 1) - 1;
+          constexpr int col = G::col(e_last);
+          if constexpr (col >= G::CORE) {
+            W.rext[L * ZMAX + z] = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
+          }
+        } else {
+          m1[L] = (T)0;
+          m2[L] = (T)0;
+          sg[L] = 0u;
+          constexpr int e_last = G::row_start(L + 1) - 1;
+          constexpr int col = G::col(e_last);
+          if constexpr (col >= G::CORE) ech[L] = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
+          else ech[L] = (T)0;
+        }
+      });
+    }
+    __syncthreads();
+
+    for (int it = 0; it < n_iter; ++it) {
+      static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(lc)::value;
+        constexpr int E0 = G::row_start(L);
+        constexpr int D = G::row_start(L + 1) - E0;
+        // Opaque copies: the (z+shift) mod Zc addresses and the kernarg shift loads are invariant over the
+        // iteration loop; without this the compiler hoists all ~300 of them and spills.
+        int zz = z;
+        int so = tab_off;
+        asm volatile("" : "+v"(zz), "+s"(so));
+        if (active) {
+          T om1, om2;
+          uint32_t osg;
+          if constexpr (EXACT) {
+            om1 = W.m1[L * ZMAX + z];
+            om2 = W.m2[L * ZMAX + z];
+            osg = W.sg[L * ZMAX + z];
+          } else {
+            om1 = m1[L];
+            om2 = m2[L];
+            osg = sg[L];
+          }
+          const uint32_t oidx = osg >> 24;
+          T t[D];
+          int ad[D];
+          // ---- pass 1: extrinsic values t_j = r_j - msg_old_j  (ldpc.py:1550-1553)
+          static_for<D>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int col = G::col(E0 + j);
+            T p;
+            if constexpr (col < G::CORE) {
+              ad[j] = col * ZMAX + wrap(zz, G::shift(so + E0 + j), zc);
+              p = P[ad[j]];
+            } else if constexpr (EXACT) {
+              ad[j] = 0;
+              p = W.rext[L * ZMAX + z];
+            } else {
+              // degree-1 extension column: r - msg_old is the channel LLR itself (up to fp32 rounding)
+              ad[j] = 0;
+              p = ech[L];
+            }
+            if constexpr (col < G::CORE || EXACT) {
+              const T mag = (oidx == (uint32_t)j) ? om2 : om1;
+              const T old = FpBits<T>::with_sign(mag, (osg >> j) & 1u);
+              t[j] = p - old;
+            } else {
+              t[j] = p;
+            }
+          });
+          // ---- min-sum (ldpc.py:1556-1564)
+          T a1 = absT(t[0]);
+          T a2 = (T)3.0e38;
+          uint32_t idx = 0;
+          uint32_t negm = t[0] < (T)0 ? 1u : 0u;
+          static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value + 1;
+            const bool ng = t[j] < (T)0;
+            const T a = absT(t[j]);
+            negm |= (ng ? 1u : 0u) << j;
+            const bool lt = a < a1;                      // strict: ties keep the first index
+            a2 = lt ? a1 : (a < a2 ? a : a2);
+            idx = lt ? (uint32_t)j : idx;
+            a1 = lt ? a : a1;
+          });
+          // QUIRK ldpc.py:1563: the argmin entry is bumped by +100000 (signed) before the 2nd min is taken
+          {
+            const T v = ((negm >> idx) & 1u) ? -a1 : a1;
+            const T q = absT(v + (T)100000);
+            a2 = q < a2 ? q : a2;
+          }
+          const T nm1 = a1 * (T)0.75, nm2 = a2 * (T)0.75;  // ldpc.py:1573 (scale commutes with the sign)
+          const uint32_t par = __popc(negm) & 1u;
+          const uint32_t nsg = (negm ^ (par ? ((1u << D) - 1u) : 0u)) | (idx << 24);
+          if constexpr (EXACT) {
+            W.m1[L * ZMAX + z] = nm1;
+            W.m2[L * ZMAX + z] = nm2;
+            W.sg[L * ZMAX + z] = nsg;
+          } else {
+            m1[L] = nm1;
+            m2[L] = nm2;
+            sg[L] = nsg;
+          }
+          // ---- pass 2: r_j = t_j + msg_new_j  (ldpc.py:1567-1576)
+          static_for<D>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int col = G::col(E0 + j);
+            if constexpr (col < G::CORE || EXACT) {
+              const T mag = (idx == (uint32_t)j) ? nm2 : nm1;
+              const T nw = FpBits<T>::with_sign(mag, (nsg >> j) & 1u);
+              const T r = t[j] + nw;
+              if constexpr (col < G::CORE) P[ad[j]] = r;
+              else W.rext[L * ZMAX + z] = r;
+            }
+          });
+        }
+        __syncthreads();
+      });
+    }
+
+    // ---- outputs (ldpc.py:1578-1581)
+    if (active) {
+      const size_t ob = (size_t)cb * out_cols;
+      static_for<G::CORE>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        if (c * zc < out_cols) {
+          const T r = P[c * ZMAX + z];
+          if (hard) hard[ob + c * zc + z] = r < (T)0 ? 1 : 0;
+          if (belief) belief[ob + c * zc + z] = r;
+        }
+      });
+      if (out_cols > G::CORE * zc) {
+        static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
+          constexpr int L = decltype(lc)::value;
+          constexpr int e = G::row_start(L + 1) - 1;
+          constexpr int col = G::col(e);
+          if constexpr (col >= G::CORE) {
+            const int pos = wrap(z, G::shift(tab_off + e), zc);
+            T r;
+            if constexpr (EXACT) {
+              r = W.rext[L * ZMAX + z];
+            } else {
+              constexpr int j = e - G::row_start(L);
+              const uint32_t s = sg[L];
+              const T mag = ((s >> 24) == (uint32_t)j) ? m2[L] : m1[L];
+              r = ech[L] + FpBits<T>::with_sign(mag, (s >> j) & 1u);
+            }
+            if (hard) hard[ob + col * zc + pos] = r < (T)0 ? 1 : 0;
+            if (belief) belief[ob + col * zc + pos] = r;
+          }
+        });
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int BG, bool EXACT>
+int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int out_cols, uint8_t* hard, T* belief,
+               void* ws, size_t ws_bytes, hipStream_t st, int tab_off) {
+  using G = BgT<BG>;
+  const int threads = ((cfg->Zc + 63) / 64) * 64;
+  int grid = n_cb < 512 ? n_cb : 512;
+  if (EXACT) {
+    const size_t per = ExactWs<T>::bytes(G::ROWS);
+    NRX_REQUIRE(ws != nullptr && ws_bytes >= per, NRX_E_ARG,
+                "nrx_ldpc_decode_f64: workspace of >= %zu bytes required", per);
+    const size_t fit = ws_bytes / per;
+    if ((size_t)grid > fit) grid = (int)fit;
+  }
+  const size_t lds = (size_t)G::CORE * ZMAX * sizeof(T);
+  auto kern = ldpc_dec_kernel<T, BG, EXACT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, llr, n_cb, cfg->Zc, n_iter, out_cols, G::COLS - 2,
+                     hard, belief, (char*)ws, tab_off);
+  NRX_CHECK_LAUNCH("nrx_ldpc_decode");
+  return NRX_OK;
+}
+
+template <typename T, bool EXACT>
+int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t out_cols,
+                     uint8_t* hard, T* belief, void* ws, size_t ws_bytes, void* stream) {
+  NRX_REQUIRE(llr && cfg, NRX_E_ARG, "nrx_ldpc_decode: NULL llr/cfg");
+  NRX_REQUIRE(hard || belief, NRX_E_ARG, "nrx_ldpc_decode: need hard_out or belief_out");
+  NRX_REQUIRE(cfg->bg == 1 || cfg->bg == 2, NRX_E_ARG, "nrx_ldpc_decode: bg must be 1|2");
+  NRX_REQUIRE(cfg->Zc >= 2 && cfg->Zc <= ZMAX && cfg->iLS >= 0 && cfg->iLS < 8, NRX_E_ARG,
+              "nrx_ldpc_decode: bad Zc/iLS (%d,%d)", cfg->Zc, cfg->iLS);
+  NRX_REQUIRE(n_cb >= 0 && n_iter >= 0, NRX_E_ARG, "nrx_ldpc_decode: negative count");
+  const int cols = cfg->bg == 1 ? NRX_BG1_COLS : NRX_BG2_COLS;
+  NRX_REQUIRE(out_cols == cfg->K || out_cols == cols * cfg->Zc, NRX_E_SHAPE,
+              "nrx_ldpc_decode: out_cols must be K (%d) or all %d columns", cfg->K, cols * cfg->Zc);
+  NRX_REQUIRE(cfg->N == (cols - 2) * cfg->Zc, NRX_E_SHAPE, "nrx_ldpc_decode: cfg->N inconsistent");
+  if (n_cb == 0) return NRX_OK;
+  int zi = -1;
+  for (int i = 0; i < 51; ++i)
+    if (kZList.z[i] == cfg->Zc) zi = i;
+  NRX_REQUIRE(zi >= 0 && kZList.ils[zi] == cfg->iLS, NRX_E_ARG, "nrx_ldpc_decode: (Zc=%d, iLS=%d) is not a lifting size",
+              cfg->Zc, cfg->iLS);
+  const int tab = zi * SHIFT_STRIDE;
+  hipStream_t st = (hipStream_t)stream;
+  if (cfg->bg == 1) return launch<T, 1, EXACT>(llr, n_cb, cfg, n_iter, out_cols, hard, belief, ws, ws_bytes, st, tab);
+  return launch<T, 2, EXACT>(llr, n_cb, cfg, n_iter, out_cols, hard, belief, ws, ws_bytes, st, tab);
+}
+
+}  // namespace
+
+extern "C" size_t nrx_ldpc_decode_ws_bytes(const nrx_ldpc_cfg* cfg, int32_t is_f64) {
+  if (!cfg || !is_f64) return 0;
+  const int rows = cfg->bg == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
+  return 512 * ExactWs<double>::bytes(rows);
+}
+
+extern "C" int32_t nrx_ldpc_decode_f32(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                       int32_t out_cols, uint8_t* hard_out, float* belief_out, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  return decode_entry<float, false>(llr, n_cb, cfg, n_iter, out_cols, hard_out, belief_out, ws, ws_bytes, stream);
+}
+
+extern "C" int32_t nrx_ldpc_decode_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                       int32_t out_cols, uint8_t* hard_out, double* belief_out, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  return decode_entry<double, true>(llr, n_cb, cfg, n_iter, out_cols, hard_out, belief_out, ws, ws_bytes, stream);
+}

@@ -1,0 +1,476 @@
+// CRC, code-block segmentation, LDPC encode, rate match / rate recover, CRC check + merge (gfx950).
+//
+// These are the integer/byte stages either side of the decoder.  They are streaming, HBM-bound kernels
+// (one pass over the bits / LLRs); none of them is a contraction, so no MFMA.  Reference lines are cited per
+// kernel.  Bits are one uint8 per bit (the reference's int8 arrays).
+#include "gen_ldpc_bg.h"
+#include "nrx_common.h"
+
+namespace {
+
+constexpr int ZMAX = 384;
+
+// chancodebase.py:37-44 -- generator polynomials, MSB first incl. the leading one.
+__host__ __device__ inline uint32_t crc_poly(int id) {
+  switch (id) {
+    case NRX_CRC6: return 0x61u;
+    case NRX_CRC11: return 0xE21u;
+    case NRX_CRC16: return 0x11021u;
+    case NRX_CRC24A: return 0x1864CFBu;
+    case NRX_CRC24B: return 0x1800063u;
+    default: return 0x1B2B117u;  // 24C
+  }
+}
+__host__ __device__ inline int crc_len(int id) {
+  switch (id) {
+    case NRX_CRC6: return 6;
+    case NRX_CRC11: return 11;
+    case NRX_CRC16: return 16;
+    default: return 24;
+  }
+}
+
+// (a * b) mod g over GF(2), degrees < L.
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t low, int L) {
+  const uint32_t mask = (1u << L) - 1u;
+  uint32_t r = 0;
+  for (int i = L - 1; i >= 0; --i) {
+    const uint32_t top = (r >> (L - 1)) & 1u;
+    r = ((r << 1) & mask) ^ (top ? low : 0u);
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r;
+}
+// x^e mod g
+__device__ __forceinline__ uint32_t gf2_xpow(uint64_t e, uint32_t low, int L) {
+  uint32_t result = 1u;          // x^0
+  uint32_t base = (L > 1) ? 2u : low;  // x^1 (L>=6 always)
+  while (e) {
+    if (e & 1) result = gf2_mulmod(result, base, low, L);
+    base = gf2_mulmod(base, base, low, L);
+    e >>= 1;
+  }
+  return result;
+}
+
+// Workgroup-parallel CRC of `n` bits produced by bit(i): each thread runs the bit-serial register over a
+// contiguous chunk, then the chunk remainders are aligned with x^(bits after the chunk) and xor-reduced
+// (CRC is linear over GF(2)).  Result is identical to the reference's long division (chancodebase.py:119-128).
+// Returns the remainder to every thread.  `red` is >= blockDim.x/64 words of LDS.
+template <class BitFn>
+__device__ uint32_t block_crc(BitFn bit, int64_t n, int poly_id, uint32_t* red) {
+  const int L = crc_len(poly_id);
+  const uint32_t low = crc_poly(poly_id) & ((1u << L) - 1u);
+  const uint32_t mask = (1u << L) - 1u;
+  const int nt = blockDim.x, tid = threadIdx.x;
+  const int64_t chunk = (n + nt - 1) / nt;
+  const int64_t b0 = (int64_t)tid * chunk;
+  int64_t b1 = b0 + chunk;
+  if (b1 > n) b1 = n;
+  uint32_t reg = 0;
+  for (int64_t i = b0; i < b1; ++i) {
+    const uint32_t top = ((reg >> (L - 1)) ^ (uint32_t)bit(i)) & 1u;
+    reg = ((reg << 1) & mask) ^ (top ? low : 0u);
+  }
+  if (b0 < n && reg != 0 && b1 < n) reg = gf2_mulmod(reg, gf2_xpow((uint64_t)(n - b1), low, L), low, L);
+  if (b0 >= n) reg = 0;
+  // xor-reduce across the workgroup
+  for (int o = 32; o > 0; o >>= 1) reg ^= __shfl_xor(reg, o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = reg;
+  __syncthreads();
+  uint32_t tot = 0;
+  for (int w = 0; w < (nt + 63) / 64; ++w) tot ^= red[w];
+  __syncthreads();
+  return tot;
+}
+
+// ---------------------------------------------------------------------------------------------- nrx_crc
+__global__ void __launch_bounds__(256)
+crc_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, int poly_id,
+                uint8_t* __restrict__ out) {
+  __shared__ uint32_t red[16];
+  const uint8_t* row = bits + (size_t)blockIdx.x * row_stride;
+  const uint32_t r = block_crc([&](int64_t i) { return row[i] & 1; }, row_len, poly_id, red);
+  const int L = crc_len(poly_id);
+  if ((int)threadIdx.x < L) out[(size_t)blockIdx.x * L + threadIdx.x] = (r >> (L - 1 - threadIdx.x)) & 1u;
+}
+
+// ------------------------------------------------------------------------------------- nrx_ldpc_segment
+// ldpc.py:981-1030.  One workgroup per (tb, code block): gathers the payload of block c from
+// [TB bits | TB CRC24A | zero pad], appends CRC24B when C>1, zero fillers.
+__global__ void __launch_bounds__(256)
+segment_kernel(const uint8_t* __restrict__ tb, int add_tb_crc, int A, int B, int C, int K, int cb_len,
+               uint8_t* __restrict__ cbs) {
+  __shared__ uint32_t red[16];
+  const int t = blockIdx.x / C, c = blockIdx.x % C;
+  const int per = (B + C - 1) / C;  // payload bits per block before its CRC
+  const uint8_t* src = tb + (size_t)t * A;
+  uint8_t* dst = cbs + (size_t)blockIdx.x * K;
+  // The (at most two) blocks that hold TB-CRC bits compute the CRC24A of the whole TB themselves
+  // (chancodebase.py:161-189 appendCrc('24A')); no scratch buffer, no extra launch.
+  uint32_t tbcrc = 0;
+  if (add_tb_crc && (int64_t)(c + 1) * per > A)
+    tbcrc = block_crc([&](int64_t i) { return src[i] & 1; }, A, NRX_CRC24A, red);
+  auto payload = [&](int64_t i) -> int {
+    const int64_t g = (int64_t)c * per + i;
+    if (g < A) return src[g] & 1;
+    if (g < B) return (int)((tbcrc >> (23 - (int)(g - A))) & 1u);
+    return 0;  // zero padding at the end of the last block (ldpc.py:1014-1016)
+  };
+  for (int i = threadIdx.x; i < per; i += blockDim.x) dst[i] = (uint8_t)payload(i);
+  if (C > 1) {
+    const uint32_t r = block_crc(payload, per, NRX_CRC24B, red);
+    if (threadIdx.x < 24) dst[per + threadIdx.x] = (r >> (23 - threadIdx.x)) & 1u;
+  }
+  for (int i = cb_len + threadIdx.x; i < K; i += blockDim.x) dst[i] = 0;  // fillers are ZERO bits (ldpc.py:1025-1028)
+}
+
+// -------------------------------------------------------------------------------------- nrx_ldpc_encode
+// ldpc.py:1033-1090.  One workgroup per code block, lane z = bit z of every Zc-column; the 22(10) information
+// columns plus the 4 core parity columns sit in LDS; circulant products are LDS reads at (z+shift) mod Zc.
+struct EncTab {
+  int16_t s[320];
+};
+
+template <int BG>
+__global__ void __launch_bounds__(ZMAX)
+encode_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __restrict__ coded, const EncTab tab) {
+  constexpr int ROWS = BG == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
+  constexpr int KB = BG == 1 ? 22 : 10;
+  const int16_t* rs = BG == 1 ? kBg1RowStart : kBg2RowStart;
+  const int16_t* cl = BG == 1 ? kBg1Col : kBg2Col;
+  __shared__ uint8_t w[(KB + 4) * ZMAX];
+  __shared__ uint8_t tmp[ZMAX];
+  const int z = threadIdx.x;
+  const bool act = z < zc;
+  const int K = KB * zc;
+  const int ncols_out = (BG == 1 ? 68 : 52) - (puncture ? 2 : 0);
+  const uint8_t* in = cbs + (size_t)blockIdx.x * K;
+  uint8_t* out = coded + (size_t)blockIdx.x * ncols_out * zc;
+  const int skip = puncture ? 2 : 0;
+  auto rot = [&](int s) { int a = z + s; return a >= zc ? a - zc : a; };
+
+  if (act)
+    for (int c = 0; c < KB; ++c) {
+      const uint8_t b = in[c * zc + z] & 1;
+      w[c * ZMAX + z] = b;
+      if (c >= skip) out[(c - skip) * zc + z] = b;
+    }
+  __syncthreads();
+  // information part of rows 0..3
+  uint8_t core[4] = {0, 0, 0, 0};
+  int sh_p[4][4];  // shift of parity column KB+q in core row i (-1 = none)
+  for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < 4; ++q) sh_p[i][q] = -1;
+  for (int i = 0; i < 4; ++i)
+    for (int e = rs[i]; e < rs[i + 1]; ++e) {
+      const int c = cl[e];
+      if (c < KB) { if (act) core[i] ^= w[c * ZMAX + rot(tab.s[e])]; }
+      else if (c < KB + 4) sh_p[i][c - KB] = tab.s[e];
+    }
+  // p0 = rot(sum of the four rows, Zc - shift) with shift = bg[1][KB] (or bg[2][KB] when that is -1): ldpc.py:1068-1074
+  const int s0 = sh_p[1][0] >= 0 ? sh_p[1][0] : sh_p[2][0];
+  if (act) tmp[z] = core[0] ^ core[1] ^ core[2] ^ core[3];
+  __syncthreads();
+  if (act) w[KB * ZMAX + z] = tmp[rot((zc - s0) % zc)];
+  __syncthreads();
+  // p1..p3: ldpc.py:1077-1080
+  for (int i = 0; i < 3; ++i) {
+    if (act) {
+      uint8_t v = core[i];
+      for (int q = 0; q <= i; ++q)
+        if (sh_p[i][q] >= 0) v ^= w[(KB + q) * ZMAX + rot(sh_p[i][q])];
+      w[(KB + i + 1) * ZMAX + z] = v;
+    }
+    __syncthreads();
+  }
+  if (act)
+    for (int q = 0; q < 4; ++q) out[(KB + q - skip) * zc + z] = w[(KB + q) * ZMAX + z];
+  // extension parities: ldpc.py:1083-1084
+  if (act)
+    for (int r = 4; r < ROWS; ++r) {
+      uint8_t v = 0;
+      for (int e = rs[r]; e < rs[r + 1]; ++e) {
+        const int c = cl[e];
+        if (c < KB + 4) v ^= w[c * ZMAX + rot(tab.s[e])];
+      }
+      out[(KB + r - skip) * zc + z] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------- nrx_ldpc_rate_match
+// ldpc.py:1093-1159.  One thread per output bit: locate the code block r and position within E_r, undo the
+// bit interleaver (out[i*qm+q] = sel[q*(E/qm)+i]), map through the filler-free circular buffer at k0.
+struct RmGeom {
+  int C, N, K, F, zc, ncb, k0, sys_len, cs;  // cs = ncb - F (circular buffer without fillers)
+  int e_small, n_small, f;                   // first n_small blocks have e_small bits, the rest e_small+f
+  int G, qm;
+};
+
+__device__ __forceinline__ void rm_locate(const RmGeom& g, int pos, int& r, int& j, int& E) {
+  const int split = g.n_small * g.e_small;
+  if (pos < split) {
+    r = pos / g.e_small;
+    j = pos - r * g.e_small;
+    E = g.e_small;
+  } else {
+    const int e2 = g.e_small + g.f;
+    r = g.n_small + (pos - split) / e2;
+    j = (pos - split) - (r - g.n_small) * e2;
+    E = e2;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+rate_match_kernel(const uint8_t* __restrict__ coded, int n_tb, RmGeom g, uint8_t* __restrict__ out) {
+  const int64_t total = (int64_t)n_tb * g.G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / g.G), pos = (int)(i - (int64_t)t * g.G);
+    int r, j, E;
+    rm_locate(g, pos, r, j, E);
+    const int eq = E / g.qm;
+    const int e = (j % g.qm) * eq + j / g.qm;        // position in the selected (pre-interleaver) sequence
+    const int ci = (e + g.k0) % g.cs;                // circular buffer without fillers
+    const int src = ci < g.sys_len ? ci : ci + g.F;  // index in the N-bit coded block (fillers skipped)
+    out[i] = coded[((size_t)t * g.C + r) * g.N + src];
+  }
+}
+
+// -------------------------------------------------------------------------------- nrx_ldpc_rate_recover
+// ldpc.py:1330-1418 as a gather: one thread per (code block, coded position).  Accumulation order over the
+// wrap-around repetitions follows the reference (increasing e), so float sums are bit-identical.
+template <typename T>
+__global__ void __launch_bounds__(256)
+rate_recover_kernel(const T* __restrict__ llr, int n_tb, int llr_len, RmGeom g, T* __restrict__ circ, T* __restrict__ out) {
+  const int64_t total = (int64_t)n_tb * g.C * g.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % g.N);
+    const int64_t cbi = i / g.N;
+    const int r = (int)(cbi % g.C), t = (int)(cbi / g.C);
+    T v;
+    if (n >= g.sys_len && n < g.sys_len + g.F) {
+      v = (T)1e20;  // LARGE_LLR for filler positions (chancodebase.py:52, ldpc.py:1414-1418)
+    } else {
+      const int ci = n < g.sys_len ? n : n - g.F;
+      v = (T)0;
+      if (ci < g.cs) {  // positions beyond the (LBRM-limited) buffer do not exist; out is N wide only when ncb==N
+        T acc = circ ? circ[cbi * g.cs + ci] : (T)0;
+        // E_r and the offset of block r inside the G-long LLR stream
+        int E, off;
+        if (r < g.n_small) { E = g.e_small; off = r * g.e_small; }
+        else { E = g.e_small + g.f; off = g.n_small * g.e_small + (r - g.n_small) * E; }
+        const int eq = E / g.qm;
+        int e = ci - g.k0;
+        e %= g.cs;
+        if (e < 0) e += g.cs;
+        for (; e < E; e += g.cs) {
+          const int j = (e % eq) * g.qm + e / eq;  // de-interleave: x[e] = rx[(e mod E/qm)*qm + e div (E/qm)]
+          const int src = off + j;
+          acc += (src < llr_len) ? llr[(size_t)t * llr_len + src] : (T)0;  // short input is zero padded
+        }
+        if (circ) circ[cbi * g.cs + ci] = acc;
+        v = acc;
+      }
+    }
+    out[i] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------- nrx_ldpc_crc_merge
+// ldpc.py:1584-1619.  One workgroup per code block.
+__global__ void __launch_bounds__(256)
+crc_merge_kernel(const uint8_t* __restrict__ dec, int C, int K, int cb_len, int B, uint8_t* __restrict__ tb_out,
+                 uint8_t* __restrict__ cb_ok) {
+  __shared__ uint32_t red[16];
+  const int t = blockIdx.x / C, c = blockIdx.x % C;
+  const uint8_t* row = dec + (size_t)blockIdx.x * K;
+  const int payload = C > 1 ? cb_len - 24 : cb_len;
+  if (tb_out) {
+    // merged stream is C*payload >= B bits long; the caller's row holds B of them
+    uint8_t* dst = tb_out + (size_t)t * B;
+    for (int i = threadIdx.x; i < payload; i += blockDim.x) {
+      const int64_t gpos = (int64_t)c * payload + i;
+      if (gpos < B) dst[gpos] = row[i] & 1;
+    }
+  }
+  const uint32_t r = block_crc([&](int64_t i) { return row[i] & 1; }, cb_len, C > 1 ? NRX_CRC24B : NRX_CRC24A, red);
+  if (threadIdx.x == 0) cb_ok[blockIdx.x] = r == 0 ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+crc_ok_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, int poly_id,
+                   uint8_t* __restrict__ ok) {
+  __shared__ uint32_t red[16];
+  const uint8_t* row = bits + (size_t)blockIdx.x * row_stride;
+  const uint32_t r = block_crc([&](int64_t i) { return row[i] & 1; }, row_len, poly_id, red);
+  if (threadIdx.x == 0) ok[blockIdx.x] = r == 0 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------- nrx_count_errors
+__global__ void __launch_bounds__(256)
+count_errors_kernel(const uint8_t* __restrict__ cb_ok, int n_ok, const uint8_t* __restrict__ tb_out,
+                    const uint8_t* __restrict__ tb_ref, int n_tb, int A, int stride, unsigned long long* counters) {
+  unsigned long long be = 0, bits = 0;
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = gtid; i < n_ok; i += gsz) be += cb_ok[i] ? 0 : 1;
+  if (tb_out && tb_ref)
+    for (int64_t i = gtid; i < (int64_t)n_tb * A; i += gsz) {
+      const int t = (int)(i / A), k = (int)(i - (int64_t)t * A);
+      bits += ((tb_out[(size_t)t * stride + k] ^ tb_ref[i]) & 1) ? 1 : 0;
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    be += __shfl_xor(be, o, 64);
+    bits += __shfl_xor(bits, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (be) atomicAdd(&counters[0], be);
+    if (bits) atomicAdd(&counters[2], bits);
+  }
+  if (gtid == 0) {
+    atomicAdd(&counters[1], (unsigned long long)n_ok);
+    if (tb_out && tb_ref) atomicAdd(&counters[3], (unsigned long long)n_tb * A);
+  }
+}
+
+int fill_geom(const nrx_ldpc_cfg* cfg, int G, int nl, int qm, int rv, int n_ref, RmGeom* g) {
+  static const int k0num[2][4] = {{0, 17, 33, 56}, {0, 13, 25, 43}};
+  g->C = cfg->C; g->N = cfg->N; g->K = cfg->K; g->F = cfg->F; g->zc = cfg->Zc;
+  g->ncb = n_ref == 0 ? cfg->N : (cfg->N < n_ref ? cfg->N : n_ref);       // ldpc.py:1138
+  g->sys_len = cfg->K - 2 * cfg->Zc - cfg->F;                             // systematic bits w/o fillers
+  g->cs = g->ncb - cfg->F;
+  g->k0 = (int)(((long)k0num[cfg->bg - 1][rv] * g->ncb / cfg->N) * cfg->Zc);  // ldpc.py:1145
+  g->f = nl * qm;
+  const int gb = (G + g->f - 1) / g->f;
+  g->e_small = (gb / cfg->C) * g->f;
+  g->n_small = cfg->C - gb % cfg->C;
+  g->G = G; g->qm = qm;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int32_t nrx_crc(const uint8_t* bits, int32_t n_rows, int64_t row_len, int64_t row_stride, int32_t poly_id,
+                           uint8_t* crc_out, void* stream) {
+  NRX_REQUIRE(bits && crc_out, NRX_E_ARG, "nrx_crc: NULL buffer");
+  NRX_REQUIRE(poly_id >= NRX_CRC6 && poly_id <= NRX_CRC24C, NRX_E_ARG, "nrx_crc: unknown polynomial id %d", poly_id);
+  NRX_REQUIRE(n_rows >= 0 && row_len >= 0 && row_stride >= row_len, NRX_E_SHAPE, "nrx_crc: bad row geometry");
+  if (n_rows == 0) return NRX_OK;
+  hipLaunchKernelGGL(crc_rows_kernel, dim3(n_rows), dim3(row_len > 4096 ? 256 : 64), 0, (hipStream_t)stream, bits,
+                     row_len, row_stride, poly_id, crc_out);
+  NRX_CHECK_LAUNCH("nrx_crc");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_ldpc_segment(const uint8_t* tb, int32_t n_tb, int32_t A, int32_t add_tb_crc,
+                                    const nrx_ldpc_cfg* cfg, uint8_t* cbs, void* stream) {
+  NRX_REQUIRE(tb && cfg && cbs, NRX_E_ARG, "nrx_ldpc_segment: NULL buffer");
+  NRX_REQUIRE(n_tb >= 0 && A > 0, NRX_E_ARG, "nrx_ldpc_segment: bad sizes");
+  NRX_REQUIRE(cfg->B == A + (add_tb_crc ? 24 : 0), NRX_E_SHAPE, "nrx_ldpc_segment: cfg->B (%d) != A (%d) + TB CRC",
+              cfg->B, A);
+  if (n_tb == 0) return NRX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(segment_kernel, dim3(n_tb * cfg->C), dim3(256), 0, st, tb, add_tb_crc, A, cfg->B, cfg->C, cfg->K,
+                     cfg->cb_len, cbs);
+  NRX_CHECK_LAUNCH("nrx_ldpc_segment");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_ldpc_encode(const uint8_t* cbs, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t puncture,
+                                   uint8_t* coded, void* stream) {
+  NRX_REQUIRE(cbs && cfg && coded, NRX_E_ARG, "nrx_ldpc_encode: NULL buffer");
+  NRX_REQUIRE(cfg->bg == 1 || cfg->bg == 2, NRX_E_ARG, "nrx_ldpc_encode: bg must be 1|2");
+  NRX_REQUIRE(cfg->Zc >= 2 && cfg->Zc <= ZMAX && cfg->iLS >= 0 && cfg->iLS < 8, NRX_E_ARG, "nrx_ldpc_encode: bad Zc/iLS");
+  NRX_REQUIRE(n_cb >= 0, NRX_E_ARG, "nrx_ldpc_encode: negative count");
+  if (n_cb == 0) return NRX_OK;
+  EncTab tab;
+  memset(&tab, 0, sizeof(tab));
+  const int E = cfg->bg == 1 ? NRX_BG1_EDGES : NRX_BG2_EDGES;
+  for (int e = 0; e < E; ++e)
+    tab.s[e] = (int16_t)((cfg->bg == 1 ? kBg1Shift[cfg->iLS][e] : kBg2Shift[cfg->iLS][e]) % cfg->Zc);
+  const int threads = ((cfg->Zc + 63) / 64) * 64;
+  if (cfg->bg == 1)
+    hipLaunchKernelGGL(encode_kernel<1>, dim3(n_cb), dim3(threads), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+  else
+    hipLaunchKernelGGL(encode_kernel<2>, dim3(n_cb), dim3(threads), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+  NRX_CHECK_LAUNCH("nrx_ldpc_encode");
+  return NRX_OK;
+}
+
+static int32_t check_rm_args(const char* who, const nrx_ldpc_cfg* cfg, int G, int nl, int qm, int rv) {
+  NRX_REQUIRE(cfg, NRX_E_ARG, "%s: NULL cfg", who);
+  NRX_REQUIRE(rv >= 0 && rv <= 3, NRX_E_ARG, "%s: Invalid 'rv' value! It must be one of 0, 1, 2, or 3.", who);
+  NRX_REQUIRE(nl >= 1 && qm >= 1 && G > 0, NRX_E_ARG, "%s: bad G/nl/qm", who);
+  const int f = nl * qm;
+  const int gb = (G + f - 1) / f;
+  NRX_REQUIRE(gb / cfg->C > 0, NRX_E_SHAPE, "%s: G=%d too small for %d code blocks", who, G, cfg->C);
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_ldpc_rate_match(const uint8_t* coded, int32_t n_tb, const nrx_ldpc_cfg* cfg, int32_t G,
+                                       int32_t nl, int32_t qm, int32_t rv, int32_t n_ref, uint8_t* out, void* stream) {
+  NRX_REQUIRE(coded && out, NRX_E_ARG, "nrx_ldpc_rate_match: NULL buffer");
+  int32_t rc = check_rm_args("nrx_ldpc_rate_match", cfg, G, nl, qm, rv);
+  if (rc) return rc;
+  if (n_tb == 0) return NRX_OK;
+  RmGeom g;
+  fill_geom(cfg, G, nl, qm, rv, n_ref, &g);
+  g.G = ((G + nl * qm - 1) / (nl * qm)) * (nl * qm);  // = sum of E_r (ldpc.py:852-855); equals G for PDSCH
+  hipLaunchKernelGGL(rate_match_kernel, dim3(nrx::stream_grid((long)n_tb * g.G, 256)), dim3(256), 0, (hipStream_t)stream,
+                     coded, n_tb, g, out);
+  NRX_CHECK_LAUNCH("nrx_ldpc_rate_match");
+  return NRX_OK;
+}
+
+template <typename T>
+static int32_t rate_recover_entry(const T* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
+                                  int32_t qm, int32_t rv, int32_t n_ref, T* circ, T* out, void* stream) {
+  NRX_REQUIRE(llr && out, NRX_E_ARG, "nrx_ldpc_rate_recover: NULL buffer");
+  int32_t rc = check_rm_args("nrx_ldpc_rate_recover", cfg, llr_len, nl, qm, rv);
+  if (rc) return rc;
+  if (n_tb == 0) return NRX_OK;
+  RmGeom g;
+  fill_geom(cfg, llr_len, nl, qm, rv, n_ref, &g);
+  hipLaunchKernelGGL(rate_recover_kernel<T>, dim3(nrx::stream_grid((long)n_tb * cfg->C * cfg->N, 256)), dim3(256), 0,
+                     (hipStream_t)stream, llr, n_tb, llr_len, g, circ, out);
+  NRX_CHECK_LAUNCH("nrx_ldpc_rate_recover");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_ldpc_rate_recover_f32(const float* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                             int32_t nl, int32_t qm, int32_t rv, int32_t n_ref, float* circ, float* out,
+                                             void* stream) {
+  return rate_recover_entry<float>(llr, n_tb, llr_len, cfg, nl, qm, rv, n_ref, circ, out, stream);
+}
+extern "C" int32_t nrx_ldpc_rate_recover_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                             int32_t nl, int32_t qm, int32_t rv, int32_t n_ref, double* circ,
+                                             double* out, void* stream) {
+  return rate_recover_entry<double>(llr, n_tb, llr_len, cfg, nl, qm, rv, n_ref, circ, out, stream);
+}
+
+extern "C" int32_t nrx_ldpc_crc_merge(const uint8_t* dec, int32_t n_tb, const nrx_ldpc_cfg* cfg, uint8_t* tb_out,
+                                      uint8_t* cb_ok, uint8_t* tb_ok, void* stream) {
+  NRX_REQUIRE(dec && cfg && cb_ok, NRX_E_ARG, "nrx_ldpc_crc_merge: NULL buffer");
+  NRX_REQUIRE(!tb_ok || tb_out, NRX_E_ARG, "nrx_ldpc_crc_merge: tb_ok needs tb_out");
+  if (n_tb == 0) return NRX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(crc_merge_kernel, dim3(n_tb * cfg->C), dim3(cfg->cb_len > 4096 ? 256 : 64), 0, st, dec, cfg->C,
+                     cfg->K, cfg->cb_len, cfg->B, tb_out, cb_ok);
+  if (tb_ok)
+    hipLaunchKernelGGL(crc_ok_rows_kernel, dim3(n_tb), dim3(cfg->B > 4096 ? 256 : 64), 0, st, tb_out, (int64_t)cfg->B,
+                       (int64_t)cfg->B, NRX_CRC24A, tb_ok);
+  NRX_CHECK_LAUNCH("nrx_ldpc_crc_merge");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_count_errors(const uint8_t* cb_ok, int32_t n_ok, const uint8_t* tb_out, const uint8_t* tb_ref,
+                                    int32_t n_tb, int32_t A, int32_t tb_out_stride, int64_t* counters, void* stream) {
+  NRX_REQUIRE(cb_ok && counters, NRX_E_ARG, "nrx_count_errors: NULL buffer");
+  NRX_REQUIRE((tb_out == nullptr) == (tb_ref == nullptr), NRX_E_ARG, "nrx_count_errors: tb_out and tb_ref go together");
+  NRX_REQUIRE(!tb_out || tb_out_stride >= A, NRX_E_SHAPE, "nrx_count_errors: stride < A");
+  const long work = (long)n_tb * A > n_ok ? (long)n_tb * A : n_ok;
+  hipLaunchKernelGGL(count_errors_kernel, dim3(nrx::stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, cb_ok,
+                     n_ok, tb_out, tb_ref, n_tb, A, tb_out_stride, (unsigned long long*)counters);
+  NRX_CHECK_LAUNCH("nrx_count_errors");
+  return NRX_OK;
+}

@@ -1,0 +1,143 @@
+"""GPU parity: LDPC/CRC chain through the C ABI (neoradium_amd.ops) vs the NumPy oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from oracle import coding as oc
+
+pytestmark = pytest.mark.gpu
+
+# (bg, A, G, nl, qm, rv)  -- sizes the NumPy oracle finishes in seconds
+CASES = [
+    (1, 10000, 22808, 1, 2, 0),     # the reference's MATLAB case: C=2, Zc=240, iLS=7, F=244
+    (2, 2408, 7800, 1, 2, 0),       # BASELINE cfg1: C=1, Zc=256
+    (1, 30216, 63648, 2, 4, 0),     # PDSCH-BLER notebook: C=4, Zc=352
+    (2, 3817, 12000, 1, 6, 2),      # BG2 two blocks, rv=2
+    (1, 800, 2400, 2, 4, 3),        # small Zc=40, rv=3
+    (2, 100, 600, 1, 2, 1),         # Zc=22 (< one wavefront)
+    (1, 25344 * 2, 3 * 13104 * 2, 4, 6, 0),   # Zc=384 (the metric's lifting size), C=7
+]
+
+
+def _t(x, dev, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.mark.parametrize("bg,A,G,nl,qm,rv", CASES)
+def test_tx_chain_bit_exact(dev, bg, A, G, nl, qm, rv):
+    from neoradium_amd import ops, _lib
+    rng = np.random.default_rng(A + rv)
+    n_tb = 3
+    tb = rng.integers(0, 2, (n_tb, A)).astype(np.uint8)
+    cfg = _lib.ldpc_config(bg, A + 24)
+    ref = [oc.encode_chain(tb[i], bg, G, nl, qm, rv) for i in range(n_tb)]
+    p = ref[0][1]['p']
+    assert (cfg.C, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F) == (p.C, p.Zc, p.iLS, p.K, p.N, p.F)
+    cbs = ops.ldpc_segment(_t(tb, dev), cfg)
+    assert np.array_equal(cbs.cpu().numpy().reshape(n_tb, p.C, p.K), np.stack([r[1]['cbs'] for r in ref]))
+    coded = ops.ldpc_encode(cbs, cfg)
+    assert np.array_equal(coded.cpu().numpy().reshape(n_tb, p.C, p.N), np.stack([r[1]['coded'] for r in ref]))
+    full = ops.ldpc_encode(cbs, cfg, puncture=False)
+    assert np.array_equal(full.cpu().numpy()[:, 2 * p.Zc:], coded.cpu().numpy())
+    rm = ops.ldpc_rate_match(coded, cfg, G, nl, qm, rv)
+    assert np.array_equal(rm.cpu().numpy(), np.stack([r[0] for r in ref]))
+    # CRC primitive on the raw TBs
+    crc = ops.crc(_t(tb, dev), '24A')
+    assert np.array_equal(crc.cpu().numpy(), oc.crc_bits(tb, '24A'))
+
+
+@pytest.mark.parametrize("bg,A,G,nl,qm,rv", CASES)
+def test_rx_chain(dev, bg, A, G, nl, qm, rv):
+    import torch
+    from neoradium_amd import ops, _lib
+    rng = np.random.default_rng(7 * A + rv)
+    n_tb = 2
+    tb = rng.integers(0, 2, (n_tb, A)).astype(np.uint8)
+    cfg = _lib.ldpc_config(bg, A + 24)
+    n_iter = 8
+    llrs, refs = [], []
+    for i in range(n_tb):
+        rm, d = oc.encode_chain(tb[i], bg, G, nl, qm, rv)
+        p = d['p']
+        hi_rate = A / G > 0.5
+        # slot 0 decodes cleanly, slot 1 sits near/below the waterfall
+        sigma = (0.5 if hi_rate else 0.75) if i == 0 else (0.74 if hi_rate else 1.15)
+        llr = (1 - 2.0 * rm) * 2 / sigma ** 2 + rng.normal(0, 2 / sigma, len(rm))
+        llrs.append(llr)
+        rr, _ = oc.rate_recover(llr, p, nl, qm, rv)
+        bel = oc.decode(rr, bg, p.iLS, p.Zc, n_iter, only_info=False, belief=True)
+        refs.append((rr, bel))
+    llr64 = _t(np.stack(llrs), dev)
+    # rate recovery: bit-identical float64 (incl. 1e20 fillers), float32 = rounded inputs
+    rr64 = ops.ldpc_rate_recover(llr64, cfg, nl, qm, rv)
+    assert np.array_equal(rr64.cpu().numpy().reshape(n_tb, p.C, p.N), np.stack([r[0] for r in refs]))
+    rr32 = ops.ldpc_rate_recover(llr64.float(), cfg, nl, qm, rv)
+    # float64 decoder: beliefs bit-exact with the reference arithmetic, all columns
+    bel64 = ops.ldpc_decode(rr64, cfg, n_iter, only_info=False, belief=True).cpu().numpy()
+    ref_bel = np.concatenate([r[1] for r in refs])
+    assert np.array_equal(bel64, ref_bel), f"max diff {np.abs(bel64 - ref_bel).max()}"
+    hard64 = ops.ldpc_decode(rr64, cfg, n_iter).cpu().numpy()
+    assert np.array_equal(hard64, (ref_bel[:, :p.K] < 0).astype(np.uint8))
+    # CRC + merge
+    tb_out, cb_ok, tb_ok = ops.ldpc_crc_merge(_t(hard64, dev), cfg)
+    for i in range(n_tb):
+        o, c = oc.crc_check_and_merge(hard64[i * p.C:(i + 1) * p.C], p)
+        assert np.array_equal(cb_ok[i].cpu().numpy().astype(bool), c)
+        assert np.array_equal(tb_out[i].cpu().numpy()[:len(o)][:p.B], o[:p.B])
+        assert bool(tb_ok[i]) == bool(oc.crc_check(o[:p.B], '24A'))
+    assert cb_ok[0].all() and np.array_equal(tb_out[0, :A].cpu().numpy(), tb[0])
+    # float32 decoder: same CRC verdicts; identical hard bits and <=1e-5 (relative to the block's LLR scale)
+    # beliefs on blocks that converged
+    bel32 = ops.ldpc_decode(rr32, cfg, n_iter, only_info=False, belief=True).cpu().numpy().astype(np.float64)
+    hard32 = ops.ldpc_decode(rr32, cfg, n_iter).cpu().numpy()
+    _, cb_ok32, _ = ops.ldpc_crc_merge(_t(hard32, dev), cfg)
+    assert np.array_equal(cb_ok32.cpu().numpy(), cb_ok.cpu().numpy())
+    ok = cb_ok.cpu().numpy().reshape(-1).astype(bool)
+    assert ok.any()
+    assert np.array_equal(hard32[ok], hard64[ok])
+    nf = np.ones(ref_bel.shape[1], bool)
+    nf[p.K - p.F:p.K] = False                   # filler columns carry +-1e10
+    for b in np.nonzero(ok)[0]:
+        scale = np.abs(ref_bel[b, nf]).max()
+        assert np.abs(bel32[b, nf] - ref_bel[b, nf]).max() <= 1e-5 * scale
+    # counters
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    ops.count_errors(cb_ok, tb_out, _t(tb, dev), counters)
+    c = counters.cpu().numpy()
+    assert c[0] == (~ok).sum() and c[1] == ok.size and c[3] == n_tb * A
+    assert c[2] == (tb_out[:, :A].cpu().numpy() != tb).sum()
+
+
+def test_harq_soft_combining(dev):
+    """recoverRate with a HARQ buffer (ldpc.py:1377-1412): 4 redundancy versions accumulate in place."""
+    from neoradium_amd import ops, _lib
+    bg, A, G, nl, qm = 1, 10000, 20900, 1, 4
+    rng = np.random.default_rng(5)
+    tb = rng.integers(0, 2, A).astype(np.uint8)
+    cfg = _lib.ldpc_config(bg, A + 24)
+    circ_ref, circ_dev = None, None
+    for rv in (0, 2, 3, 1):
+        rm, d = oc.encode_chain(tb, bg, G, nl, qm, rv)
+        p = d['p']
+        llr = (1 - 2.0 * rm) + rng.normal(0, 1.2, len(rm))
+        rr_ref, circ_ref = oc.rate_recover(llr, p, nl, qm, rv, circ=circ_ref)
+        if circ_dev is None:
+            import torch
+            circ_dev = torch.zeros((p.C, p.N - p.F), dtype=torch.float64, device=dev)
+        rr = ops.ldpc_rate_recover(_t(llr[None], dev), cfg, nl, qm, rv, circ=circ_dev)
+        assert np.array_equal(rr.cpu().numpy(), rr_ref)
+        assert np.array_equal(circ_dev.cpu().numpy(), circ_ref)
+
+
+def test_errors_are_valueerrors(dev):
+    import torch
+    from neoradium_amd import ops, _lib
+    cfg = _lib.ldpc_config(1, 10024)
+    with pytest.raises(ValueError):
+        _lib.ldpc_config(3, 100)
+    coded = torch.zeros((cfg.C, cfg.N), dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        ops.ldpc_rate_match(coded, cfg, 22808, 1, 2, rv=4)      # ldpc.py:1131
+    with pytest.raises(ValueError):
+        ops.ldpc_decode(torch.zeros((2, 17), device=dev), cfg)
