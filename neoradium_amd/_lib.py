@@ -44,6 +44,31 @@ SIGNATURES = {
     'nrx_ldpc_crc_merge': (i32, [vp, i32, _cfgp, vp, vp, vp, vp]),
     'nrx_count_errors': (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
 }
+f64 = C.c_double
+u64_ = C.c_uint64
+_i32p = C.POINTER(i32)
+for _t in ('f32', 'f64'):
+    SIGNATURES.update({
+        'nrx_qam_map_' + _t: (i32, [vp, i64, vp, i32, vp, i32, vp, i64, i32, vp]),
+        'nrx_precode_' + _t: (i32, [vp, vp, i64, i32, i32, i32, vp, i32, vp]),
+        'nrx_apply_channel_fd_' + _t: (i32, [vp, vp, i64, i32, i32, i32, vp, i32, vp]),
+        'nrx_mmse_equalize_' + _t: (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
+        'nrx_noise_level_' + _t: (i32, [vp, i64, i64, vp, i64, i32, vp, vp, vp, i32, f64, vp, vp, f64, vp]),
+        'nrx_add_noise_' + _t: (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
+        'nrx_awgn_' + _t: (i32, [vp, vp, i32, i64, vp, i32, u64_, u64_, i64, vp]),
+        'nrx_ofdm_modulate_' + _t: (i32, [vp, i32, i32, i32, _i32p, i32, i32, vp, i64, vp]),
+        'nrx_ofdm_demodulate_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, vp, vp]),
+        'nrx_chest_ls_' + _t: (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    })
+for _t in ('f32', 'f64', 'f64o32'):
+    SIGNATURES['nrx_qam_demap_' + _t] = (i32, [vp, i64, vp, vp, i32, vp, i32, vp, i32, vp, i64, i32, i32, f64, vp])
+SIGNATURES.update({
+    'nrx_cdl_gains_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'nrx_cir_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'nrx_channel_matrix_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
+    'nrx_apply_td_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, _i32p, vp, vp]),
+})
+_unused = {}
 
 _lib = None
 

@@ -1,0 +1,279 @@
+// Tapped-delay-line channel (CDL/TDL): per-slot path gains, discrete CIR, frequency-domain channel matrix and
+// the time-domain filtering of the transmit waveform (gfx950, float64).
+//
+// Replaces reference cdl.py:641-645,741-811,672-738,871-887 (CdlChannel.getPathGains: the time-varying part
+// of TR 38.901 Eq 7.5-22/-29), channelmodel.py:321-354 (prepareForNextSlot: CIR + chanOffset),
+// :362-400 (getChannelMatrix), :403-448 (applyToSignal).
+#include "nrx_common.h"
+#include "nrx_fft.h"
+
+namespace {
+using nrx::cx;
+typedef cx<double> cd;
+
+// ---------------------------------------------------------------------------------------------- CDL gains
+// gains[b][t][rt][p]:  NLOS cluster n:  sum_m A[rt][n][m] * exp(j*2*pi*time[b][t]*nu[n][m])
+//                      LOS (p = 0 when present):  Alos[rt] * exp(j*2*pi*time*nu_los)
+// A already contains the field/polarisation/location terms, sqrt(P_n/M) and the output normalisations
+// (channelmodel.py:451-469): everything that does not depend on time.
+__global__ void __launch_bounds__(256)
+cdl_gains_kernel(const cd* __restrict__ A, const double* __restrict__ nu, const cd* __restrict__ Alos, double nu_los,
+                 const double* __restrict__ times, int n_t, int n_rt, int n_cl, int n_ray, cd* __restrict__ gains) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cd* ph = (cd*)smem;  // [n_cl*n_ray] Doppler phasors of this (item, instant)
+  const int bt = blockIdx.x;  // item * n_t + instant
+  const double t = times[bt];
+  for (int i = threadIdx.x; i < n_cl * n_ray; i += blockDim.x) {
+    double s, c;
+    sincos((6.283185307179586 * t) * nu[i], &s, &c);  // cdl.py:887 exp(2j*pi*t*nu)
+    ph[i] = cd(c, s);
+  }
+  __syncthreads();
+  const int P = n_cl + (Alos ? 1 : 0);
+  for (int o = threadIdx.x; o < n_rt * P; o += blockDim.x) {
+    const int rt = o / P, p = o - rt * P;
+    cd acc(0, 0);
+    if (Alos && p == 0) {
+      double s, c;
+      sincos((6.283185307179586 * t) * nu_los, &s, &c);
+      acc = Alos[rt] * cd(c, s);
+    } else {
+      const int n = p - (Alos ? 1 : 0);
+      const cd* a = A + ((size_t)rt * n_cl + n) * n_ray;
+      for (int m = 0; m < n_ray; ++m) nrx::cmac(acc, a[m], ph[n * n_ray + m]);
+    }
+    gains[((size_t)bt * n_rt + rt) * P + p] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- CIR
+// cir[b][t][rt][l] = sum_p gains[b][t][rt][p] * coeff[p][l]   (channelmodel.py:343)
+__global__ void __launch_bounds__(256)
+cir_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff, int n_p, int cl, int64_t n_rows,
+           cd* __restrict__ cir) {
+  const int64_t total = n_rows * cl;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = g / cl;
+    const int l = (int)(g - row * cl);
+    const cd* gr = gains + (size_t)row * n_p;
+    cd acc(0, 0);
+    for (int p = 0; p < n_p; ++p) {
+      const double c = coeff[(size_t)p * cl + l];
+      acc.re += gr[p].re * c;
+      acc.im += gr[p].im * c;
+    }
+    cir[g] = acc;
+  }
+}
+
+// chanOffset[b] = argmax_l sum_r | sum_{c<nc, t} cir[b][c][r][t][l] |   (channelmodel.py:345-346; first max)
+__global__ void __launch_bounds__(256)
+chan_offset_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int nr, int nt, int cl, int32_t* __restrict__ off) {
+  __shared__ double bestv[256];
+  __shared__ int besti[256];
+  const int b = blockIdx.x;
+  const cd* base = cir + (size_t)b * n_t_total * nr * nt * cl;
+  double bv = -1.0;
+  int bi = 0;
+  for (int l = threadIdx.x; l < cl; l += blockDim.x) {
+    double tot = 0;
+    for (int r = 0; r < nr; ++r) {
+      cd s(0, 0);
+      for (int c = 0; c < nc; ++c)
+        for (int t = 0; t < nt; ++t) s = s + base[(((size_t)c * nr + r) * nt + t) * cl + l];
+      tot += hypot(s.re, s.im);
+    }
+    if (tot > bv) { bv = tot; bi = l; }
+  }
+  bestv[threadIdx.x] = bv;
+  besti[threadIdx.x] = bi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = -1.0;
+    int idx = 0;
+    for (int i = 0; i < blockDim.x; ++i)
+      if (bestv[i] > v || (bestv[i] == v && besti[i] < idx)) { v = bestv[i]; idx = besti[i]; }
+    off[b] = idx;
+  }
+}
+
+// ----------------------------------------------------------------------------------------- channel matrix
+// H[b][c][k][rt] = FFT_nfft( cir[b][c][rt][.] circularly advanced by chanOffset )[(k - K/2) mod nfft]
+// (channelmodel.py:381-399).  One LDS FFT per (b, c, rt); workgroups loop over tasks.
+__global__ void __launch_bounds__(256)
+chan_matrix_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int n_rt, int cl, const int32_t* __restrict__ off,
+                   int K, int nfft, int log2n, cd* __restrict__ H, int n_tasks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cd* buf = (cd*)smem;
+  cd* tw = buf + nfft;
+  nrx::fft_fill_twiddles(tw, nfft);
+  for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    const int rt = task % n_rt;
+    const int c = (task / n_rt) % nc;
+    const int b = task / (n_rt * nc);
+    const cd* src = cir + (((size_t)b * n_t_total + c) * n_rt + rt) * cl;
+    const int o = off[b];
+    const int use = cl < nfft ? cl : nfft;  // longer responses are truncated (channelmodel.py:384-388)
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfft; i += blockDim.x) buf[i] = cd(0, 0);
+    __syncthreads();
+    for (int l = threadIdx.x; l < use; l += blockDim.x) buf[(l - o + nfft) & (nfft - 1)] = src[l];
+    __syncthreads();
+    nrx::fft_dif_lds(buf, tw, nfft, log2n, false);
+    cd* dst = H + (((size_t)b * nc + c) * K) * n_rt + rt;
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+      dst[(size_t)k * n_rt] = buf[nrx::fft_bitrev((k - K / 2 + nfft) & (nfft - 1), log2n)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ applyToSignal
+// y[b][r][n] = sum_t sum_l cir1[b][sym(n)][r][t][l] * x[b][t][n-l]   (zero state before the slot)
+// which is what the reference's per-path lfilter + per-symbol gain mix evaluates (channelmodel.py:431-447):
+// gains are piecewise constant per OUTPUT symbol (whole-symbol lengths, the extra (nc+1)-th set beyond the slot).
+// Workgroup = one tile of TILE output samples inside ONE symbol, so the CIR is workgroup-uniform (scalar
+// loads); the input tile (+cl-1 history) of all Nt antennas is staged in LDS.
+struct TdGeom {
+  int32_t n_sets;     // nc + 1
+  int32_t start[17];  // first output sample of each gain set; start[n_sets] = ns
+  int32_t tiles_per_set;
+};
+constexpr int TD_TILE = 256;
+
+template <int NR>
+__global__ void __launch_bounds__(TD_TILE)
+apply_td_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ cir1, int cl, TdGeom g,
+                cd* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cd* xs = (cd*)smem;  // [nt][TD_TILE + cl - 1]
+  const int b = blockIdx.y;
+  const int set = blockIdx.x / g.tiles_per_set, tile = blockIdx.x % g.tiles_per_set;
+  const int n0 = g.start[set] + tile * TD_TILE;
+  const int n_end = g.start[set + 1];
+  if (n0 >= n_end) return;
+  const int span = TD_TILE + cl - 1;
+  for (int i = threadIdx.x; i < nt * span; i += blockDim.x) {
+    const int t = i / span, j = i - t * span;
+    const int64_t n = (int64_t)n0 - (cl - 1) + j;
+    xs[i] = (n >= 0 && n < ns) ? x[((size_t)b * nt + t) * ns + n] : cd(0, 0);
+  }
+  __syncthreads();
+  const int n = n0 + threadIdx.x;
+  if (n >= n_end) return;
+  cd acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = cd(0, 0);
+  const cd* cb = cir1 + ((size_t)b * g.n_sets + set) * NR * nt * cl;
+  for (int t = 0; t < nt; ++t) {
+    const cd* xr = xs + t * span + (cl - 1) + threadIdx.x;
+    for (int l = 0; l < cl; ++l) {
+      const cd xv = xr[-l];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) nrx::cmac(acc[r], cb[((size_t)r * nt + t) * cl + l], xv);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) y[((size_t)b * NR + r) * ns + n] = acc[r];
+}
+
+int ilog2(int n) {
+  int l = 0;
+  while ((1 << l) < n) ++l;
+  return l;
+}
+
+}  // namespace
+
+extern "C" int32_t nrx_cdl_gains_f64(const void* A, const double* nu, const void* A_los, double nu_los,
+                                     const double* times, int32_t n_items, int32_t n_t, int32_t n_rx, int32_t n_tx,
+                                     int32_t n_clusters, int32_t n_rays, void* gains, void* stream) {
+  NRX_REQUIRE(A && nu && times && gains, NRX_E_ARG, "nrx_cdl_gains: NULL buffer");
+  NRX_REQUIRE(n_t >= 1 && n_rx >= 1 && n_tx >= 1 && n_clusters >= 1 && n_rays >= 1 && n_items >= 0, NRX_E_ARG,
+              "nrx_cdl_gains: bad sizes");
+  if (n_items == 0) return NRX_OK;
+  const size_t lds = sizeof(cd) * (size_t)n_clusters * n_rays;
+  NRX_REQUIRE(lds <= 64 * 1024, NRX_E_UNSUPPORTED, "nrx_cdl_gains: too many rays (%d x %d)", n_clusters, n_rays);
+  hipLaunchKernelGGL(cdl_gains_kernel, dim3(n_items * n_t), dim3(256), lds, (hipStream_t)stream, (const cd*)A, nu,
+                     (const cd*)A_los, nu_los, times, n_t, n_rx * n_tx, n_clusters, n_rays, (cd*)gains);
+  NRX_CHECK_LAUNCH("nrx_cdl_gains");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_cir_f64(const void* gains, const double* coeff, int32_t n_items, int32_t n_t, int32_t nc,
+                               int32_t n_rx, int32_t n_tx, int32_t n_paths, int32_t cl, void* cir, int32_t* chan_offset,
+                               void* stream) {
+  NRX_REQUIRE(gains && coeff && cir, NRX_E_ARG, "nrx_cir: NULL buffer");
+  NRX_REQUIRE(n_t >= 1 && nc >= 1 && nc <= n_t && n_rx >= 1 && n_tx >= 1 && n_paths >= 1 && cl >= 1 && n_items >= 0,
+              NRX_E_ARG, "nrx_cir: bad sizes");
+  if (n_items == 0) return NRX_OK;
+  const int64_t rows = (int64_t)n_items * n_t * n_rx * n_tx;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cir_kernel, dim3(nrx::stream_grid(rows * cl, 256)), dim3(256), 0, st, (const cd*)gains, coeff,
+                     n_paths, cl, rows, (cd*)cir);
+  if (chan_offset)
+    hipLaunchKernelGGL(chan_offset_kernel, dim3(n_items), dim3(256), 0, st, (const cd*)cir, n_t, nc, n_rx, n_tx, cl,
+                       chan_offset);
+  NRX_CHECK_LAUNCH("nrx_cir");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_channel_matrix_f64(const void* cir, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx,
+                                          int32_t n_tx, int32_t cl, const int32_t* chan_offset, int32_t K, int32_t nfft,
+                                          void* H, void* stream) {
+  NRX_REQUIRE(cir && chan_offset && H, NRX_E_ARG, "nrx_channel_matrix: NULL buffer");
+  NRX_REQUIRE(nfft >= 64 && nfft <= 8192 && (nfft & (nfft - 1)) == 0, NRX_E_ARG, "nrx_channel_matrix: nfft must be a power of two");
+  NRX_REQUIRE(K > 0 && K <= nfft && nc >= 1 && nc <= n_t && cl >= 1, NRX_E_SHAPE, "nrx_channel_matrix: bad sizes");
+  const int n_tasks = n_items * nc * n_rx * n_tx;
+  if (n_tasks == 0) return NRX_OK;
+  const size_t lds = sizeof(cd) * ((size_t)nfft + nfft / 2);
+  (void)hipFuncSetAttribute((const void*)chan_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(chan_matrix_kernel, dim3(n_tasks < 1024 ? n_tasks : 1024), dim3(256), lds, (hipStream_t)stream,
+                     (const cd*)cir, n_t, nc, n_rx * n_tx, cl, chan_offset, K, nfft, ilog2(nfft), (cd*)H, n_tasks);
+  NRX_CHECK_LAUNCH("nrx_channel_matrix");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_apply_td_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* cir1,
+                                    int32_t n_sets, int32_t n_rx, int32_t cl, const int32_t* set_lens, void* y,
+                                    void* stream) {
+  NRX_REQUIRE(x && cir1 && set_lens && y, NRX_E_ARG, "nrx_apply_td: NULL buffer");
+  NRX_REQUIRE(n_sets >= 1 && n_sets <= 16 && n_tx >= 1 && cl >= 1 && ns > 0 && n_items >= 0, NRX_E_ARG, "nrx_apply_td: bad sizes");
+  NRX_REQUIRE(n_rx == 1 || n_rx == 2 || n_rx == 4 || n_rx == 8, NRX_E_UNSUPPORTED, "nrx_apply_td: Nr must be 1, 2, 4 or 8 (got %d)", n_rx);
+  if (n_items == 0) return NRX_OK;
+  TdGeom g;
+  g.n_sets = n_sets;
+  int64_t s = 0;
+  int maxlen = 0;
+  for (int i = 0; i < n_sets; ++i) {
+    g.start[i] = (int32_t)(s < ns ? s : ns);
+    s += set_lens[i];
+  }
+  g.start[n_sets] = (int32_t)ns;  // samples past the listed symbols keep the last gain set (channelmodel.py:443-446)
+  for (int i = 0; i < n_sets; ++i) {
+    const int len = g.start[i + 1] - g.start[i];
+    maxlen = len > maxlen ? len : maxlen;
+  }
+  // when ns is shorter than the listed symbols, trailing sets are empty: start[i] == ns
+  for (int i = 1; i < n_sets; ++i)
+    if (g.start[i] > g.start[n_sets]) g.start[i] = g.start[n_sets];
+  g.tiles_per_set = (maxlen + TD_TILE - 1) / TD_TILE;
+  if (g.tiles_per_set < 1) g.tiles_per_set = 1;
+  const size_t lds = sizeof(cd) * (size_t)n_tx * (TD_TILE + cl - 1);
+  NRX_REQUIRE(lds <= 160 * 1024, NRX_E_UNSUPPORTED, "nrx_apply_td: Nt*cl too large for LDS staging (%zu B)", lds);
+  const dim3 grid(g.tiles_per_set * n_sets, n_items);
+  hipStream_t st = (hipStream_t)stream;
+#define NRX_TD_CASE(NR)                                                                                             \
+  case NR:                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)apply_td_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(apply_td_kernel<NR>, grid, dim3(TD_TILE), lds, st, (const cd*)x, n_tx, ns, (const cd*)cir1, cl, g, \
+                       (cd*)y);                                                                                     \
+    break;
+  switch (n_rx) {
+    NRX_TD_CASE(1)
+    NRX_TD_CASE(2)
+    NRX_TD_CASE(4)
+    NRX_TD_CASE(8)
+  }
+#undef NRX_TD_CASE
+  NRX_CHECK_LAUNCH("nrx_apply_td");
+  return NRX_OK;
+}

@@ -1,0 +1,385 @@
+// Per-resource-element grid stages (gfx950): precoding, frequency-domain channel, MMSE equalisation,
+// complex variance (noise scaling), AWGN.  One RE per lane, float64 arithmetic inside; no MFMA -- the
+// matrices are 1x1 .. 8x8 per RE, not a contraction.
+//
+// Replaces reference grid.py:456-518 (precode), :978-1018 (applyChannel), :626-694 (equalize),
+// :1040-1046 (getNoiseStd -> np.var), :1049-1187 + waveform.py:145-292 (addNoise), random.py:203 (awgn).
+#include "nrx_common.h"
+#include "nrx_cplx.h"
+
+namespace {
+using nrx::cx;
+typedef cx<double> cd;
+
+// ------------------------------------------------------------------------------------------------ precode
+// out[b][t][lk] = sum_n F[b][t][n] * grid[b][n][lk]            (wideband Nt x Nl precoder, grid.py:505-516)
+template <typename T>
+__global__ void __launch_bounds__(256)
+precode_kernel(const cx<T>* __restrict__ grid, const cx<T>* __restrict__ f, int64_t f_stride, int nl, int nt, int lk,
+               cx<T>* __restrict__ out, int n_batch) {
+  const int64_t total = (int64_t)n_batch * lk;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / lk), i = (int)(g - (int64_t)b * lk);
+    cd x[8];
+    for (int n = 0; n < nl; ++n) x[n] = cd(grid[((size_t)b * nl + n) * lk + i]);
+    const cx<T>* fb = f + (size_t)b * f_stride;
+    for (int t = 0; t < nt; ++t) {
+      cd acc(0, 0);
+      for (int n = 0; n < nl; ++n) nrx::cmac(acc, cd(fb[t * nl + n]), x[n]);
+      out[((size_t)b * nt + t) * lk + i] = cx<T>(acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ applyChannel
+// out[b][r][lk] = sum_t H[b][lk][r][t] * grid[b][t][lk]        (grid.py:1006-1011)
+template <typename T>
+__global__ void __launch_bounds__(256)
+apply_fd_kernel(const cx<T>* __restrict__ grid, const cx<T>* __restrict__ h, int64_t h_stride, int nt, int nr, int lk,
+                cx<T>* __restrict__ out, int n_batch) {
+  const int64_t total = (int64_t)n_batch * lk;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / lk), i = (int)(g - (int64_t)b * lk);
+    const cx<T>* hb = h + (size_t)b * h_stride + (size_t)i * nr * nt;
+    for (int r = 0; r < nr; ++r) {
+      cd acc(0, 0);
+      for (int t = 0; t < nt; ++t) nrx::cmac(acc, cd(hb[r * nt + t]), cd(grid[((size_t)b * nt + t) * lk + i]));
+      out[((size_t)b * nr + r) * lk + i] = cx<T>(acc);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------- equalize
+// MMSE per RE (grid.py:669-688):  Ainv = (H^H H + s2 I)^-1,  xhat = Ainv H^H y,  llrScale = 1/Re diag(Ainv).
+// The reference goes through pinv/SVD of the same Hermitian positive-definite matrix; here it is a Cholesky
+// factorisation in float64, one RE per lane, everything in registers (NR, NL compile-time).
+template <typename T, int NR, int NL>
+__global__ void __launch_bounds__(256)
+mmse_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ hf, int64_t h_stride,
+            const T* __restrict__ noise_var, int nv_stride, int lk, cx<T>* __restrict__ eq, T* __restrict__ scale,
+            int n_batch) {
+  const int64_t total = (int64_t)n_batch * lk;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / lk), i = (int)(g - (int64_t)b * lk);
+    double nv = (double)noise_var[(size_t)b * nv_stride];
+    nv = nv > 1e-8 ? nv : 1e-8;  // grid.py:676
+    cd H[NR][NL], y[NR];
+    const cx<T>* hb = hf + (size_t)b * h_stride + (size_t)i * NR * NL;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      y[r] = cd(rx[((size_t)b * NR + r) * lk + i]);
+#pragma unroll
+      for (int p = 0; p < NL; ++p) H[r][p] = cd(hb[r * NL + p]);
+    }
+    // A = H^H H + nv I (lower triangle), z = H^H y
+    cd A[NL][NL], z[NL];
+#pragma unroll
+    for (int p = 0; p < NL; ++p) {
+      cd zz(0, 0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) nrx::cmacc(zz, H[r][p], y[r]);
+      z[p] = zz;
+#pragma unroll
+      for (int q = 0; q <= p; ++q) {
+        cd a(0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) nrx::cmacc(a, H[r][q], H[r][p]);  // conj(H[r][q]) * H[r][p] = A[q][p]
+        A[p][q] = nrx::conj(a);                                         // store A[p][q] = conj(A[q][p])
+      }
+      A[p][p].re += nv;
+    }
+    // Cholesky A = L L^H (L lower, real positive diagonal)
+    cd Lm[NL][NL];
+    double dinv[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      double d = A[j][j].re;
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= nrx::norm2(Lm[j][k]);
+      const double ljj = sqrt(d);
+      dinv[j] = 1.0 / ljj;
+      Lm[j][j] = cd(ljj, 0);
+#pragma unroll
+      for (int r = j + 1; r < NL; ++r) {
+        cd s = A[r][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) {  // s -= L[r][k] * conj(L[j][k])
+          s.re -= Lm[r][k].re * Lm[j][k].re + Lm[r][k].im * Lm[j][k].im;
+          s.im -= Lm[r][k].im * Lm[j][k].re - Lm[r][k].re * Lm[j][k].im;
+        }
+        Lm[r][j] = s * dinv[j];
+      }
+    }
+    // M = L^-1 (lower)
+    cd M[NL][NL];
+#pragma unroll
+    for (int c = 0; c < NL; ++c) {
+      M[c][c] = cd(dinv[c], 0);
+#pragma unroll
+      for (int r = c + 1; r < NL; ++r) {
+        cd s(0, 0);
+#pragma unroll
+        for (int k = c; k < r; ++k) nrx::cmac(s, Lm[r][k], M[k][c]);
+        M[r][c] = cd(-s.re * dinv[r], -s.im * dinv[r]);
+      }
+    }
+    // xhat = M^H (M z);  diag(Ainv)_p = sum_{k>=p} |M[k][p]|^2
+    cd u[NL];
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+      cd s(0, 0);
+#pragma unroll
+      for (int c = 0; c <= r; ++c) nrx::cmac(s, M[r][c], z[c]);
+      u[r] = s;
+    }
+#pragma unroll
+    for (int p = 0; p < NL; ++p) {
+      cd s(0, 0);
+      double dg = 0;
+#pragma unroll
+      for (int k = p; k < NL; ++k) {
+        nrx::cmacc(s, M[k][p], u[k]);
+        dg += nrx::norm2(M[k][p]);
+      }
+      eq[((size_t)b * NL + p) * lk + i] = cx<T>(s);
+      scale[((size_t)b * NL + p) * lk + i] = (T)(1.0 / dg);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- complex variance
+// np.var of a complex array = mean |x - mean(x)|^2 (grid.py:1046, waveform.py:117): per batch item, float64,
+// two-level reduction (sum x, sum |x|^2 per workgroup -> atomics on 3 doubles), finalised by var_finish_kernel.
+template <typename T>
+__global__ void __launch_bounds__(256)
+var_partial_kernel(const cx<T>* __restrict__ x, int64_t n_per, int64_t x_stride, const int32_t* __restrict__ gather,
+                   int64_t n_gather, double* __restrict__ acc /* n_batch x 3 */) {
+  const int b = blockIdx.y;
+  const int64_t n = gather ? n_gather : n_per;
+  double sr = 0, si = 0, s2 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = gather ? (int64_t)gather[i] : i;
+    const cx<T> v = x[(size_t)b * x_stride + j];
+    sr += (double)v.re;
+    si += (double)v.im;
+    s2 += (double)v.re * (double)v.re + (double)v.im * (double)v.im;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sr += __shfl_xor(sr, o, 64);
+    si += __shfl_xor(si, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  __shared__ double red[3][4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = sr; red[1][w] = si; red[2][w] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, c = 0, d = 0;
+    for (int k = 0; k < 4; ++k) { a += red[0][k]; c += red[1][k]; d += red[2][k]; }
+    atomicAdd(&acc[b * 3 + 0], a);
+    atomicAdd(&acc[b * 3 + 1], c);
+    atomicAdd(&acc[b * 3 + 2], d);
+  }
+}
+
+// sigma[b] = sqrt(var * mult / snr_lin[b])  and  noise_var_out[b] = sigma^2 * nv_mult (both optional outputs)
+template <typename T>
+__global__ void var_finish_kernel(const double* __restrict__ acc, double n, int n_batch, T* __restrict__ var_out,
+                                  const double* __restrict__ snr_lin, int snr_stride, double mult,
+                                  T* __restrict__ sigma_out, T* __restrict__ nv_out, double nv_mult) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_batch) return;
+  const double mr = acc[b * 3] / n, mi = acc[b * 3 + 1] / n;
+  double var = acc[b * 3 + 2] / n - (mr * mr + mi * mi);
+  if (var < 0) var = 0;
+  if (var_out) var_out[b] = (T)var;
+  if (snr_lin) {
+    const double sg = sqrt(var * mult / snr_lin[(size_t)b * snr_stride]);
+    if (sigma_out) sigma_out[b] = (T)sg;
+    if (nv_out) nv_out[b] = (T)(sg * sg * nv_mult);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- noise
+// out = x + (sigma[b]/sqrt(2)) * z   with z = standard-normal pairs supplied by the caller (host PCG64 stream
+// in parity mode: random.py:203 awgn = normal(0, sigma/sqrt(2), shape+(2,))).
+template <typename T>
+__global__ void __launch_bounds__(256)
+add_noise_kernel(const cx<T>* __restrict__ x, const cx<T>* __restrict__ z, const T* __restrict__ sigma,
+                 int sigma_stride, int64_t n_per, cx<T>* __restrict__ out, int n_batch) {
+  const int64_t total = (int64_t)n_batch * n_per;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / n_per);
+    const double s = (double)sigma[(size_t)b * sigma_stride] / 1.4142135623730951;
+    const cx<T> v = x[g], w = z[g];
+    out[g] = cx<T>((T)((double)v.re + s * (double)w.re), (T)((double)v.im + s * (double)w.im));
+  }
+}
+
+// Counter-based generator for the throughput mode: Philox4x32-10 keyed by (seed), counter = (element index,
+// stream id); Box-Muller in float64.  Results do not depend on grid size, batch split or GPU count.
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+awgn_philox_kernel(const cx<T>* __restrict__ x, const T* __restrict__ sigma, int sigma_stride, int64_t n_per,
+                   cx<T>* __restrict__ out, int n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset) {
+  const int64_t total = (int64_t)n_batch * n_per;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / n_per);
+    const int64_t e = g - (int64_t)b * n_per;
+    const uint64_t item = (uint64_t)(batch_offset + b);
+    uint32_t c[4] = {(uint32_t)e, (uint32_t)((uint64_t)e >> 32), (uint32_t)item, (uint32_t)(item >> 32) ^ (uint32_t)stream_id};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // two 53-bit-ish uniforms in (0,1]
+    const double u1 = ((double)(((uint64_t)c[0] << 21) ^ (c[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(((uint64_t)c[2] << 21) ^ (c[3] >> 11))) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    const double s = (double)sigma[(size_t)b * sigma_stride] / 1.4142135623730951;
+    const cx<T> v = x[g];
+    out[g] = cx<T>((T)((double)v.re + s * rad * cs), (T)((double)v.im + s * rad * sn));
+  }
+}
+
+template <typename T, int NR>
+int32_t mmse_dispatch_nl(int nl, dim3 grid, hipStream_t st, const cx<T>* rx, const cx<T>* hf, int64_t h_stride,
+                         const T* nv, int nv_stride, int lk, cx<T>* eq, T* sc, int n_batch) {
+#define NRX_MMSE_CASE(NL)                                                                                          \
+  case NL:                                                                                                         \
+    hipLaunchKernelGGL((mmse_kernel<T, NR, NL>), grid, dim3(256), 0, st, rx, hf, h_stride, nv, nv_stride, lk, eq, sc, \
+                       n_batch);                                                                                   \
+    return NRX_OK;
+  switch (nl) {
+    NRX_MMSE_CASE(1)
+    NRX_MMSE_CASE(2)
+    NRX_MMSE_CASE(3)
+    NRX_MMSE_CASE(4)
+    default: return NRX_E_UNSUPPORTED;
+  }
+#undef NRX_MMSE_CASE
+}
+
+template <typename T>
+int32_t mmse_entry(const void* rx, const void* hf, int64_t h_stride, const void* noise_var, int32_t nv_stride,
+                   int32_t nr, int32_t nl, int32_t lk, void* eq, void* scale, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(rx && hf && noise_var && eq && scale, NRX_E_ARG, "nrx_mmse_equalize: NULL buffer");
+  NRX_REQUIRE(nr >= 1 && nl >= 1 && lk >= 0 && n_batch >= 0, NRX_E_ARG, "nrx_mmse_equalize: bad sizes");
+  if (lk == 0 || n_batch == 0) return NRX_OK;
+  const dim3 grid(nrx::stream_grid((long)lk * n_batch, 256));
+  hipStream_t st = (hipStream_t)stream;
+  int32_t rc = NRX_E_UNSUPPORTED;
+  switch (nr) {
+    case 1: rc = mmse_dispatch_nl<T, 1>(nl, grid, st, (const cx<T>*)rx, (const cx<T>*)hf, h_stride, (const T*)noise_var, nv_stride, lk, (cx<T>*)eq, (T*)scale, n_batch); break;
+    case 2: rc = mmse_dispatch_nl<T, 2>(nl, grid, st, (const cx<T>*)rx, (const cx<T>*)hf, h_stride, (const T*)noise_var, nv_stride, lk, (cx<T>*)eq, (T*)scale, n_batch); break;
+    case 4: rc = mmse_dispatch_nl<T, 4>(nl, grid, st, (const cx<T>*)rx, (const cx<T>*)hf, h_stride, (const T*)noise_var, nv_stride, lk, (cx<T>*)eq, (T*)scale, n_batch); break;
+    case 8: rc = mmse_dispatch_nl<T, 8>(nl, grid, st, (const cx<T>*)rx, (const cx<T>*)hf, h_stride, (const T*)noise_var, nv_stride, lk, (cx<T>*)eq, (T*)scale, n_batch); break;
+    default: break;
+  }
+  NRX_REQUIRE(rc != NRX_E_UNSUPPORTED, NRX_E_UNSUPPORTED,
+              "nrx_mmse_equalize: (Nr=%d, layers=%d) not built (Nr in {1,2,4,8}, layers 1..4)", nr, nl);
+  NRX_CHECK_LAUNCH("nrx_mmse_equalize");
+  return rc;
+}
+
+}  // namespace
+
+#define NRX_T2(NAME, IMPL)                                      \
+  extern "C" int32_t NAME##_f32 IMPL(float) extern "C" int32_t NAME##_f64 IMPL(double)
+
+extern "C" int32_t nrx_precode_f32(const void* grid, const void* f, int64_t f_stride, int32_t nl, int32_t nt, int32_t lk, void* out, int32_t n_batch, void* stream);
+extern "C" int32_t nrx_precode_f64(const void* grid, const void* f, int64_t f_stride, int32_t nl, int32_t nt, int32_t lk, void* out, int32_t n_batch, void* stream);
+
+template <typename T>
+static int32_t precode_entry(const void* grid, const void* f, int64_t f_stride, int32_t nl, int32_t nt, int32_t lk,
+                             void* out, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(grid && f && out, NRX_E_ARG, "nrx_precode: NULL buffer");
+  NRX_REQUIRE(nl >= 1 && nl <= 8 && nt >= 1 && lk >= 0 && n_batch >= 0, NRX_E_ARG, "nrx_precode: bad sizes (layers 1..8)");
+  if (lk == 0 || n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(precode_kernel<T>, dim3(nrx::stream_grid((long)lk * n_batch, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const cx<T>*)grid, (const cx<T>*)f, f_stride, nl, nt, lk, (cx<T>*)out, n_batch);
+  NRX_CHECK_LAUNCH("nrx_precode");
+  return NRX_OK;
+}
+extern "C" int32_t nrx_precode_f32(const void* grid, const void* f, int64_t f_stride, int32_t nl, int32_t nt, int32_t lk, void* out, int32_t n_batch, void* stream) { return precode_entry<float>(grid, f, f_stride, nl, nt, lk, out, n_batch, stream); }
+extern "C" int32_t nrx_precode_f64(const void* grid, const void* f, int64_t f_stride, int32_t nl, int32_t nt, int32_t lk, void* out, int32_t n_batch, void* stream) { return precode_entry<double>(grid, f, f_stride, nl, nt, lk, out, n_batch, stream); }
+
+template <typename T>
+static int32_t apply_fd_entry(const void* grid, const void* h, int64_t h_stride, int32_t nt, int32_t nr, int32_t lk,
+                              void* out, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(grid && h && out, NRX_E_ARG, "nrx_apply_channel_fd: NULL buffer");
+  NRX_REQUIRE(nt >= 1 && nr >= 1 && lk >= 0 && n_batch >= 0, NRX_E_ARG, "nrx_apply_channel_fd: bad sizes");
+  if (lk == 0 || n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(apply_fd_kernel<T>, dim3(nrx::stream_grid((long)lk * n_batch, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const cx<T>*)grid, (const cx<T>*)h, h_stride, nt, nr, lk, (cx<T>*)out, n_batch);
+  NRX_CHECK_LAUNCH("nrx_apply_channel_fd");
+  return NRX_OK;
+}
+extern "C" int32_t nrx_apply_channel_fd_f32(const void* grid, const void* h, int64_t h_stride, int32_t nt, int32_t nr, int32_t lk, void* out, int32_t n_batch, void* stream) { return apply_fd_entry<float>(grid, h, h_stride, nt, nr, lk, out, n_batch, stream); }
+extern "C" int32_t nrx_apply_channel_fd_f64(const void* grid, const void* h, int64_t h_stride, int32_t nt, int32_t nr, int32_t lk, void* out, int32_t n_batch, void* stream) { return apply_fd_entry<double>(grid, h, h_stride, nt, nr, lk, out, n_batch, stream); }
+
+extern "C" int32_t nrx_mmse_equalize_f32(const void* rx, const void* hf, int64_t h_stride, const void* noise_var, int32_t nv_stride, int32_t nr, int32_t nl, int32_t lk, void* eq, void* scale, int32_t n_batch, void* stream) { return mmse_entry<float>(rx, hf, h_stride, noise_var, nv_stride, nr, nl, lk, eq, scale, n_batch, stream); }
+extern "C" int32_t nrx_mmse_equalize_f64(const void* rx, const void* hf, int64_t h_stride, const void* noise_var, int32_t nv_stride, int32_t nr, int32_t nl, int32_t lk, void* eq, void* scale, int32_t n_batch, void* stream) { return mmse_entry<double>(rx, hf, h_stride, noise_var, nv_stride, nr, nl, lk, eq, scale, n_batch, stream); }
+
+// Per-item complex variance + (optionally) the noise std of addNoise(snrDb, useRxPower=True).
+template <typename T>
+static int32_t noise_level_entry(const void* x, int64_t n_per, int64_t x_stride, const int32_t* gather, int64_t n_gather,
+                                 int32_t n_batch, double* acc_ws, void* var_out, const double* snr_lin, int32_t snr_stride,
+                                 double mult, void* sigma_out, void* nv_out, double nv_mult, void* stream) {
+  NRX_REQUIRE(x && acc_ws, NRX_E_ARG, "nrx_noise_level: NULL buffer (acc_ws = 3 doubles per batch item)");
+  NRX_REQUIRE(n_per > 0 && n_batch >= 0, NRX_E_ARG, "nrx_noise_level: bad sizes");
+  if (n_batch == 0) return NRX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(acc_ws, 0, sizeof(double) * 3 * n_batch, st);
+  const int64_t n = gather ? n_gather : n_per;
+  int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(var_partial_kernel<T>, dim3(gx, n_batch), dim3(256), 0, st, (const cx<T>*)x, n_per, x_stride, gather,
+                     n_gather, acc_ws);
+  hipLaunchKernelGGL(var_finish_kernel<T>, dim3((n_batch + 63) / 64), dim3(64), 0, st, acc_ws, (double)n, n_batch,
+                     (T*)var_out, snr_lin, snr_stride, mult, (T*)sigma_out, (T*)nv_out, nv_mult);
+  NRX_CHECK_LAUNCH("nrx_noise_level");
+  return NRX_OK;
+}
+extern "C" int32_t nrx_noise_level_f32(const void* x, int64_t n_per, int64_t x_stride, const int32_t* gather, int64_t n_gather, int32_t n_batch, double* acc_ws, void* var_out, const double* snr_lin, int32_t snr_stride, double mult, void* sigma_out, void* nv_out, double nv_mult, void* stream) { return noise_level_entry<float>(x, n_per, x_stride, gather, n_gather, n_batch, acc_ws, var_out, snr_lin, snr_stride, mult, sigma_out, nv_out, nv_mult, stream); }
+extern "C" int32_t nrx_noise_level_f64(const void* x, int64_t n_per, int64_t x_stride, const int32_t* gather, int64_t n_gather, int32_t n_batch, double* acc_ws, void* var_out, const double* snr_lin, int32_t snr_stride, double mult, void* sigma_out, void* nv_out, double nv_mult, void* stream) { return noise_level_entry<double>(x, n_per, x_stride, gather, n_gather, n_batch, acc_ws, var_out, snr_lin, snr_stride, mult, sigma_out, nv_out, nv_mult, stream); }
+
+template <typename T>
+static int32_t add_noise_entry(const void* x, const void* z, const void* sigma, int32_t sigma_stride, int64_t n_per,
+                               void* out, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(x && z && sigma && out, NRX_E_ARG, "nrx_add_noise: NULL buffer");
+  if (n_per == 0 || n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(add_noise_kernel<T>, dim3(nrx::stream_grid((long)n_per * n_batch, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const cx<T>*)x, (const cx<T>*)z, (const T*)sigma, sigma_stride, n_per,
+                     (cx<T>*)out, n_batch);
+  NRX_CHECK_LAUNCH("nrx_add_noise");
+  return NRX_OK;
+}
+extern "C" int32_t nrx_add_noise_f32(const void* x, const void* z, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, void* stream) { return add_noise_entry<float>(x, z, sigma, sigma_stride, n_per, out, n_batch, stream); }
+extern "C" int32_t nrx_add_noise_f64(const void* x, const void* z, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, void* stream) { return add_noise_entry<double>(x, z, sigma, sigma_stride, n_per, out, n_batch, stream); }
+
+template <typename T>
+static int32_t awgn_entry(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out,
+                          int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) {
+  NRX_REQUIRE(x && sigma && out, NRX_E_ARG, "nrx_awgn: NULL buffer");
+  if (n_per == 0 || n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(awgn_philox_kernel<T>, dim3(nrx::stream_grid((long)n_per * n_batch, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const cx<T>*)x, (const T*)sigma, sigma_stride, n_per, (cx<T>*)out, n_batch,
+                     seed, stream_id, batch_offset);
+  NRX_CHECK_LAUNCH("nrx_awgn");
+  return NRX_OK;
+}
+extern "C" int32_t nrx_awgn_f32(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) { return awgn_entry<float>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, stream); }
+extern "C" int32_t nrx_awgn_f64(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) { return awgn_entry<double>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, stream); }

@@ -1,0 +1,225 @@
+// QAM mapping / max-log LLR demapping with PDSCH scrambling and layer/RE (de)mapping fused (gfx950).
+//
+// Replaces reference modulation.py:127-156 (Modem.modulate), :159-204 (getLLRsFromSymbols),
+// pdsch.py:603-616 (scrambleBits/scrambleLLRs), :619-639 + :855-932 (layer map + populateGrid scatter),
+// :935-1005 (getLLRsFromGrid gather).  Streaming kernels: one thread per modulation symbol; arithmetic is
+// float64 internally whatever the storage type (an LLR is a difference of near-equal squared distances).
+#include "nrx_common.h"
+#include "nrx_cplx.h"
+
+namespace {
+using nrx::cx;
+
+// TS 38.211 5.1.2-5.1.7 amplitude of one axis from its bits a[0] (sign), a[1..h-1] (MSB-first amplitude bits),
+// un-normalised odd integer; the recursion of reference modulation.py:60-74.
+__device__ __forceinline__ int pam_level(uint32_t axis_bits, int h) {
+  // axis_bits: bit (h-1-i) holds a[i]
+  int v = 1;
+  for (int i = h - 1; i >= 1; --i) {  // innermost bit first
+    const int b = (axis_bits >> (h - 1 - i)) & 1;
+    v = (1 << (h - i)) - (1 - 2 * b) * v;
+  }
+  const int s = (axis_bits >> (h - 1)) & 1;
+  return (1 - 2 * s) * v;
+}
+
+// split the qm bits of a symbol (MSB first: b0 b1 b2 ...) into real-axis bits (even positions) and imag-axis bits
+__device__ __forceinline__ void split_axes(uint32_t v, int qm, uint32_t& re_bits, uint32_t& im_bits) {
+  re_bits = im_bits = 0;
+  const int h = qm / 2;
+  for (int i = 0; i < h; ++i) {
+    re_bits = (re_bits << 1) | ((v >> (qm - 1 - 2 * i)) & 1);
+    im_bits = (im_bits << 1) | ((v >> (qm - 2 - 2 * i)) & 1);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+qam_map_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, const uint8_t* __restrict__ scr, int qm,
+               double scale, const int32_t* __restrict__ re_index, int n_sym, cx<T>* __restrict__ out,
+               int64_t out_stride, int n_batch) {
+  const int64_t total = (int64_t)n_batch * n_sym;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / n_sym), i = (int)(g - (int64_t)b * n_sym);
+    const uint8_t* src = bits + (size_t)b * bits_stride + (size_t)i * qm;
+    uint32_t v = 0;
+    for (int q = 0; q < qm; ++q) {
+      uint32_t bit = src[q] & 1;
+      if (scr) bit ^= scr[(size_t)i * qm + q] & 1;  // pdsch.py:603-608
+      v = (v << 1) | bit;
+    }
+    double re, im;
+    if (qm == 1) {
+      re = im = (double)(1 - 2 * (int)v) * scale;
+    } else {
+      uint32_t rb, ib;
+      split_axes(v, qm, rb, ib);
+      re = (double)pam_level(rb, qm / 2) * scale;
+      im = (double)pam_level(ib, qm / 2) * scale;
+    }
+    const int64_t dst = re_index ? (int64_t)re_index[i] : (int64_t)i;
+    out[(size_t)b * out_stride + dst] = cx<T>((T)re, (T)im);
+  }
+}
+
+// Max-log LLRs (useMax=True, the reference default).  The exhaustive max over the 2^qm points of
+// -|y-s|^2/s2 separates per axis for square QAM: bits on the real axis only see (Re y - a)^2 because the
+// imaginary-axis minimum is common to both hypotheses and cancels in the difference.
+template <typename T, typename TL>
+__global__ void __launch_bounds__(256)
+qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __restrict__ scales,
+                 const T* __restrict__ noise_var, int nv_stride, const uint8_t* __restrict__ scr, int qm,
+                 double scale, const int32_t* __restrict__ re_index, int n_sym, TL* __restrict__ llr,
+                 int64_t llr_stride, int n_batch, double nv_floor) {
+  __shared__ double lev[32];
+  const int h = qm / 2;
+  if (qm > 1 && (int)threadIdx.x < (1 << h)) lev[threadIdx.x] = (double)pam_level(threadIdx.x, h) * scale;
+  __syncthreads();
+  const int64_t total = (int64_t)n_batch * n_sym;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / n_sym), i = (int)(g - (int64_t)b * n_sym);
+    const int64_t src = re_index ? (int64_t)re_index[i] : (int64_t)i;
+    const cx<T> y = syms[(size_t)b * sym_stride + src];
+    double nv = (double)noise_var[(size_t)b * nv_stride];
+    nv = nv > nv_floor ? nv : nv_floor;  // pdsch.py:966 max(noiseVar, 1e-10)
+    const double sc = scales ? (double)scales[(size_t)b * sym_stride + src] : 1.0;
+    TL* dst = llr + (size_t)b * llr_stride + (size_t)i * qm;
+    if (qm == 1) {
+      const double d0 = ((double)y.re - scale) * ((double)y.re - scale) + ((double)y.im - scale) * ((double)y.im - scale);
+      const double d1 = ((double)y.re + scale) * ((double)y.re + scale) + ((double)y.im + scale) * ((double)y.im + scale);
+      double l = (-d0 / nv) - (-d1 / nv);
+      if (scr) l *= (double)(1 - 2 * (int)(scr[i] & 1));
+      dst[0] = (TL)(l * sc);
+      continue;
+    }
+    for (int axis = 0; axis < 2; ++axis) {
+      const double yv = axis == 0 ? (double)y.re : (double)y.im;
+      double m0[5], m1[5];
+      for (int q = 0; q < h; ++q) m0[q] = m1[q] = 1e300;
+      for (int a = 0; a < (1 << h); ++a) {
+        const double d = yv - lev[a];
+        const double d2 = d * d;
+        for (int q = 0; q < h; ++q) {
+          if ((a >> (h - 1 - q)) & 1) m1[q] = d2 < m1[q] ? d2 : m1[q];
+          else m0[q] = d2 < m0[q] ? d2 : m0[q];
+        }
+      }
+      for (int q = 0; q < h; ++q) {
+        const int pos = 2 * q + axis;  // bit index inside the symbol
+        double l = (-m0[q] / nv) - (-m1[q] / nv);  // modulation.py:200-202, positive = bit 0
+        if (scr) l *= (double)(1 - 2 * (int)(scr[(size_t)i * qm + pos] & 1));  // pdsch.py:611-616
+        dst[pos] = (TL)(l * sc);                                               // pdsch.py:1002-1003
+      }
+    }
+  }
+}
+
+// Exact log-likelihood ratios (useMax=False, modulation.py:198-201): exhaustive log-sum-exp with the
+// reference's +-700 exponent clip.
+template <typename T, typename TL>
+__global__ void __launch_bounds__(256)
+qam_demap_exact_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __restrict__ scales,
+                       const T* __restrict__ noise_var, int nv_stride, const uint8_t* __restrict__ scr, int qm,
+                       double scale, const int32_t* __restrict__ re_index, int n_sym, TL* __restrict__ llr,
+                       int64_t llr_stride, int n_batch, double nv_floor) {
+  const int64_t total = (int64_t)n_batch * n_sym;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / n_sym), i = (int)(g - (int64_t)b * n_sym);
+    const int64_t src = re_index ? (int64_t)re_index[i] : (int64_t)i;
+    const cx<T> y = syms[(size_t)b * sym_stride + src];
+    double nv = (double)noise_var[(size_t)b * nv_stride];
+    nv = nv > nv_floor ? nv : nv_floor;
+    const double sc = scales ? (double)scales[(size_t)b * sym_stride + src] : 1.0;
+    double s0[10], s1[10];
+    for (int q = 0; q < qm; ++q) s0[q] = s1[q] = 0.0;
+    for (uint32_t v = 0; v < (1u << qm); ++v) {
+      double re, im;
+      if (qm == 1) re = im = (double)(1 - 2 * (int)v) * scale;
+      else {
+        uint32_t rb, ib;
+        split_axes(v, qm, rb, ib);
+        re = (double)pam_level(rb, qm / 2) * scale;
+        im = (double)pam_level(ib, qm / 2) * scale;
+      }
+      const double dr = (double)y.re - re, di = (double)y.im - im;
+      double e = -(dr * dr + di * di) / nv;
+      e = e < -700.0 ? -700.0 : (e > 700.0 ? 700.0 : e);
+      const double w = exp(e);
+      for (int q = 0; q < qm; ++q) {
+        if ((v >> (qm - 1 - q)) & 1) s1[q] += w;
+        else s0[q] += w;
+      }
+    }
+    TL* dst = llr + (size_t)b * llr_stride + (size_t)i * qm;
+    for (int q = 0; q < qm; ++q) {
+      double l = log(s0[q]) - log(s1[q]);
+      if (scr) l *= (double)(1 - 2 * (int)(scr[(size_t)i * qm + q] & 1));
+      dst[q] = (TL)(l * sc);
+    }
+  }
+}
+
+double qam_scale(int qm) {
+  static const int norm[11] = {0, 2, 2, 0, 10, 0, 42, 0, 170, 0, 682};  // modulation.py:58
+  return 1.0 / sqrt((double)norm[qm]);
+}
+bool qm_ok(int qm) { return qm == 1 || qm == 2 || qm == 4 || qm == 6 || qm == 8 || qm == 10; }
+
+template <typename T>
+int32_t map_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index,
+                  int32_t n_sym, void* out, int64_t out_stride, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(bits && out, NRX_E_ARG, "nrx_qam_map: NULL buffer");
+  NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_qam_map: unsupported modulation order %d", qm);
+  NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && bits_stride >= (int64_t)n_sym * qm, NRX_E_SHAPE, "nrx_qam_map: bad sizes");
+  if (n_sym == 0 || n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(qam_map_kernel<T>, dim3(nrx::stream_grid((long)n_sym * n_batch, 256)), dim3(256), 0,
+                     (hipStream_t)stream, bits, bits_stride, scr, qm, qam_scale(qm), re_index, n_sym, (cx<T>*)out,
+                     out_stride, n_batch);
+  NRX_CHECK_LAUNCH("nrx_qam_map");
+  return NRX_OK;
+}
+
+template <typename T, typename TL>
+int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var, int32_t nv_stride,
+                    const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym, void* llr,
+                    int64_t llr_stride, int32_t n_batch, int32_t exact, double nv_floor, void* stream) {
+  NRX_REQUIRE(syms && noise_var && llr, NRX_E_ARG, "nrx_qam_demap: NULL buffer");
+  NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_qam_demap: unsupported modulation order %d", qm);
+  NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && llr_stride >= (int64_t)n_sym * qm, NRX_E_SHAPE, "nrx_qam_demap: bad sizes");
+  if (n_sym == 0 || n_batch == 0) return NRX_OK;
+  const dim3 grid(nrx::stream_grid((long)n_sym * n_batch, 256));
+  if (exact)
+    hipLaunchKernelGGL((qam_demap_exact_kernel<T, TL>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,
+                       sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qm, qam_scale(qm), re_index,
+                       n_sym, (TL*)llr, llr_stride, n_batch, nv_floor);
+  else
+    hipLaunchKernelGGL((qam_demap_kernel<T, TL>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,
+                       sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qm, qam_scale(qm), re_index,
+                       n_sym, (TL*)llr, llr_stride, n_batch, nv_floor);
+  NRX_CHECK_LAUNCH("nrx_qam_demap");
+  return NRX_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t nrx_qam_map_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm,
+                                   const int32_t* re_index, int32_t n_sym, void* out, int64_t out_stride,
+                                   int32_t n_batch, void* stream) {
+  return map_entry<float>(bits, bits_stride, scr, qm, re_index, n_sym, out, out_stride, n_batch, stream);
+}
+extern "C" int32_t nrx_qam_map_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm,
+                                   const int32_t* re_index, int32_t n_sym, void* out, int64_t out_stride,
+                                   int32_t n_batch, void* stream) {
+  return map_entry<double>(bits, bits_stride, scr, qm, re_index, n_sym, out, out_stride, n_batch, stream);
+}
+#define NRX_DEMAP(NAME, T, TL)                                                                                     \
+  extern "C" int32_t NAME(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,         \
+                          int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym, \
+                          void* llr, int64_t llr_stride, int32_t n_batch, int32_t exact, double nv_floor,          \
+                          void* stream) {                                                                          \
+    return demap_entry<T, TL>(syms, sym_stride, scales, noise_var, nv_stride, scr, qm, re_index, n_sym, llr,       \
+                              llr_stride, n_batch, exact, nv_floor, stream);                                       \
+  }
+NRX_DEMAP(nrx_qam_demap_f32, float, float)
+NRX_DEMAP(nrx_qam_demap_f64, double, double)
+NRX_DEMAP(nrx_qam_demap_f64o32, double, float)

@@ -1,0 +1,190 @@
+// OFDM modulation (IFFT + cyclic prefix + raised-cosine overlap windowing) and demodulation (CP strip + FFT)
+// as batched LDS FFTs (gfx950).
+//
+// Replaces reference grid.py:521-582 (Grid.ofdmModulate), waveform.py:380-470 (applyWindowing "STD"),
+// waveform.py:473-527 (Waveform.ofdmDemodulate).  HBM-bound: one read of the grid, one write of the waveform.
+#include "nrx_common.h"
+#include "nrx_fft.h"
+
+namespace {
+using nrx::cx;
+
+struct SymGeom {
+  int32_t n_sym;
+  int32_t cp[16];     // CP length of each symbol of the slot (samples)
+  int32_t start[16];  // first sample of each symbol (CP included) inside the slot
+};
+
+// One workgroup per (batch item, antenna port): the 14 symbols are produced in order because the windowed tail
+// of symbol l-1 is overlap-added onto the head of symbol l (waveform.py:436-465).
+template <typename T>
+__global__ void __launch_bounds__(256)
+ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
+                cx<T>* __restrict__ wave, int64_t wave_stride /* samples per (item, port) row */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cx<T>* buf = (cx<T>*)smem;
+  cx<T>* tw = buf + nfft;
+  cx<T>* tail = tw + nfft / 2;  // [w] windowed tail of the previous symbol
+  cx<T>* head0 = tail + w;      // [w] windowed head of symbol 0 (completed by the last symbol's tail)
+  const int row = blockIdx.x;   // item * ports + port
+  const cx<T>* src = grid + (size_t)row * g.n_sym * K;
+  cx<T>* dst = wave + (size_t)row * wave_stride;
+  nrx::fft_fill_twiddles(tw, nfft);
+  const int pad_lo = (nfft - K + 1) / 2;  // grid.py:543
+  const double inv_n = 1.0 / (double)nfft;
+  for (int l = 0; l < g.n_sym; ++l) {
+    __syncthreads();
+    // zero-pad to nfft and ifftshift: buf[i] = padded[(i + nfft/2) mod nfft]
+    for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
+      const int j = (i + nfft / 2) & (nfft - 1);
+      const int k = j - pad_lo;
+      buf[i] = (k >= 0 && k < K) ? src[(size_t)l * K + k] : cx<T>(0, 0);
+    }
+    __syncthreads();
+    nrx::fft_dif_lds(buf, tw, nfft, log2n, true);
+    const int cp = g.cp[l], n_l = cp + nfft;
+    // extended symbol ex[i], i in [0, n_l + w): sample time t = i - w - cp of the periodic extension
+    for (int i = threadIdx.x; i < n_l + w; i += blockDim.x) {
+      const int t = (i - w - cp + 2 * nfft) & (nfft - 1);
+      const cx<T> x = buf[nrx::fft_bitrev(t, log2n)];
+      double win = 1.0;
+      if (i < w) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * i) / (double)(2 * w)));
+      else if (i >= n_l) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * (n_l + w - 1 - i)) / (double)(2 * w)));
+      cx<T> v((T)((double)x.re * inv_n * win), (T)((double)x.im * inv_n * win));
+      if (i >= n_l) continue;  // tails are handled below (needs the barrier)
+      if (i < w) {
+        if (l == 0) { head0[i] = v; continue; }
+        v = v + tail[i];
+      }
+      int pos = g.start[l] + i - w;  // roll(-w) of waveform.py:467
+      if (pos < 0) pos += slot_len;
+      dst[pos] = v;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < w; q += blockDim.x) {
+      const int i = n_l + q;
+      const int t = (i - w - cp + 2 * nfft) & (nfft - 1);
+      const cx<T> x = buf[nrx::fft_bitrev(t, log2n)];
+      const double win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * (w - 1 - q)) / (double)(2 * w)));
+      tail[q] = cx<T>((T)((double)x.re * inv_n * win), (T)((double)x.im * inv_n * win));
+    }
+  }
+  __syncthreads();
+  // the last symbol's tail wraps onto the slot start (waveform.py:462-465)
+  for (int q = threadIdx.x; q < w; q += blockDim.x) {
+    int pos = g.start[0] + q - w;
+    if (pos < 0) pos += slot_len;
+    dst[pos] = head0[q] + tail[q];
+  }
+}
+
+// No-window variant is the same kernel with w = 0 (tail/head loops vanish).
+
+// One FFT per (item, antenna, symbol); workgroups loop over tasks so the twiddle table is built once.
+template <typename T>
+__global__ void __launch_bounds__(256)
+ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t wave_len,
+                  const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
+                  cx<T>* __restrict__ grid, int n_tasks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cx<T>* buf = (cx<T>*)smem;
+  cx<T>* tw = buf + nfft;
+  nrx::fft_fill_twiddles(tw, nfft);
+  for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    const int l = task % g.n_sym;
+    const int row = task / g.n_sym;  // item * n_ant + antenna
+    const int item = row / n_ant;
+    const int64_t ts = t_off ? (int64_t)t_off[(size_t)item * t_off_stride] : 0;  // Waveform.sync (waveform.py:317-341)
+    const cx<T>* src = wave + (size_t)row * wave_stride;
+    const int cp = g.cp[l];
+    const int off = (int)rint((double)cp * 0.5);  // np.round(cpLens * cpOffsetRatio), waveform.py:507
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
+      const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));  // waveform.py:509
+      buf[i] = s < wave_len ? src[s] : cx<T>(0, 0);
+    }
+    __syncthreads();
+    nrx::fft_dif_lds(buf, tw, nfft, log2n, false);
+    cx<T>* dst = grid + ((size_t)row * g.n_sym + l) * K;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      const int q = (k - K / 2 + nfft) & (nfft - 1);  // fftshift + centre K bins (waveform.py:514-520)
+      dst[k] = buf[nrx::fft_bitrev(q, log2n)];
+    }
+  }
+}
+
+int ilog2(int n) {
+  int l = 0;
+  while ((1 << l) < n) ++l;
+  return l;
+}
+
+int32_t fill_geom(const int32_t* cp_lens, int32_t n_sym, int32_t nfft, SymGeom* g, int* slot_len) {
+  NRX_REQUIRE(cp_lens && n_sym >= 1 && n_sym <= 16, NRX_E_ARG, "nrx_ofdm: need 1..16 CP lengths");
+  NRX_REQUIRE(nfft >= 64 && nfft <= 8192 && (nfft & (nfft - 1)) == 0, NRX_E_ARG, "nrx_ofdm: nfft must be a power of two in [64, 8192]");
+  g->n_sym = n_sym;
+  int s = 0;
+  for (int l = 0; l < n_sym; ++l) {
+    NRX_REQUIRE(cp_lens[l] >= 0 && cp_lens[l] < nfft, NRX_E_ARG, "nrx_ofdm: CP length out of range");
+    g->cp[l] = cp_lens[l];
+    g->start[l] = s;
+    s += cp_lens[l] + nfft;
+  }
+  *slot_len = s;
+  return NRX_OK;
+}
+
+template <typename T>
+int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
+                  int32_t window_len, void* wave, int64_t wave_stride, void* stream) {
+  NRX_REQUIRE(grid && wave, NRX_E_ARG, "nrx_ofdm_modulate: NULL buffer");
+  SymGeom g;
+  int slot_len;
+  int32_t rc = fill_geom(cp_lens, n_sym, nfft, &g, &slot_len);
+  if (rc) return rc;
+  NRX_REQUIRE(K > 0 && K <= nfft, NRX_E_SHAPE, "nrx_ofdm_modulate: K (%d) exceeds nfft (%d)", K, nfft);
+  NRX_REQUIRE(wave_stride >= slot_len, NRX_E_SHAPE, "nrx_ofdm_modulate: wave_stride < slot length %d", slot_len);
+  int wmin = nfft;
+  for (int l = 0; l < n_sym; ++l) wmin = g.cp[l] < wmin ? g.cp[l] : wmin;
+  NRX_REQUIRE(window_len >= 0 && (window_len == 0 || window_len < wmin), NRX_E_ARG,
+              "nrx_ofdm_modulate: The windowing size must be smaller than CP size");
+  if (n_rows == 0) return NRX_OK;
+  const size_t lds = sizeof(cx<T>) * ((size_t)nfft + nfft / 2 + 2 * (size_t)window_len);
+  auto kern = ofdm_mod_kernel<T>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(n_rows), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft, ilog2(nfft), g,
+                     window_len, slot_len, (cx<T>*)wave, wave_stride);
+  NRX_CHECK_LAUNCH("nrx_ofdm_modulate");
+  return NRX_OK;
+}
+
+template <typename T>
+int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride,
+                    int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
+                    void* grid, void* stream) {
+  NRX_REQUIRE(wave && grid, NRX_E_ARG, "nrx_ofdm_demodulate: NULL buffer");
+  SymGeom g;
+  int slot_len;
+  int32_t rc = fill_geom(cp_lens, n_sym, nfft, &g, &slot_len);
+  if (rc) return rc;
+  NRX_REQUIRE(K > 0 && K <= nfft, NRX_E_SHAPE, "nrx_ofdm_demodulate: K (%d) exceeds nfft (%d)", K, nfft);
+  NRX_REQUIRE(wave_len >= slot_len && wave_stride >= wave_len, NRX_E_SHAPE,
+              "nrx_ofdm_demodulate: waveform shorter than one slot (%d samples)", slot_len);
+  const int n_tasks = n_items * n_ant * n_sym;
+  if (n_tasks == 0) return NRX_OK;
+  const size_t lds = sizeof(cx<T>) * ((size_t)nfft + nfft / 2);
+  auto kern = ofdm_demod_kernel<T>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int grid_dim = n_tasks < 1024 ? n_tasks : 1024;
+  hipLaunchKernelGGL(kern, dim3(grid_dim), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)wave, wave_stride, wave_len,
+                     t_off, t_off_stride, n_ant, K, nfft, ilog2(nfft), g, (cx<T>*)grid, n_tasks);
+  NRX_CHECK_LAUNCH("nrx_ofdm_demodulate");
+  return NRX_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<float>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
+extern "C" int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
+extern "C" int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }
+extern "C" int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }

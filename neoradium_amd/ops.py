@@ -147,3 +147,311 @@ def count_errors(cb_ok, tb_out, tb_ref, counters):
     check(lib().nrx_count_errors(ptr(cb_ok), cb_ok.numel(), ptr(tb_out), ptr(_u8(tb_ref)), n_tb, A,
                                  tb_out.shape[1], ptr(counters), stream()))
     return counters
+
+
+# ------------------------------------------------------------------------------------------------- modem / grid
+_CT = {torch.complex64: ('f32', torch.float32), torch.complex128: ('f64', torch.float64)}
+
+
+def _ct(t):
+    if t.dtype not in _CT:
+        raise ValueError(f"complex64/complex128 tensor expected, got {t.dtype}")
+    return _CT[t.dtype]
+
+
+def _i32(x, dev):
+    if x is None:
+        return None
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(x, dtype=torch.int32)
+    return x.to(device=dev, dtype=torch.int32).contiguous()
+
+
+def _host_i32(seq):
+    arr = (C.c_int32 * len(seq))(*[int(v) for v in seq])
+    return arr
+
+
+def qam_map(bits, qm, scr=None, re_index=None, out=None, out_elems=None, dtype=torch.complex128):
+    """Modem.modulate (+ PDSCH scrambling + layer/RE scatter): (n, n_sym*qm) bits -> (n, out_elems) complex.
+
+    With ``re_index`` the symbols are scattered into ``out`` (an existing (n, out_elems) grid buffer, e.g. one
+    pre-filled with DMRS); without it the output is the plain (n, n_sym) symbol array."""
+    bits = _u8(bits)
+    n, nb = bits.shape
+    if nb % qm:
+        raise ValueError("The length of 'bitstream' (%d) must be a multiple of 'qm' (%d)!" % (nb, qm))
+    n_sym = nb // qm
+    dev = _dev(bits)
+    if out is None:
+        out_elems = n_sym if out_elems is None else out_elems
+        out = torch.zeros((n, out_elems), dtype=dtype, device=dev)
+    flat = out.reshape(n, -1)
+    assert flat.is_contiguous()
+    if re_index is None and flat.shape[1] < n_sym:
+        raise ValueError("output too small")
+    sfx, _ = _ct(flat)
+    ri = _i32(re_index, dev)
+    if ri is not None:
+        if ri.numel() != n_sym:
+            raise ValueError(f"re_index must have {n_sym} entries, got {ri.numel()}")
+    scr_t = None if scr is None else _u8(scr.to(dev))
+    if scr_t is not None and scr_t.numel() < nb:
+        raise ValueError("scrambling sequence shorter than the bit stream")
+    fn = getattr(lib(), 'nrx_qam_map_' + sfx)
+    check(fn(ptr(bits), nb, ptr(scr_t), qm, ptr(ri), n_sym, ptr(flat), flat.shape[1], n, stream()))
+    return out
+
+
+def qam_demap(syms, noise_var, qm, n_sym=None, scr=None, re_index=None, scales=None, exact=False, nv_floor=0.0,
+              llr_dtype=None):
+    """Modem.getLLRsFromSymbols / PDSCH.getLLRsFromGrid: (n, E) complex -> (n, n_sym*qm) LLRs."""
+    flat = syms.reshape(syms.shape[0], -1).contiguous()
+    n, E = flat.shape
+    sfx, rt = _ct(flat)
+    dev = _dev(flat)
+    ri = _i32(re_index, dev)
+    if n_sym is None:
+        n_sym = E if ri is None else ri.numel()
+    if ri is not None and ri.numel() != n_sym:
+        raise ValueError("re_index length mismatch")
+    if ri is None and n_sym > E:
+        raise ValueError("n_sym exceeds the number of symbols")
+    nv = torch.as_tensor(noise_var, dtype=rt, device=dev).reshape(-1).contiguous()
+    if nv.numel() not in (1, n):
+        raise ValueError("noise_var must be a scalar or one value per batch item")
+    sc = None
+    if scales is not None:
+        sc = scales.reshape(n, -1).to(rt).contiguous()
+        if sc.shape[1] != E:
+            raise ValueError("scales must have the shape of syms")
+    scr_t = None if scr is None else _u8(scr.to(dev))
+    if scr_t is not None and scr_t.numel() < n_sym * qm:
+        raise ValueError("scrambling sequence shorter than the LLR stream")
+    llr_dtype = rt if llr_dtype is None else llr_dtype
+    if (rt, llr_dtype) == (torch.float64, torch.float32):
+        sfx = 'f64o32'
+    elif llr_dtype != rt:
+        raise ValueError("unsupported LLR dtype for this input type")
+    llr = torch.empty((n, n_sym * qm), dtype=llr_dtype, device=dev)
+    fn = getattr(lib(), 'nrx_qam_demap_' + sfx)
+    check(fn(ptr(flat), E, ptr(sc), ptr(nv), 0 if nv.numel() == 1 else 1, ptr(scr_t), qm, ptr(ri), n_sym, ptr(llr),
+             n_sym * qm, n, 1 if exact else 0, float(nv_floor), stream()))
+    return llr
+
+
+def precode(grid, f):
+    """Grid.precode (wideband F): (n,Nl,L,K) x (Nt,Nl) or (n,Nt,Nl) -> (n,Nt,L,K)."""
+    grid = grid.contiguous()
+    sfx, _ = _ct(grid)
+    n, nl, L, K = grid.shape
+    f = f.to(grid.dtype).contiguous()
+    shared = f.dim() == 2
+    nt = f.shape[-2]
+    if f.shape[-1] != nl or (not shared and f.shape[0] != n):
+        raise ValueError("The last dimension of 'f' (%d) must match the first dimension of the grid (%d)" % (f.shape[-1], nl))
+    out = torch.empty((n, nt, L, K), dtype=grid.dtype, device=_dev(grid))
+    fn = getattr(lib(), 'nrx_precode_' + sfx)
+    check(fn(ptr(grid), ptr(f), 0 if shared else nt * nl, nl, nt, L * K, ptr(out), n, stream()))
+    return out
+
+
+def apply_channel_fd(grid, h):
+    """Grid.applyChannel: grid (n,Nt,L,K), h (n,L,K,Nr,Nt) or (L,K,Nr,Nt) -> (n,Nr,L,K)."""
+    grid = grid.contiguous()
+    sfx, _ = _ct(grid)
+    n, nt, L, K = grid.shape
+    h = h.to(grid.dtype).contiguous()
+    shared = h.dim() == 4
+    if tuple(h.shape[-4:-2]) != (L, K) or h.shape[-1] != nt:
+        raise ValueError("Mismatch in the number of transmitter antennas (%d vs %d)!" % (h.shape[-1], nt))
+    nr = h.shape[-2]
+    out = torch.empty((n, nr, L, K), dtype=grid.dtype, device=_dev(grid))
+    fn = getattr(lib(), 'nrx_apply_channel_fd_' + sfx)
+    check(fn(ptr(grid), ptr(h), 0 if shared else L * K * nr * nt, nt, nr, L * K, ptr(out), n, stream()))
+    return out
+
+
+def mmse_equalize(rx, hf, noise_var):
+    """Grid.equalize: rx (n,Nr,L,K), hf (n,L,K,Nr,P) -> eq (n,P,L,K), llrScales (n,P,L,K)."""
+    rx = rx.contiguous()
+    sfx, rt = _ct(rx)
+    n, nr, L, K = rx.shape
+    hf = hf.to(rx.dtype).contiguous()
+    shared = hf.dim() == 4
+    if tuple(hf.shape[-4:-1]) != (L, K, nr):
+        raise ValueError("Mismatch in the number of receiver antennas, OFDM symbols, or subcarriers!")
+    P = hf.shape[-1]
+    dev = _dev(rx)
+    nv = torch.as_tensor(noise_var, dtype=rt, device=dev).reshape(-1).contiguous()
+    eq = torch.empty((n, P, L, K), dtype=rx.dtype, device=dev)
+    sc = torch.empty((n, P, L, K), dtype=rt, device=dev)
+    fn = getattr(lib(), 'nrx_mmse_equalize_' + sfx)
+    check(fn(ptr(rx), ptr(hf), 0 if shared else L * K * nr * P, ptr(nv), 0 if nv.numel() == 1 else 1, nr, P, L * K,
+             ptr(eq), ptr(sc), n, stream()))
+    return eq, sc
+
+
+def noise_level(x, snr_lin=None, mult=1.0, nv_mult=1.0, gather=None):
+    """Complex variance per batch item (np.var) and, with ``snr_lin``, sigma = sqrt(var*mult/snr), nv = sigma^2*nv_mult."""
+    flat = x.reshape(x.shape[0], -1).contiguous()
+    sfx, rt = _ct(flat)
+    n, m = flat.shape
+    dev = _dev(flat)
+    acc = torch.empty(3 * n, dtype=torch.float64, device=dev)
+    var = torch.empty(n, dtype=rt, device=dev)
+    g = _i32(gather, dev)
+    snr = sigma = nv = None
+    if snr_lin is not None:
+        snr = torch.as_tensor(snr_lin, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+        sigma = torch.empty(n, dtype=rt, device=dev)
+        nv = torch.empty(n, dtype=rt, device=dev)
+    fn = getattr(lib(), 'nrx_noise_level_' + sfx)
+    check(fn(ptr(flat), m, m, ptr(g), 0 if g is None else g.numel(), n, ptr(acc), ptr(var), ptr(snr),
+             0 if snr is None or snr.numel() == 1 else 1, float(mult), ptr(sigma), ptr(nv), float(nv_mult), stream()))
+    return var, sigma, nv
+
+
+def add_noise(x, z, sigma):
+    """x + (sigma/sqrt2) * z with caller-supplied standard-normal pairs z (parity mode)."""
+    x = x.contiguous()
+    sfx, rt = _ct(x)
+    n = x.shape[0]
+    z = z.to(x.dtype).contiguous()
+    if z.shape != x.shape:
+        raise ValueError(f"Shape Mismatch: Grid: {tuple(x.shape)} vs Noise: {tuple(z.shape)}")
+    sg = torch.as_tensor(sigma, dtype=rt, device=_dev(x)).reshape(-1).contiguous()
+    out = torch.empty_like(x)
+    fn = getattr(lib(), 'nrx_add_noise_' + sfx)
+    check(fn(ptr(x), ptr(z), ptr(sg), 0 if sg.numel() == 1 else 1, x[0].numel(), ptr(out), n, stream()))
+    return out
+
+
+def awgn(x, sigma, seed, stream_id=0, batch_offset=0):
+    """x + complex AWGN of std sigma[b] from the counter-based device generator (throughput mode)."""
+    x = x.contiguous()
+    sfx, rt = _ct(x)
+    n = x.shape[0]
+    sg = torch.as_tensor(sigma, dtype=rt, device=_dev(x)).reshape(-1).contiguous()
+    out = torch.empty_like(x)
+    fn = getattr(lib(), 'nrx_awgn_' + sfx)
+    check(fn(ptr(x), ptr(sg), 0 if sg.numel() == 1 else 1, x[0].numel(), ptr(out), n, int(seed), int(stream_id),
+             int(batch_offset), stream()))
+    return out
+
+
+# -------------------------------------------------------------------------------------------------------- OFDM
+def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0):
+    """Grid.ofdmModulate (+windowing): (n,P,L,K) -> (n,P,slotLen+pad) (the pad samples are zeros, Waveform.pad)."""
+    grid = grid.contiguous()
+    sfx, _ = _ct(grid)
+    n, P, L, K = grid.shape
+    if len(cp_lens) != L:
+        raise ValueError("one CP length per OFDM symbol is required")
+    S = int(sum(cp_lens)) + L * nfft
+    wave = torch.zeros((n, P, S + pad), dtype=grid.dtype, device=_dev(grid))
+    fn = getattr(lib(), 'nrx_ofdm_modulate_' + sfx)
+    check(fn(ptr(grid), n * P, K, nfft, _host_i32(cp_lens), L, int(window_len), ptr(wave), S + pad, stream()))
+    return wave
+
+
+def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None):
+    """Waveform.sync(t_off).ofdmDemodulate: (n,Nr,S_in) -> (n,Nr,L,K)."""
+    wave = wave.contiguous()
+    sfx, _ = _ct(wave)
+    n, nr, S_in = wave.shape
+    L = len(cp_lens)
+    dev = _dev(wave)
+    to = _i32(t_off, dev)
+    if to is not None:
+        to = to.reshape(-1)
+        if to.numel() not in (1, n):
+            raise ValueError("one timing offset per batch item expected")
+    grid = torch.empty((n, nr, L, K), dtype=wave.dtype, device=dev)
+    fn = getattr(lib(), 'nrx_ofdm_demodulate_' + sfx)
+    check(fn(ptr(wave), S_in, S_in, ptr(to), 0 if to is None or to.numel() == 1 else 1, n, nr, K, nfft,
+             _host_i32(cp_lens), L, ptr(grid), stream()))
+    return grid
+
+
+# ----------------------------------------------------------------------------------------- tapped delay line
+def cdl_gains(A, nu, times, A_los=None, nu_los=0.0):
+    """Time-varying CDL path gains: A (Nr,Nt,N,M) c128, nu (N,M) f64, times (n,T) f64 -> (n,T,Nr,Nt,P)."""
+    A = A.to(torch.complex128).contiguous()
+    nr, nt, N, M = A.shape
+    dev = _dev(A)
+    nu = nu.to(device=dev, dtype=torch.float64).contiguous()
+    times = times.to(device=dev, dtype=torch.float64).contiguous()
+    n, T = times.shape
+    al = None if A_los is None else A_los.to(device=dev, dtype=torch.complex128).contiguous()
+    P = N + (0 if al is None else 1)
+    gains = torch.empty((n, T, nr, nt, P), dtype=torch.complex128, device=dev)
+    check(lib().nrx_cdl_gains_f64(ptr(A), ptr(nu), ptr(al), float(nu_los), ptr(times), n, T, nr, nt, N, M, ptr(gains),
+                                  stream()))
+    return gains
+
+
+def cir(gains, coeff, nc):
+    """gains (n,T,Nr,Nt,P) x coeff (P,cl) -> cir (n,T,Nr,Nt,cl), chanOffset (n,) int32 (from the first nc instants)."""
+    gains = gains.to(torch.complex128).contiguous()
+    n, T, nr, nt, P = gains.shape
+    dev = _dev(gains)
+    coeff = coeff.to(device=dev, dtype=torch.float64).contiguous()
+    if coeff.shape[0] != P:
+        raise ValueError("coefficient matrix / path count mismatch")
+    cl = coeff.shape[1]
+    out = torch.empty((n, T, nr, nt, cl), dtype=torch.complex128, device=dev)
+    off = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib().nrx_cir_f64(ptr(gains), ptr(coeff), n, T, nc, nr, nt, P, cl, ptr(out), ptr(off), stream()))
+    return out, off
+
+
+def channel_matrix(cir_t, off, nc, K, nfft):
+    """ChannelModel.getChannelMatrix: cir (n,T,Nr,Nt,cl) -> H (n,nc,K,Nr,Nt)."""
+    cir_t = cir_t.contiguous()
+    n, T, nr, nt, cl = cir_t.shape
+    dev = _dev(cir_t)
+    H = torch.empty((n, nc, K, nr, nt), dtype=torch.complex128, device=dev)
+    check(lib().nrx_channel_matrix_f64(ptr(cir_t), n, T, nc, nr, nt, cl, ptr(_i32(off, dev)), K, nfft, ptr(H), stream()))
+    return H
+
+
+def apply_td(x, cir1, set_lens):
+    """ChannelModel.applyToSignal: x (n,Nt,ns), cir1 (n,nc+1,Nr,Nt,cl) -> (n,Nr,ns)."""
+    x = x.to(torch.complex128).contiguous()
+    cir1 = cir1.contiguous()
+    n, nt, ns = x.shape
+    if cir1.shape[0] != n or cir1.shape[3] != nt or cir1.shape[1] != len(set_lens):
+        raise ValueError("The number of transmit antennas in the signal does not match the channel.")
+    nr, cl = cir1.shape[2], cir1.shape[4]
+    y = torch.empty((n, nr, ns), dtype=torch.complex128, device=_dev(x))
+    check(lib().nrx_apply_td_f64(ptr(x), n, nt, ns, ptr(cir1), len(set_lens), nr, cl, _host_i32(set_lens), ptr(y),
+                                 stream()))
+    return y
+
+
+def chest_ls(rx, pilots, port_ks, dmrs_syms, l_cdm=1, k_cdm=2, pil_set=None):
+    """Grid.estimateChannelLS (linear): rx (n,Nr,L,K), pilots (sets,P,nDs,nK) -> (n,L,K,Nr,P)."""
+    rx = rx.contiguous()
+    sfx, _ = _ct(rx)
+    n, nr, L, K = rx.shape
+    dev = _dev(rx)
+    pilots = pilots.to(device=dev, dtype=rx.dtype).contiguous()
+    if pilots.dim() == 3:
+        pilots = pilots[None]
+    sets, P, nds, nk = pilots.shape
+    if nds != len(dmrs_syms):
+        raise ValueError("pilot / DMRS symbol count mismatch")
+    pk = _i32(port_ks, dev)
+    if tuple(pk.shape) != (P, nk):
+        raise ValueError("port_ks must be (P, nK)")
+    if int(pk.max()) >= K or int(pk.min()) < 0:
+        raise ValueError("pilot subcarrier index out of range")
+    ps = _i32(pil_set, dev)
+    if ps is not None and (ps.numel() != n or int(ps.max()) >= sets):
+        raise ValueError("pil_set must hold one valid pilot-set index per batch item")
+    hest = torch.empty((n, L, K, nr, P), dtype=rx.dtype, device=dev)
+    fn = getattr(lib(), 'nrx_chest_ls_' + sfx)
+    check(fn(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), _host_i32(dmrs_syms), nds, l_cdm, k_cdm, nk, L, K, nr, P, ptr(hest),
+             n, stream()))
+    return hest

@@ -1,0 +1,212 @@
+"""GPU parity: modem / grid / OFDM / channel / estimator kernels through the C ABI vs the NumPy oracle (float64).
+
+Tolerances (written out per the north star): complex128 paths <= 1e-10 relative to the array's scale (FFT, FIR,
+interpolation and 4x4 solves are mathematically defined; only rounding order differs); LLRs <= 1e-9 absolute in
+float64 and <= 1e-5 relative to the LLR scale in float32.
+"""
+import numpy as np
+import pytest
+
+from oracle import phy as op
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def crandn(rng, *shape):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
+
+
+@pytest.mark.parametrize("mod", ['BPSK', 'QPSK', '16QAM', '64QAM', '256QAM', '1024QAM'])
+def test_modem(dev, mod):
+    import torch
+    from neoradium_amd import ops
+    qm = op.QM[mod]
+    rng = np.random.default_rng(qm)
+    n, ns = 3, 257
+    bits = rng.integers(0, 2, (n, ns * qm)).astype(np.uint8)
+    ref = np.stack([op.modulate(b, qm) for b in bits])
+    out = ops.qam_map(T(bits, dev), qm).cpu().numpy()
+    assert np.array_equal(out, ref)                                   # constellation points are exact
+    y = ref + 0.15 * crandn(rng, n, ns)
+    nv = np.array([0.02, 0.05, 0.3])
+    llr = ops.qam_demap(T(y, dev), T(nv, dev), qm).cpu().numpy()
+    refl = np.stack([op.demap_maxlog(y[i], nv[i], qm) for i in range(n)])
+    assert np.abs(llr - refl).max() <= 1e-9
+    assert np.array_equal(llr < 0, refl < 0) or np.abs(refl[(llr < 0) != (refl < 0)]).max() < 1e-9
+    llr32 = ops.qam_demap(T(y, dev), T(nv, dev), qm, llr_dtype=torch.float32).cpu().numpy()
+    assert np.abs(llr32 - refl).max() <= 1e-5 * np.abs(refl).max()
+    if qm <= 6:
+        ex = ops.qam_demap(T(y, dev), T(nv, dev), qm, exact=True).cpu().numpy()
+        refe = np.stack([op.demap_exact(y[i], nv[i], qm) for i in range(n)])
+        assert np.abs(ex - refe).max() <= 1e-8 * max(1.0, np.abs(refe).max())
+
+
+def test_pdsch_map_demap_with_scrambling_and_index(dev):
+    from neoradium_amd import ops
+    rng = np.random.default_rng(3)
+    qm, nl, L, K = 6, 2, 14, 48
+    elems = nl * L * K
+    nsym = 500
+    re_index = rng.permutation(elems)[:nsym].astype(np.int32)
+    cinit = op.pdsch_scramble_cinit(1, 0, 17)
+    scr = op.gold(cinit, nsym * qm).astype(np.uint8)
+    bits = rng.integers(0, 2, (2, nsym * qm)).astype(np.uint8)
+    import torch
+    grid = torch.zeros((2, nl, L, K), dtype=torch.complex128, device=dev)
+    ops.qam_map(T(bits, dev), qm, scr=T(scr, dev), re_index=T(re_index, dev), out=grid)
+    g = grid.cpu().numpy().reshape(2, -1)
+    for b in range(2):
+        assert np.array_equal(g[b][re_index], op.modulate(bits[b] ^ scr, qm))
+        mask = np.ones(elems, bool); mask[re_index] = False
+        assert not g[b][mask].any()
+    eq = g + 0.05 * crandn(rng, 2, elems)
+    scales = rng.uniform(0.5, 20, (2, elems))
+    nv = np.array([1e-12, 0.01])                                     # first one exercises the 1e-10 floor
+    llr = ops.qam_demap(T(eq, dev), T(nv, dev), qm, scr=T(scr, dev), re_index=T(re_index, dev), scales=T(scales, dev),
+                        nv_floor=1e-10).cpu().numpy()
+    for b in range(2):
+        ref = op.pdsch_llrs(eq[b][re_index], scales[b][re_index], nv[b], qm, cinit)
+        assert np.abs(llr[b] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("nr,nl", [(1, 1), (2, 1), (2, 2), (4, 2), (4, 4), (8, 3)])
+def test_precode_channel_equalize(dev, nr, nl):
+    from neoradium_amd import ops
+    rng = np.random.default_rng(10 * nr + nl)
+    n, L, K, nt = 2, 14, 36, max(nr, nl) * 2
+    x = crandn(rng, n, nl, L, K)
+    f = crandn(rng, n, nt, nl)
+    pg = ops.precode(T(x, dev), T(f, dev)).cpu().numpy()
+    assert rel(pg, np.stack([op.precode(x[i], f[i]) for i in range(n)])) < 1e-13
+    h = crandn(rng, n, L, K, nr, nt)
+    rx = ops.apply_channel_fd(T(pg, dev), T(h, dev)).cpu().numpy()
+    assert rel(rx, np.stack([op.apply_channel_fd(pg[i], h[i]) for i in range(n)])) < 1e-13
+    hf = h @ f[:, None, None]
+    nv = np.array([1e-9, 0.03])
+    eq, sc = ops.mmse_equalize(T(rx, dev), T(hf, dev), T(nv, dev))
+    for i in range(n):
+        e, s = op.equalize_mmse(rx[i], hf[i], nv[i])
+        assert rel(eq[i].cpu().numpy(), e) < 1e-10
+        assert rel(sc[i].cpu().numpy(), s) < 1e-10
+
+
+def test_noise_level_and_noise(dev):
+    import torch
+    from neoradium_amd import ops
+    rng = np.random.default_rng(4)
+    x = crandn(rng, 3, 4, 14, 60) * np.array([1.0, 3.0, 0.1])[:, None, None, None] + 0.2
+    snr_db = np.array([0.0, 10.0, 25.5])
+    var, sigma, nv = ops.noise_level(T(x, dev), snr_lin=10 ** (snr_db / 10))
+    for i in range(3):
+        assert abs(var[i].item() - np.var(x[i])) <= 1e-13 * np.var(x[i])
+        assert abs(sigma[i].item() - op.noise_std_grid(x[i], snr_db[i])) <= 1e-13 * sigma[i].item()
+        assert abs(nv[i].item() - sigma[i].item() ** 2) <= 1e-15
+    z = rng.standard_normal((3, 4, 14, 60, 2))
+    zc = z[..., 0] + 1j * z[..., 1]
+    y = ops.add_noise(T(x, dev), T(zc, dev), sigma).cpu().numpy()
+    s = sigma.cpu().numpy()
+    ref = x + (z * (s / np.sqrt(2))[:, None, None, None, None]) @ np.array([1, 1j])
+    assert rel(y, ref) < 1e-15
+    # counter-based generator: statistics + independence of the batch split
+    big = torch.zeros((4, 200000), dtype=torch.complex128, device=dev)
+    sg = torch.tensor([1.0, 2.0, 0.5, 1.0], dtype=torch.float64, device=dev)
+    a = ops.awgn(big, sg, seed=99).cpu().numpy()
+    for i in range(4):
+        assert abs(np.var(a[i]) - sg[i].item() ** 2) < 0.02 * sg[i].item() ** 2
+        assert abs(a[i].mean()) < 0.02 and abs(np.var(a[i].real) - np.var(a[i].imag)) < 0.03 * sg[i].item() ** 2
+    b = ops.awgn(big[2:], sg[2:], seed=99, batch_offset=2).cpu().numpy()
+    assert np.array_equal(a[2:], b)
+
+
+@pytest.mark.parametrize("mu,nfft,K,slot", [(0, 2048, 300, 0), (1, 1024, 612, 1), (1, 4096, 3276, 0), (2, 512, 240, 2)])
+def test_ofdm_mod_demod(dev, mu, nfft, K, slot):
+    from neoradium_amd import ops
+    rng = np.random.default_rng(nfft + K)
+    n, P, L = 2, 2, 14
+    grid = crandn(rng, n, P, L, K)
+    cps = op.cp_lens_slot(mu, slot, nfft)
+    w = op.window_len_std(cps)
+    for win in (0, w):
+        wave = ops.ofdm_modulate(T(grid, dev), nfft, cps, window_len=win, pad=7).cpu().numpy()
+        ref = np.stack([op.ofdm_modulate(grid[i], nfft, cps, window=win > 0) for i in range(n)])
+        assert rel(wave[..., :-7], ref) < 1e-12, win
+        assert not wave[..., -7:].any()
+    # demodulate a time-shifted noisy waveform with per-item timing offsets
+    S = ref.shape[-1]
+    rxw = np.concatenate([crandn(rng, n, P, 20), ref, crandn(rng, n, P, 30)], axis=-1)
+    toff = np.array([20, 17], dtype=np.int32)
+    g = ops.ofdm_demodulate(T(rxw, dev), nfft, cps, K, t_off=T(toff, dev)).cpu().numpy()
+    for i in range(n):
+        assert rel(g[i], op.ofdm_demodulate(rxw[i][:, toff[i]:], nfft, cps, K)) < 1e-12
+    # round trip without windowing recovers the grid (cdlTiming.ipynb cell 3: NMSE ~ 1e-32)
+    nw = ops.ofdm_modulate(T(grid, dev), nfft, cps, window_len=0)
+    back = ops.ofdm_demodulate(nw, nfft, cps, K).cpu().numpy()
+    assert rel(back, grid) < 1e-12
+
+
+def test_tdl_chain(dev):
+    """gains -> CIR -> channel matrix / time-domain filtering, CDL-like random static tensors."""
+    from neoradium_amd import ops
+    rng = np.random.default_rng(8)
+    n, nr, nt, N, M, nfft, K, mu = 2, 2, 4, 5, 20, 1024, 300, 1
+    A = crandn(rng, nr, nt, N, M) / np.sqrt(M)
+    nu = rng.uniform(-50, 50, (N, M))
+    Alos, nulos = crandn(rng, nr, nt), 33.0
+    fs = 30.72e6
+    cps = np.append(op.cp_lens_slot(mu, 0, nfft), op.cp_lens_slot(mu, 1, nfft)[0])
+    slot_len = int((cps[:-1] + nfft).sum())
+    times = np.stack([op.sym_gain_times(cps, nfft, s * slot_len) / fs for s in (3, 4)])
+    gains = ops.cdl_gains(T(A, dev), T(nu, dev), T(times, dev), A_los=T(Alos, dev), nu_los=nulos)
+    ph = np.exp(2j * np.pi * times[:, :, None, None] * nu[None, None])
+    ref_nlos = np.einsum('rtnm,bcnm->bcrtn', A, ph)
+    ref_los = Alos[None, None] * np.exp(2j * np.pi * times * nulos)[:, :, None, None]
+    ref_g = np.concatenate([ref_los[..., None], ref_nlos], axis=-1)
+    assert rel(gains.cpu().numpy(), ref_g) < 1e-11
+    delays = np.sort(rng.uniform(0, 900, N + 1))
+    delays[0] = 0
+    coeff, _ = op.coeff_matrix(delays, fs, op.build_firs())
+    nc = 14
+    cir, off = ops.cir(gains, T(coeff, dev), nc)
+    for b in range(n):
+        c_ref, o_ref = op.cir_from_gains(ref_g[b][:nc], coeff)
+        assert rel(cir[b, :nc].cpu().numpy(), c_ref) < 1e-11 and int(off[b]) == o_ref
+    H = ops.channel_matrix(cir, off, nc, K, nfft).cpu().numpy()
+    for b in range(n):
+        c_ref, o_ref = op.cir_from_gains(ref_g[b][:nc], coeff)
+        assert rel(H[b], op.channel_matrix(c_ref, o_ref, nfft, K)) < 1e-11
+    ns = slot_len + coeff.shape[1] + 5
+    x = crandn(rng, n, nt, ns)
+    x[..., slot_len:] = 0
+    y = ops.apply_td(T(x, dev), cir, list(cps + nfft)).cpu().numpy()
+    for b in range(n):
+        assert rel(y[b], op.apply_td(x[b], ref_g[b], coeff, cps + nfft)) < 1e-11
+
+
+@pytest.mark.parametrize("P,l_cdm,ds,ctype", [(1, 1, [2], 1), (2, 1, [2, 11], 1), (4, 1, [2, 7, 11], 1), (4, 2, [2, 3, 10, 11], 1),
+                                             (3, 1, [3, 9], 2)])
+def test_chest_ls(dev, P, l_cdm, ds, ctype):
+    from neoradium_amd import ops
+    rng = np.random.default_rng(P * 7 + l_cdm)
+    n, nr, L, nrb = 2, 2, 14, 6
+    K = 12 * nrb
+    base = np.arange(0, 11, 2) if ctype == 1 else np.array([0, 1, 6, 7])
+    delta = [(p // 2) % 2 if ctype == 1 else 2 * ((p // 2) % 3) for p in range(P)]
+    ks = np.stack([np.concatenate([12 * rb + base + delta[p] for rb in range(nrb)]) for p in range(P)])
+    nk = ks.shape[1]
+    sets = 3
+    pil = np.exp(1j * rng.uniform(0, 2 * np.pi, (sets, P, len(ds), nk)))
+    rx = crandn(rng, n, nr, L, K)
+    pset = np.array([2, 0], dtype=np.int32)
+    h = ops.chest_ls(T(rx, dev), T(pil, dev), ks, ds, l_cdm=l_cdm, k_cdm=2, pil_set=pset).cpu().numpy()
+    for b in range(n):
+        ref = op.estimate_channel_ls(rx[b], pil[pset[b]], ds, ks, l_cdm=l_cdm, k_cdm=2)
+        assert rel(h[b], ref) < 1e-11
