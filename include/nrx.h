@@ -112,7 +112,8 @@ int32_t nrx_ldpc_decode_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg*
                             void* stream);
 
 /* ldpc.py:1584-1619 checkCrcAndMerge (+ the TB-level checkCrc('24A') the harness applies).
- * dec: (n_tb*C) x K hard bits.  tb_out (nullable): n_tb x B bits (TB incl. its CRC24A).
+ * dec: (n_tb*C) x K hard bits.  tb_out (nullable): n_tb x M bits, M = C*(cb_len - 24) for C>1 (>= B: the TB incl.
+ * its CRC24A followed by the segmentation zero padding, exactly what the reference returns), M = B for C==1.
  * cb_ok: n_tb x C (C>1: CRC24B per block; C==1: the TB CRC24A).  tb_ok (nullable): n_tb (CRC24A of tb_out). */
 int32_t nrx_ldpc_crc_merge(const uint8_t* dec, int32_t n_tb, const nrx_ldpc_cfg* cfg, uint8_t* tb_out,
                            uint8_t* cb_ok, uint8_t* tb_ok, void* stream);
@@ -121,6 +122,9 @@ int32_t nrx_ldpc_crc_merge(const uint8_t* dec, int32_t n_tb, const nrx_ldpc_cfg*
  * [2] += #(tb_out[:, :A] != tb_ref), [3] += n_tb*A.  counters: int64[4] on device, accumulated atomically. */
 int32_t nrx_count_errors(const uint8_t* cb_ok, int32_t n_ok, const uint8_t* tb_out, const uint8_t* tb_ref,
                          int32_t n_tb, int32_t A, int32_t tb_out_stride, int64_t* counters, void* stream);
+
+/* utils.py:70-94 goldSequence: c(0..n-1) of TS 38.211 5.2.1 for c_init, written to a HOST buffer (host-only). */
+int32_t nrx_gold_sequence(uint32_t c_init, int64_t n, uint8_t* out_host);
 
 /* ------------------------------------------------------------------------------------------- modem / mapping
  * modulation.py:127-156 Modem.modulate fused with pdsch.py:603-608 scrambleBits and the layer/RE scatter of
@@ -200,6 +204,11 @@ int32_t nrx_awgn_f32(const void* x, const void* sigma, int32_t sigma_stride, int
 int32_t nrx_awgn_f64(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out,
                      int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream);
 
+/* Synthetic transport blocks (random.py:202 bits) for the throughput mode: n_batch x n_per uniform bits from the
+ * same counter-based generator (independent of launch geometry / batch split / GPU count). */
+int32_t nrx_random_bits(uint8_t* out, int64_t n_per, int32_t n_batch, uint64_t seed, uint64_t stream_id,
+                        int64_t batch_offset, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------ OFDM
  * grid.py:521-582 Grid.ofdmModulate (f0=0) + waveform.py:380-470 applyWindowing: grid rows (n_rows = items*ports,
  * each n_sym x K) -> waveform rows of wave_stride samples (slot length = sum(cp)+n_sym*nfft used).
@@ -234,6 +243,18 @@ int32_t nrx_cir_f64(const void* gains, const double* coeff, int32_t n_items, int
 /* channelmodel.py:362-400 getChannelMatrix: H (n_items,nc,K,n_rx,n_tx) from the first nc CIRs of each item. */
 int32_t nrx_channel_matrix_f64(const void* cir, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx, int32_t n_tx,
                                int32_t cl, const int32_t* chan_offset, int32_t K, int32_t nfft, void* H, void* stream);
+/* The same transform at n_k consecutive subcarriers from k0 only (direct DFT): H_sub (n_items,nc,n_k,n_rx,n_tx). */
+int32_t nrx_channel_matrix_sub_f64(const void* cir, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx,
+                                   int32_t n_tx, int32_t cl, const int32_t* chan_offset, int32_t K, int32_t nfft,
+                                   int32_t k0, int32_t n_k, void* H, void* stream);
+/* pdsch.py:1080-1131 getPrecodingMatrix (one precoding group): mean of the n_avg (n_rx x n_tx) matrices of each item,
+ * SVD, F = V[:, :n_layers]/sqrt(n_layers) -> (n_items,n_tx,n_layers).  Column phases are implementation defined. */
+int32_t nrx_svd_precoder_f64(const void* H_block, int32_t n_items, int32_t n_avg, int32_t n_rx, int32_t n_tx,
+                             int32_t n_layers, void* F, void* stream);
+/* "Perfect" channel state of the BLER harness (PDSCH-BLER.ipynb: channelMatrix @ precoder[None,...]):
+ * out (n_items,lk,n_rx,n_layers) = H (n_items,lk,n_rx,n_tx) x F (n_tx,n_layers; item b at F + b*f_stride). */
+int32_t nrx_effective_channel_f64(const void* H, const void* F, int64_t f_stride, int32_t n_items, int32_t lk,
+                                  int32_t n_rx, int32_t n_tx, int32_t n_layers, void* out, void* stream);
 /* channelmodel.py:403-448 applyToSignal: x (n_items,n_tx,ns) -> y (n_items,n_rx,ns) with the CIR of gain set
  * sym(n) of the OUTPUT sample; cir1 (n_items,n_sets,n_rx,n_tx,cl); set_lens: HOST array of n_sets whole-symbol
  * lengths (bwp.getSymLens(), the last set also covers samples beyond their sum).  n_rx in {1,2,4,8}. */

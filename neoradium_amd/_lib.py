@@ -30,6 +30,7 @@ _cfgp = C.POINTER(LdpcCfg)
 SIGNATURES = {
     'nrx_version': (i32, []),
     'nrx_last_error': (i32, [C.c_char_p, i32]),
+    'nrx_gold_sequence': (i32, [C.c_uint32, i64, C.c_char_p]),
     'nrx_crc': (i32, [vp, i32, i64, i64, i32, vp, vp]),
     'nrx_ldpc_config': (i32, [i32, i32, _cfgp]),
     'nrx_ldpc_cb_lens': (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
@@ -67,8 +68,11 @@ SIGNATURES.update({
     'nrx_cir_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_channel_matrix_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     'nrx_apply_td_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, _i32p, vp, vp]),
+    'nrx_random_bits': (i32, [vp, i64, i32, u64_, u64_, i64, vp]),
+    'nrx_channel_matrix_sub_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp]),
+    'nrx_svd_precoder_f64': (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    'nrx_effective_channel_f64': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
 })
-_unused = {}
 
 _lib = None
 
@@ -129,3 +133,11 @@ def ldpc_cb_lens(G, Cn, nl, qm):
     arr = (i32 * Cn)()
     check(lib().nrx_ldpc_cb_lens(int(G), int(Cn), int(nl), int(qm), arr))
     return list(arr)
+
+
+def gold_sequence(c_init, n):
+    """utils.py:70-94 goldSequence -> numpy int8 array of n bits (host)."""
+    import numpy as np
+    buf = C.create_string_buffer(max(int(n), 1))
+    check(lib().nrx_gold_sequence(int(c_init) & 0xFFFFFFFF, int(n), buf))
+    return np.frombuffer(buf.raw, dtype=np.uint8, count=int(n)).astype(np.int8)

@@ -70,3 +70,19 @@ extern "C" int32_t nrx_ldpc_cb_lens(int32_t G, int32_t C, int32_t nl, int32_t qm
   for (int r = 0; r < C; ++r) e_out[r] = (gb / C) * f + ((gb % C) && r >= C - gb % C ? f : 0);
   return NRX_OK;
 }
+
+// TS 38.211 5.2.1 length-31 Gold sequence c(n), Nc = 1600 (reference utils.py:70-94 goldSequence).  Host-only:
+// scrambling / DMRS sequences are per-configuration constants that the wrappers upload once.
+extern "C" int32_t nrx_gold_sequence(uint32_t c_init, int64_t n, uint8_t* out_host) {
+  NRX_REQUIRE(out_host && n >= 0, NRX_E_ARG, "nrx_gold_sequence: bad argument");
+  uint32_t x1 = 1u, x2 = c_init & 0x7FFFFFFFu;   // bit i of the word = x(n+i)
+  auto step1 = [](uint32_t x) { return (x >> 1) | ((((x >> 3) ^ x) & 1u) << 30); };
+  auto step2 = [](uint32_t x) { return (x >> 1) | ((((x >> 3) ^ (x >> 2) ^ (x >> 1) ^ x) & 1u) << 30); };
+  for (int i = 0; i < 1600; ++i) { x1 = step1(x1); x2 = step2(x2); }
+  for (int64_t i = 0; i < n; ++i) {
+    out_host[i] = (uint8_t)((x1 ^ x2) & 1u);
+    x1 = step1(x1);
+    x2 = step2(x2);
+  }
+  return NRX_OK;
+}

@@ -277,3 +277,166 @@ extern "C" int32_t nrx_apply_td_f64(const void* x, int32_t n_items, int32_t n_tx
   NRX_CHECK_LAUNCH("nrx_apply_td");
   return NRX_OK;
 }
+
+// ------------------------------------------------------------------------------ channel at selected subcarriers
+// Direct DFT of the CIR at n_k consecutive subcarriers starting at k0 (same result as nrx_channel_matrix at those
+// bins; channelmodel.py:381-399) -- used for the wideband SVD precoder, which by the reference's grouping quirk
+// only looks at the first PRB (pdsch.py:1142-1163), so the full K-point transform is not needed in the
+// time-domain path.  H_sub: (n_items, nc, n_k, n_rx*n_tx).
+namespace {
+__global__ void __launch_bounds__(256)
+chan_matrix_sub_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int n_rt, int cl, const int32_t* __restrict__ off,
+                       int K, int nfft, int k0, int n_k, cd* __restrict__ H, int64_t total) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int rt = (int)(g % n_rt);
+    const int k = (int)((g / n_rt) % n_k);
+    const int c = (int)((g / ((int64_t)n_rt * n_k)) % nc);
+    const int b = (int)(g / ((int64_t)n_rt * n_k * nc));
+    const cd* src = cir + (((size_t)b * n_t_total + c) * n_rt + rt) * cl;
+    const int bin = (k0 + k - K / 2 + nfft) & (nfft - 1);
+    const int o = off[b];
+    const int use = cl < nfft ? cl : nfft;
+    cd acc(0, 0);
+    for (int l = 0; l < use; ++l) {
+      const int pos = (l - o + nfft) & (nfft - 1);
+      const int ph = (int)(((int64_t)bin * pos) & (nfft - 1));
+      double s, c2;
+      sincospi(-2.0 * (double)ph / (double)nfft, &s, &c2);
+      nrx::cmac(acc, src[l], cd(c2, s));
+    }
+    H[g] = acc;
+  }
+}
+
+// SVD precoder (pdsch.py:1125-1131): mean of H over the given (symbols x subcarriers) block, right singular
+// vectors of the Nr x Nt mean via a cyclic Jacobi eigen-decomposition of G = Hm Hm^H (Nr x Nr Hermitian),
+// v_i = Hm^H u_i / sigma_i, F = V[:, :nl] / sqrt(nl).  One thread per batch item (the matrices are tiny).
+// Column phases are implementation defined (LAPACK's are too); H*F -- all that the link sees -- is not.
+constexpr int PMAX = 8;
+__global__ void svd_precoder_kernel(const cd* __restrict__ Hblk, int n_avg, int nr, int nt, int nl, cd* __restrict__ F,
+                                    int n_items) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_items) return;
+  cd Hm[PMAX][32];
+  const cd* src = Hblk + (size_t)b * n_avg * nr * nt;
+  for (int r = 0; r < nr; ++r)
+    for (int t = 0; t < nt; ++t) {
+      cd s(0, 0);
+      for (int a = 0; a < n_avg; ++a) s = s + src[((size_t)a * nr + r) * nt + t];
+      Hm[r][t] = cd(s.re / n_avg, s.im / n_avg);
+    }
+  cd G[PMAX][PMAX], U[PMAX][PMAX];
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nr; ++j) {
+      cd s(0, 0);
+      for (int t = 0; t < nt; ++t) nrx::cmacc(s, Hm[j][t], Hm[i][t]);  // conj(Hm[j][t]) * Hm[i][t]
+      G[i][j] = s;
+      U[i][j] = cd(i == j ? 1.0 : 0.0, 0.0);
+    }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double offn = 0;
+    for (int p = 0; p < nr; ++p)
+      for (int q = p + 1; q < nr; ++q) offn += nrx::norm2(G[p][q]);
+    if (offn < 1e-300) break;
+    for (int p = 0; p < nr; ++p)
+      for (int q = p + 1; q < nr; ++q) {
+        const double apq = sqrt(nrx::norm2(G[p][q]));
+        if (apq < 1e-300) continue;
+        // complex Jacobi rotation zeroing G[p][q]
+        const cd ph(G[p][q].re / apq, G[p][q].im / apq);  // e^{j arg(G_pq)}
+        const double tau = (G[q][q].re - G[p][p].re) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+        // J = [[c, s*ph],[-s*conj(ph), c]] applied as G <- J^H G J, U <- U J
+        for (int k = 0; k < nr; ++k) {  // columns p,q
+          const cd gkp = G[k][p], gkq = G[k][q];
+          G[k][p] = cd(c * gkp.re - s * (gkq.re * ph.re + gkq.im * ph.im), c * gkp.im - s * (gkq.im * ph.re - gkq.re * ph.im));
+          G[k][q] = cd(s * (gkp.re * ph.re - gkp.im * ph.im) + c * gkq.re, s * (gkp.re * ph.im + gkp.im * ph.re) + c * gkq.im);
+          const cd ukp = U[k][p], ukq = U[k][q];
+          U[k][p] = cd(c * ukp.re - s * (ukq.re * ph.re + ukq.im * ph.im), c * ukp.im - s * (ukq.im * ph.re - ukq.re * ph.im));
+          U[k][q] = cd(s * (ukp.re * ph.re - ukp.im * ph.im) + c * ukq.re, s * (ukp.re * ph.im + ukp.im * ph.re) + c * ukq.im);
+        }
+        for (int k = 0; k < nr; ++k) {  // rows p,q
+          const cd gpk = G[p][k], gqk = G[q][k];
+          G[p][k] = cd(c * gpk.re - s * (gqk.re * ph.re - gqk.im * ph.im), c * gpk.im - s * (gqk.re * ph.im + gqk.im * ph.re));
+          G[q][k] = cd(s * (gpk.re * ph.re + gpk.im * ph.im) + c * gqk.re, s * (gpk.im * ph.re - gpk.re * ph.im) + c * gqk.im);
+        }
+      }
+  }
+  // order by descending eigenvalue, emit the first nl right singular vectors
+  int order[PMAX];
+  for (int i = 0; i < nr; ++i) order[i] = i;
+  for (int i = 0; i < nr; ++i)
+    for (int j = i + 1; j < nr; ++j)
+      if (G[order[j]][order[j]].re > G[order[i]][order[i]].re) { const int tmp = order[i]; order[i] = order[j]; order[j] = tmp; }
+  const double inv_nl = 1.0 / sqrt((double)nl);
+  for (int i = 0; i < nl; ++i) {
+    const int e = order[i];
+    double nrm = 0;
+    cd v[32];
+    for (int t = 0; t < nt; ++t) {
+      cd s(0, 0);
+      for (int r = 0; r < nr; ++r) nrx::cmacc(s, Hm[r][t], U[r][e]);  // (Hm^H u)_t
+      v[t] = s;
+      nrm += nrx::norm2(s);
+    }
+    const double sc = nrm > 0 ? inv_nl / sqrt(nrm) : 0.0;
+    for (int t = 0; t < nt; ++t) F[((size_t)b * nt + t) * nl + i] = cd(v[t].re * sc, v[t].im * sc);
+  }
+}
+
+// Hest[b][lk][r][p] = sum_t H[b][lk][r][t] * F[b][t][p]   ("perfect" CSI of the BLER notebook: H @ F)
+__global__ void __launch_bounds__(256)
+eff_channel_kernel(const cd* __restrict__ H, const cd* __restrict__ F, int64_t f_stride, int lk, int nr, int nt, int nl,
+                   cd* __restrict__ out, int64_t total) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(g % nl);
+    const int r = (int)((g / nl) % nr);
+    const int64_t i = g / ((int64_t)nl * nr);  // b*lk + re
+    const int b = (int)(i / lk);
+    const cd* h = H + ((size_t)i * nr + r) * nt;
+    const cd* f = F + (size_t)b * f_stride;
+    cd acc(0, 0);
+    for (int t = 0; t < nt; ++t) nrx::cmac(acc, h[t], f[t * nl + p]);
+    out[g] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int32_t nrx_channel_matrix_sub_f64(const void* cir, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx,
+                                              int32_t n_tx, int32_t cl, const int32_t* chan_offset, int32_t K, int32_t nfft,
+                                              int32_t k0, int32_t n_k, void* H, void* stream) {
+  NRX_REQUIRE(cir && chan_offset && H, NRX_E_ARG, "nrx_channel_matrix_sub: NULL buffer");
+  NRX_REQUIRE(nfft >= 64 && (nfft & (nfft - 1)) == 0 && K > 0 && K <= nfft, NRX_E_ARG, "nrx_channel_matrix_sub: bad nfft/K");
+  NRX_REQUIRE(k0 >= 0 && n_k >= 1 && k0 + n_k <= K && nc >= 1 && nc <= n_t, NRX_E_SHAPE, "nrx_channel_matrix_sub: bad range");
+  const int64_t total = (int64_t)n_items * nc * n_k * n_rx * n_tx;
+  if (total == 0) return NRX_OK;
+  hipLaunchKernelGGL(chan_matrix_sub_kernel, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const cd*)cir, n_t, nc, n_rx * n_tx, cl, chan_offset, K, nfft, k0, n_k, (cd*)H, total);
+  NRX_CHECK_LAUNCH("nrx_channel_matrix_sub");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_svd_precoder_f64(const void* H_block, int32_t n_items, int32_t n_avg, int32_t n_rx, int32_t n_tx,
+                                        int32_t n_layers, void* F, void* stream) {
+  NRX_REQUIRE(H_block && F, NRX_E_ARG, "nrx_svd_precoder: NULL buffer");
+  NRX_REQUIRE(n_rx >= 1 && n_rx <= PMAX && n_tx >= 1 && n_tx <= 32 && n_avg >= 1, NRX_E_UNSUPPORTED,
+              "nrx_svd_precoder: Nr <= 8 and Nt <= 32 supported (got %dx%d)", n_rx, n_tx);
+  NRX_REQUIRE(n_layers >= 1 && n_layers <= n_rx && n_layers <= n_tx, NRX_E_ARG, "nrx_svd_precoder: layers must be <= min(Nr,Nt)");
+  if (n_items == 0) return NRX_OK;
+  hipLaunchKernelGGL(svd_precoder_kernel, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const cd*)H_block,
+                     n_avg, n_rx, n_tx, n_layers, (cd*)F, n_items);
+  NRX_CHECK_LAUNCH("nrx_svd_precoder");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_effective_channel_f64(const void* H, const void* F, int64_t f_stride, int32_t n_items, int32_t lk,
+                                             int32_t n_rx, int32_t n_tx, int32_t n_layers, void* out, void* stream) {
+  NRX_REQUIRE(H && F && out, NRX_E_ARG, "nrx_effective_channel: NULL buffer");
+  const int64_t total = (int64_t)n_items * lk * n_rx * n_layers;
+  if (total == 0) return NRX_OK;
+  hipLaunchKernelGGL(eff_channel_kernel, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const cd*)H, (const cd*)F, f_stride, lk, n_rx, n_tx, n_layers, (cd*)out, total);
+  NRX_CHECK_LAUNCH("nrx_effective_channel");
+  return NRX_OK;
+}

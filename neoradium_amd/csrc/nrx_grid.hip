@@ -253,6 +253,24 @@ awgn_philox_kernel(const cx<T>* __restrict__ x, const T* __restrict__ sigma, int
   }
 }
 
+// Synthetic transport blocks for the throughput mode: bit e of item b = one Philox output bit, keyed like awgn.
+__global__ void __launch_bounds__(256)
+random_bits_kernel(uint8_t* __restrict__ out, int64_t n_per, int n_batch, uint64_t seed, uint64_t stream_id,
+                   int64_t batch_offset) {
+  const int64_t words = (n_per + 127) / 128;  // one Philox call = 128 bits
+  const int64_t total = (int64_t)n_batch * words;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / words);
+    const int64_t w = g - (int64_t)b * words;
+    const uint64_t item = (uint64_t)(batch_offset + b);
+    uint32_t c[4] = {(uint32_t)w, (uint32_t)((uint64_t)w >> 32), (uint32_t)item, (uint32_t)(item >> 32) ^ (uint32_t)stream_id};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint8_t* dst = out + (size_t)b * n_per + w * 128;
+    const int64_t lim = n_per - w * 128 < 128 ? n_per - w * 128 : 128;
+    for (int i = 0; i < lim; ++i) dst[i] = (uint8_t)((c[i >> 5] >> (i & 31)) & 1u);
+  }
+}
+
 template <typename T, int NR>
 int32_t mmse_dispatch_nl(int nl, dim3 grid, hipStream_t st, const cx<T>* rx, const cx<T>* hf, int64_t h_stride,
                          const T* nv, int nv_stride, int lk, cx<T>* eq, T* sc, int n_batch) {
@@ -383,3 +401,13 @@ static int32_t awgn_entry(const void* x, const void* sigma, int32_t sigma_stride
 }
 extern "C" int32_t nrx_awgn_f32(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) { return awgn_entry<float>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, stream); }
 extern "C" int32_t nrx_awgn_f64(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) { return awgn_entry<double>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, stream); }
+
+extern "C" int32_t nrx_random_bits(uint8_t* out, int64_t n_per, int32_t n_batch, uint64_t seed, uint64_t stream_id,
+                                   int64_t batch_offset, void* stream) {
+  NRX_REQUIRE(out && n_per >= 0 && n_batch >= 0, NRX_E_ARG, "nrx_random_bits: bad argument");
+  if (n_per == 0 || n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(random_bits_kernel, dim3(nrx::stream_grid(((long)n_per + 127) / 128 * n_batch, 256)), dim3(256), 0,
+                     (hipStream_t)stream, out, n_per, n_batch, seed, stream_id, batch_offset);
+  NRX_CHECK_LAUNCH("nrx_random_bits");
+  return NRX_OK;
+}

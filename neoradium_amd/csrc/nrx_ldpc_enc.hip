@@ -287,12 +287,9 @@ crc_merge_kernel(const uint8_t* __restrict__ dec, int C, int K, int cb_len, int 
   const uint8_t* row = dec + (size_t)blockIdx.x * K;
   const int payload = C > 1 ? cb_len - 24 : cb_len;
   if (tb_out) {
-    // merged stream is C*payload >= B bits long; the caller's row holds B of them
-    uint8_t* dst = tb_out + (size_t)t * B;
-    for (int i = threadIdx.x; i < payload; i += blockDim.x) {
-      const int64_t gpos = (int64_t)c * payload + i;
-      if (gpos < B) dst[gpos] = row[i] & 1;
-    }
+    // merged stream: C*payload >= B bits (the zero padding of the last block is kept, like the reference)
+    uint8_t* dst = tb_out + (size_t)t * C * payload + (size_t)c * payload;
+    for (int i = threadIdx.x; i < payload; i += blockDim.x) dst[i] = row[i] & 1;
   }
   const uint32_t r = block_crc([&](int64_t i) { return row[i] & 1; }, cb_len, C > 1 ? NRX_CRC24B : NRX_CRC24A, red);
   if (threadIdx.x == 0) cb_ok[blockIdx.x] = r == 0 ? 1 : 0;
@@ -458,7 +455,7 @@ extern "C" int32_t nrx_ldpc_crc_merge(const uint8_t* dec, int32_t n_tb, const nr
                      cfg->K, cfg->cb_len, cfg->B, tb_out, cb_ok);
   if (tb_ok)
     hipLaunchKernelGGL(crc_ok_rows_kernel, dim3(n_tb), dim3(cfg->B > 4096 ? 256 : 64), 0, st, tb_out, (int64_t)cfg->B,
-                       (int64_t)cfg->B, NRX_CRC24A, tb_ok);
+                       (int64_t)cfg->C * (cfg->cb_len - (cfg->C > 1 ? 24 : 0)), NRX_CRC24A, tb_ok);
   NRX_CHECK_LAUNCH("nrx_ldpc_crc_merge");
   return NRX_OK;
 }

@@ -1,0 +1,213 @@
+"""Batched PDSCH Monte-Carlo link engine: the loop body of the reference's BLER harness
+(Playground/PDSCH/PDSCH-BLER.ipynb cell 2) for a whole batch of slots resident on one GPU.
+
+One call of :meth:`PdschLink.run` = `n_slots` independent PDSCH slots through
+
+    random TB -> CRC24A/segmentation/CB-CRC -> LDPC encode -> rate match -> scramble -> QAM -> layer/RE map (+DMRS)
+    -> SVD precoder -> [ OFDM mod (+window) -> tapped-delay-line channel -> AWGN -> timing sync -> OFDM demod ]
+                     | [ frequency-domain channel -> AWGN ]
+    -> DMRS LS channel estimate (or perfect CSI) -> MMSE equalise -> max-log demap + descramble
+    -> rate recovery -> layered min-sum LDPC decode -> CB/TB CRC -> error counters
+
+every stage being one libnrx kernel launch over the whole batch (no host round trips, no per-slot Python).
+Configuration comes from the same host objects the notebooks build (PDSCH + DMRS, CdlChannel/TdlChannel);
+everything that depends only on (configuration, slot number in frame) is precomputed once here.
+
+Slots are independent given their absolute slot index (channel time, DMRS/scrambling by slotNoInFrame), so a
+sweep shards over GPUs by slot range with no data-path communication; only the 4 error counters are reduced.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._dev import D, device as _device
+from .waveform import Waveform
+
+
+class PdschLink:
+    def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
+                 decoder="f32", windowing="STD", dev=None):
+        if pdsch.numCW != 1:
+            raise NotImplementedError("PdschLink: two-codeword PDSCH (more than 4 layers) is not built")
+        if pdsch.prgSize != 0:
+            raise NotImplementedError("PdschLink: only the wideband precoder (prgSize=0) is built")
+        if pdsch.dmrs is None:
+            raise ValueError("PdschLink: the PDSCH needs a DMRS configuration (pdsch.setDMRS)")
+        if chanEst not in ("LS", "Perfect"):
+            raise ValueError("chanEst must be 'LS' or 'Perfect'")
+        if decoder not in ("f32", "f64"):
+            raise ValueError("decoder must be 'f32' (throughput) or 'f64' (bit-exact with the reference arithmetic)")
+        self.dev = _device() if dev is None else dev
+        self.pdsch, self.channel = pdsch, channel
+        self.bwp = bwp = pdsch.bwp
+        self.carrier = bwp.carrier
+        self.freqDomain, self.chanEst, self.decoder = freqDomain, chanEst, decoder
+        self.numIter = int(numIter)
+        self.codeRate = codeRate
+        self.nl = pdsch.numLayers
+        self.qm = pdsch.modems[0].qm
+        self.nr, self.nt = channel.nrNt
+        self.K, self.L, self.nfft = 12 * bwp.numRbs, bwp.symbolsPerSlot, bwp.nFFT
+        dmrs = pdsch.dmrs
+
+        # ---- per slotNoInFrame: DMRS-filled grid template and pilot table
+        saved = self.carrier.slotNo
+        templ, pil = [], []
+        idx0 = None
+        for s in range(bwp.slotsPerFrame):
+            self.carrier.slotNo = s
+            g = pdsch.getGrid()
+            templ.append(g.grid.copy())
+            p, ks, ds = dmrs.getPilots()
+            pil.append(p)
+            if idx0 is None:
+                idx0 = tuple(i.copy() for i in pdsch.dataIndices)
+                self.tbs = int(pdsch.getTxBlockSize(codeRate)[0])
+                self.port_ks, self.dmrs_syms = ks, [int(v) for v in ds]
+            else:
+                assert all(np.array_equal(a, b) for a, b in zip(idx0, pdsch.dataIndices))
+        self.carrier.slotNo = saved
+        self.templates = D(np.stack(templ))                    # (S, Nl, L, K) complex128
+        self.pilots = D(np.stack(pil))                         # (S, P, nDs, nK)
+        self.l_cdm, self.k_cdm = dmrs.symbols, (4 if dmrs.enhanced else 2)
+        n_re = len(idx0[0])
+        self.G = n_re * self.qm
+        lm = pdsch.getLayerMapIndexes(idx0, [n_re])[0]
+        self.re_index = D(np.int32((np.int64(lm[0]) * self.L + lm[1]) * self.K + lm[2]))
+        self.scr = D(pdsch._scrambling(0, self.G))
+        self.cfg = _lib.ldpc_config(baseGraphNo, self.tbs + 24)
+        self.first_prb = int(pdsch.prbSet[0])
+
+        # ---- channel: static ray coefficients + tap matrix on the device
+        A, nu, Alos, nulos = channel._staticOnDevice()
+        self.A, self.nu, self.Alos, self.nulos = A, nu, Alos, nulos
+        coeff = channel.getCoeffMatrix()
+        self.coeff = D(coeff)
+        self.max_delay = channel.getMaxDelay()
+        self.fs = bwp.sampleRate
+        self.window = windowing
+
+        # ---- slot geometry by slot number in subframe
+        spsf = bwp.slotsPerSubFrame
+        self.sym_lens = [bwp.symbolLens[s * self.L:s * self.L + self.L + 1].astype(np.int64) for s in range(spsf)]
+        self.slot_len = [int(v[:-1].sum()) for v in self.sym_lens]
+        self.subframe_len = int(sum(self.slot_len))
+        self._gather = {}
+
+    # ------------------------------------------------------------------------------------------- geometry
+    def slot_start(self, n):
+        """First sample of absolute slot n on the channel's time axis (channelmodel.py:173-193 bookkeeping)."""
+        spsf = self.bwp.slotsPerSubFrame
+        return (n // spsf) * self.subframe_len + int(sum(self.slot_len[:n % spsf]))
+
+    def gain_times(self, slots):
+        """(n, L+1) seconds: starts of the useful part of each symbol (+ first symbol of the next slot)."""
+        spsf = self.bwp.slotsPerSubFrame
+        out = np.empty((len(slots), self.L + 1))
+        for i, n in enumerate(slots):
+            sl = self.sym_lens[n % spsf].copy()
+            sl[0] -= self.nfft
+            out[i] = (self.slot_start(n) + np.cumsum(sl)) / self.fs
+        return out
+
+    def _cp_gather(self, sis, width):
+        """Element offsets of the CP-stripped samples of all Nr rows (Waveform.getRePower, waveform.py:107-117)."""
+        key = (sis, width)
+        if key not in self._gather:
+            cps = (self.sym_lens[sis][:-1] - self.nfft)
+            sym = cps + self.nfft
+            starts = np.concatenate([[0], np.cumsum(sym[:-1])])
+            off = np.int64(np.round(cps * 0.5))
+            idx = ((cps[:, None] - off[:, None] + np.arange(self.nfft)) % self.nfft + off[:, None] + starts[:, None]).reshape(-1)
+            g = (np.arange(self.nr)[:, None] * width + idx[None, :]).reshape(-1)
+            self._gather[key] = D(np.int32(g))
+        return self._gather[key]
+
+    # ------------------------------------------------------------------------------------------------ run
+    def run(self, slot0, n_slots, snr_db, seed=0, tb_bits=None, noise=None, counters=None, details=False):
+        """Simulate absolute slots [slot0, slot0+n_slots).  Returns the int64[4] device counters
+        (blockErrors, totalBlocks, bitErrors, totalBits) -- accumulated into ``counters`` when given.
+
+        Throughput mode (default): transport blocks and noise come from the counter-based device generator keyed by
+        (seed, slot index), so results do not depend on batch size or on how slots are sharded over GPUs.
+        Parity mode: pass ``tb_bits`` (n_slots, TBS) and ``noise`` (standard-normal complex pairs, shape of the
+        noisy signal) to reproduce a host NumPy PCG64 stream."""
+        dev = self.dev
+        if counters is None:
+            counters = torch.zeros(4, dtype=torch.int64, device=dev)
+        slots = np.arange(slot0, slot0 + n_slots)
+        spsf = self.bwp.slotsPerSubFrame
+        # one sub-batch per slot geometry (identical for mu <= 1)
+        geoms = {}
+        for i, n in enumerate(slots):
+            geoms.setdefault(tuple(self.sym_lens[n % spsf]), []).append(i)
+        det = []
+        for _, sel in geoms.items():
+            sel = np.asarray(sel)
+            d = self._run_group(slots[sel], snr_db, seed, None if tb_bits is None else tb_bits[sel],
+                                None if noise is None else noise[sel], counters, details)
+            if details:
+                det.append((sel, d))
+        return (counters, det) if details else counters
+
+    def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details):
+        dev, cfg = self.dev, self.cfg
+        n = len(slots)
+        sis = int(slots[0]) % self.bwp.slotsPerSubFrame
+        sif = torch.as_tensor(slots % self.bwp.slotsPerFrame, dtype=torch.int64, device=dev)
+        snr_lin = torch.full((n,), 10.0 ** (float(snr_db) / 10.0), dtype=torch.float64, device=dev) \
+            if np.isscalar(snr_db) else D(10.0 ** (np.float64(snr_db) / 10.0))
+
+        # ---- Tx
+        tb = ops.random_bits(n, self.tbs, seed, dev, stream_id=1, batch_offset=int(slots[0])) if tb_bits is None \
+            else tb_bits.to(dev).to(torch.uint8).contiguous()
+        coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+        bits = ops.ldpc_rate_match(coded, cfg, self.G, self.nl, self.qm)
+        grid = self.templates.index_select(0, sif)                              # DMRS-filled (n, Nl, L, K)
+        ops.qam_map(bits, self.qm, scr=self.scr, re_index=self.re_index, out=grid)
+
+        # ---- channel state of each slot
+        times = D(self.gain_times(slots))
+        gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
+        cir1, off = ops.cir(gains1, self.coeff, self.L)
+        hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+        F = ops.svd_precoder(hsub, self.nl)                                     # wideband SVD precoder (first PRB)
+        pg = ops.precode(grid, F)
+        H = None
+        if self.freqDomain or self.chanEst == "Perfect":
+            H = ops.channel_matrix(cir1, off, self.L, self.K, self.nfft)
+
+        if self.freqDomain:
+            rx = ops.apply_channel_fd(pg, H)
+            _, sigma, nv = ops.noise_level(rx, snr_lin=snr_lin)                 # grid.py:1040-1046
+            rxg = ops.add_noise(rx, noise.to(dev), sigma) if noise is not None else \
+                ops.awgn(rx, sigma, seed, stream_id=2, batch_offset=int(slots[0]))
+        else:
+            cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
+            w = Waveform.windowLength(cps, self.window, self.bwp)
+            tx = ops.ofdm_modulate(pg, self.nfft, cps, window_len=w, pad=self.max_delay)
+            ry = ops.apply_td(tx, cir1, [int(v) for v in self.sym_lens[sis]])
+            width = ry.shape[-1]
+            _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=self.nfft / (12.0 * self.bwp.numRbs),
+                                           nv_mult=float(self.nfft), gather=self._cp_gather(sis, width))
+            ry = ops.add_noise(ry, noise.to(dev), sigma) if noise is not None else \
+                ops.awgn(ry, sigma, seed, stream_id=2, batch_offset=int(slots[0]))
+            rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off)
+
+        # ---- Rx
+        if self.chanEst == "Perfect":
+            hest = ops.effective_channel(H, F)
+        else:
+            hest = ops.chest_ls(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,
+                                pil_set=sif.to(torch.int32))
+        eq, sc = ops.mmse_equalize(rxg, hest, nv)
+        llr = ops.qam_demap(eq, nv, self.qm, scr=self.scr, re_index=self.re_index, scales=sc, nv_floor=1e-10,
+                            llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
+        rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm)
+        dec = ops.ldpc_decode(rr, cfg, self.numIter)
+        tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg)
+        ops.count_errors(cb_ok, tb_out, tb, counters)
+        if details:
+            return dict(tb=tb, cb_ok=cb_ok, tb_out=tb_out, llr=llr, eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv,
+                        sigma=sigma, grid=grid)
+        return None

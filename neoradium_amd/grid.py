@@ -1,0 +1,291 @@
+"""Resource grid (reference grid.py:47-1246) -- NumPy-in/NumPy-out surface over the HIP kernels.
+
+The per-RE arithmetic (precode, applyChannel, equalize, estimateChannelLS, ofdmModulate, addNoise) runs in
+libnrx on the GPU; RE bookkeeping (type map, indexing) is host logic.  For throughput use
+``neoradium_amd.engine`` which keeps whole slot batches resident on the device.
+"""
+import numpy as np
+
+from . import ops
+from ._dev import D, N
+from .random import random
+from .utils import toLinear
+
+_RE_TYPES = ["UNASSIGNED", "RESERVED", "NO_DATA", "DMRS", "PTRS", "CSIRS_NZP", "CSIRS_ZP", "DATA", "PDSCH", "PDCCH",
+             "PUSCH", "PUCCH", "PRECODED_MIX", "RX_DATA"]
+_RE_COLORS = ["white", "gray", "lightgray", "pink", "yellow", "red", "orange", "cyan", "cornflowerblue", "lime",
+              "lightblue", "peachpuff", "violet", "sienna"]
+_DATA_TYPES = ("DATA", "PDSCH", "PDCCH", "PUSCH", "PUCCH")
+
+
+class Grid:
+    retMaxPredefine, retMaxCustom = 50, 20
+    retIdToName = _RE_TYPES + [None] * (70 - len(_RE_TYPES))
+    retColors = _RE_COLORS + ["white"] * (70 - len(_RE_COLORS))
+    retNameToId = {n: i for i, n in enumerate(_RE_TYPES)}
+    retNumCustom = 0
+
+    def __init__(self, bwp, numPlanes=1, contents="DATA", useReDesc=False, numSlots=1):
+        self.bwp = bwp
+        if isinstance(contents, str):
+            if contents not in _DATA_TYPES:
+                raise ValueError("Unsupported grid content type \"%s\"!" % (contents))
+            self.defaultReType = self.retNameToId[contents]
+        else:
+            if not self.retValid(contents):
+                raise ValueError("Unsupported grid content type \"%d\"!" % (contents))
+            if self.retIdToName[contents] not in _DATA_TYPES:
+                raise ValueError("Unsupported grid content type \"%s\"!" % (self.retIdToName[contents]))
+            self.defaultReType = contents
+        self.numSlots = numSlots
+        shape = (numPlanes, numSlots * bwp.symbolsPerSlot, 12 * bwp.numRbs)
+        self.grid = np.zeros(shape, dtype=np.complex128)
+        self.reTypeIds = np.zeros(shape, dtype=np.uint8)          # UNASSIGNED = 0
+        self.reDesc = np.full(shape, "UNASSIGNED", dtype='<U20') if useReDesc else None
+        self.noiseVar = 0
+
+    # ------------------------------------------------------------------ RE-type registry
+    @classmethod
+    def retValid(cls, key):
+        return key in cls.retNameToId if isinstance(key, str) else key in cls.retNameToId.values()
+
+    @classmethod
+    def retRegister(cls, name, color):
+        if name in cls.retNameToId:
+            return cls.retNameToId[name]
+        if color in cls.retColors:
+            raise ValueError("RE Color \"%s\" is already taken!" % (color))
+        if cls.retNumCustom >= cls.retMaxCustom:
+            raise ValueError("Too many Custom RE types!")
+        new = cls.retMaxPredefine + cls.retNumCustom
+        cls.retNumCustom += 1
+        cls.retNameToId[name], cls.retIdToName[new], cls.retColors[new] = new, name, color
+        return new
+
+    # ------------------------------------------------------------------ shape helpers
+    @property
+    def shape(self): return self.grid.shape
+    @property
+    def numPlanes(self): return self.grid.shape[0]
+    numPorts = numPlanes
+    numLayers = numPlanes
+    @property
+    def numSymbols(self): return self.grid.shape[1]
+    @property
+    def numSubcarriers(self): return self.grid.shape[2]
+    @property
+    def numRBs(self): return self.grid.shape[2] // 12
+    @property
+    def size(self): return self.grid.size
+
+    def __getattr__(self, name):
+        if name in ("startRb", "numRbs", "nFFT", "symbolsPerSlot", "slotsPerSubFrame", "slotsPerFrame",
+                    "symbolsPerSubFrame"):
+            return getattr(self.__dict__['bwp'], name)
+        raise AttributeError("Class '%s' does not have any property named '%s'!" % (self.__class__.__name__, name))
+
+    def __getitem__(self, key):
+        return self.grid[key]
+
+    def __setitem__(self, key, values):
+        """grid[idx] = value | (value, "TYPE") | "TYPE"  (reference grid.py 'Resource Grid Indexing')."""
+        if isinstance(values, tuple):
+            values, name = values
+        elif isinstance(values, str):
+            values, name = 0, values
+        else:
+            name = None
+        if name is None:
+            ret = self.defaultReType
+        else:
+            if not self.retValid(name):
+                raise ValueError("Unknown content type \"%s\"!" % (name))
+            ret = self.retNameToId[name]
+        if self.reDesc is not None:
+            self.reDesc[key] = self.retIdToName[ret]
+        self.grid[key] = values
+        self.reTypeIds[key] = ret
+
+    def reTypeAt(self, p, l, k):
+        return self.retIdToName[self.reTypeIds[p, l, k]]
+
+    def getReIndexes(self, reTypeStr=None):
+        if reTypeStr is None:
+            reTypeStr = self.retIdToName[self.defaultReType]
+        if not self.retValid(reTypeStr):
+            raise ValueError("Unknown RE Content type \"%s\"!" % (reTypeStr))
+        return np.where(self.reTypeIds == self.retNameToId[reTypeStr])
+
+    def getReValues(self, reTypeStr=None):
+        return self.grid[self.getReIndexes(reTypeStr)]
+
+    def getStats(self):
+        stats = {"GridSize": self.grid.size}
+        for name, rid in self.retNameToId.items():
+            n = int(np.count_nonzero(self.reTypeIds == rid))
+            if n:
+                stats[name] = n
+        return stats
+
+    def clone(self):
+        g = Grid(self.bwp, self.numPlanes, self.defaultReType, self.reDesc is not None, self.numSlots)
+        g.grid, g.reTypeIds, g.noiseVar = self.grid.copy(), self.reTypeIds.copy(), self.noiseVar
+        return g
+
+    def _like(self, data, retName="RX_DATA", noiseVar=0):
+        g = Grid(self.bwp, numPlanes=data.shape[0], numSlots=self.numSlots)
+        g.grid = data
+        g.reTypeIds = np.full(data.shape, self.retNameToId[retName], dtype=np.uint8)
+        g.noiseVar = noiseVar
+        return g
+
+    def __repr__(self): return self.print(getStr=True)
+
+    def print(self, indent=0, title=None, getStr=False):
+        title = "Resource Grid Properties:" if title is None else title
+        pad = indent * ' '
+        s = ("\n" if indent == 0 else "") + pad + title + "\n"
+        s += pad + "  startRb: %d\n" % (self.startRb) + pad + "  numRbs: %d\n" % (self.numRbs)
+        s += pad + "  numSlots: %d\n" % (self.numSlots)
+        s += pad + "  Data Contents: %s\n" % (self.retIdToName[self.defaultReType])
+        s += pad + "  Size: %d\n" % (self.size) + pad + "  Shape: %s\n" % (str(self.shape))
+        if self.noiseVar > 0:
+            s += pad + "  Noise Var.: %s\n" % (str(self.noiseVar))
+        s += self.bwp.print(indent + 2, "Bandwidth Part:", True)
+        if getStr:
+            return s
+        print(s)
+
+    # ------------------------------------------------------------------ GPU stages
+    def precode(self, f):
+        """grid.py:456-518.  ``f``: (Nt,Nl) matrix, or a list of (rbList, (Nt,Nl)) per PRG."""
+        if isinstance(f, list):
+            nt, nl = f[0][1].shape
+            perk = np.zeros((self.numSubcarriers, nt, nl), dtype=np.complex128)
+            for rbs, fg in f:
+                for rb in rbs:
+                    perk[rb * 12:rb * 12 + 12] = fg
+            # per-subcarrier precoder: one device call per distinct PRG matrix is wasteful; do it per group
+            out = np.zeros((nt,) + self.shape[1:], dtype=np.complex128)
+            for rbs, fg in f:
+                ks = np.concatenate([np.arange(rb * 12, rb * 12 + 12) for rb in rbs]) if len(rbs) else np.arange(0)
+                if len(ks) == 0:
+                    continue
+                sub = np.ascontiguousarray(self.grid[:, :, ks])
+                out[:, :, ks] = N(ops.precode(D(sub[None]), D(np.complex128(fg))))[0]
+            data = out
+        else:
+            if not isinstance(f, np.ndarray):
+                raise ValueError("'f' must be a 2D NumPy array or a list of tuples.")
+            if f.shape[1] != self.numLayers:
+                raise ValueError("The last dimension of 'f' (%d) must match the first dimension of the grid (%d)" %
+                                 (f.shape[-1], self.shape[0]))
+            data = N(ops.precode(D(self.grid[None]), D(np.complex128(f))))[0]
+        pg = Grid(self.bwp, data.shape[0], self.defaultReType, numSlots=self.numSlots)
+        pg.grid = data
+        types = self.reTypeIds[0].copy()
+        mixed = (self.reTypeIds != self.reTypeIds[0:1]).any(0)
+        types[mixed] = self.retNameToId["PRECODED_MIX"]
+        pg.reTypeIds[:] = types
+        return pg
+
+    def applyChannel(self, channelMatrix):
+        """grid.py:978-1018: per-RE H x (frequency-domain channel)."""
+        ll, kk, nr, nt = channelMatrix.shape
+        if nt != self.numPorts:
+            raise ValueError("Mismatch in the number of transmitter antennas (%d vs %d)!" % (nt, self.numPorts))
+        rx = N(ops.apply_channel_fd(D(self.grid[None]), D(np.complex128(channelMatrix))))[0]
+        return self._like(rx)
+
+    def equalize(self, hf, noiseVar=None):
+        """grid.py:626-694: MMSE equalisation -> (eqGrid, llrScales)."""
+        if (self.shape[0] != hf.shape[2]) or (self.shape[1] != hf.shape[0]) or (self.shape[2] != hf.shape[1]):
+            raise ValueError("Mismatch in the number of receiver antennas, OFDM symbols, or subcarriers!")
+        nv = self.noiseVar if noiseVar is None else noiseVar
+        nv = max(1e-8, nv)
+        eq, sc = ops.mmse_equalize(D(self.grid[None]), D(np.complex128(hf)[None]), D(np.float64([nv])))
+        # like the reference the equalised grid has hf.shape[2] planes allocated but carries the layer estimates
+        g = self._like(N(eq)[0], noiseVar=nv)
+        return g, N(sc)[0]
+
+    def estimateChannelLS(self, rsInfo, meanCdm=True, polarInt=False, kernel='linear'):
+        """grid.py:874-975 with DMRS pilots, CDM averaging and linear interpolation -> (H (L,K,Nr,P), noiseVar est.).
+
+        Only the default path is built (meanCdm=True, polarInt=False, kernel='linear'); the reference's
+        noise-variance side output (IFFT/window/FFT + MLP rescale, grid.py:808-851) is not on the link path the
+        notebooks use, so ``None`` is returned in its place."""
+        from .dmrs import DMRS
+        if not isinstance(rsInfo, DMRS):
+            raise NotImplementedError("estimateChannelLS: only DMRS-based estimation is built (CSI-RS is out of scope)")
+        if not meanCdm or polarInt or kernel != 'linear':
+            raise NotImplementedError("estimateChannelLS: only meanCdm=True, polarInt=False, kernel='linear' is built")
+        dmrs = rsInfo
+        pil, ks, ds = dmrs.getPilots()
+        if self.shape[1:] != (self.bwp.symbolsPerSlot, 12 * self.bwp.numRbs):
+            raise ValueError("The Grid size (%dx%d) does not match Reference Signals (%dx%d)." %
+                             (self.shape[1], self.shape[2], self.bwp.symbolsPerSlot, 12 * self.bwp.numRbs))
+        h = ops.chest_ls(D(self.grid[None]), D(pil[None]), ks, list(ds), l_cdm=dmrs.symbols,
+                         k_cdm=4 if dmrs.enhanced else 2)
+        return N(h)[0], None
+
+    def ofdmModulate(self, f0=0, windowing="STD"):
+        """grid.py:521-582 + waveform.py:380-470."""
+        from .waveform import Waveform
+        if f0 != 0:
+            raise NotImplementedError("ofdmModulate: carrier up-conversion (f0>0) is not built")
+        pp, ll, kk = self.shape
+        bwp = self.bwp
+        if ll % bwp.symbolsPerSlot:
+            raise ValueError("the grid must hold whole slots")
+        l0 = bwp.slotNoInSubFrame * bwp.symbolsPerSlot
+        if ll > bwp.symbolsPerSubFrame - l0:
+            raise ValueError("Cannot modulate across subframe boundary! (At most %d symbols)" % (bwp.symbolsPerSubFrame - l0))
+        cps = (bwp.symbolLens[l0:l0 + ll] - bwp.nFFT).astype(np.int32)
+        w = Waveform.windowLength(cps, windowing, bwp)
+        if ll > 16:
+            raise NotImplementedError("ofdmModulate: more than one slot per call is not built")
+        wave = ops.ofdm_modulate(D(self.grid[None]), bwp.nFFT, list(cps), window_len=w)
+        return Waveform(N(wave)[0])
+
+    def getRePower(self):
+        return (self.grid.var() / (self.bwp.nFFT ** 2)).item()
+
+    def getNoiseStd(self, snr):
+        """grid.py:1040-1046 (signal variance on the device)."""
+        var, _, _ = ops.noise_level(D(self.grid[None]))
+        return float(np.sqrt(var.item() / snr))
+
+    def addNoise(self, **kwargs):
+        """grid.py:1049-1187: noise=, noiseStd=, noiseVar= or snrDb= (+useRxPower)."""
+        noise = kwargs.get('noise', None)
+        if noise is not None:
+            if self.shape != noise.shape:
+                raise ValueError(f"Shape Mismatch: Grid: {self.shape} vs Noise: {noise.shape}")
+            g = self._like(self.grid + noise, noiseVar=noise.var())
+            g.reTypeIds = self.reTypeIds.copy()
+            return g
+        ranGen = kwargs.get('ranGen', random)
+        noiseStd = kwargs.get('noiseStd', None)
+        if noiseStd is None:
+            noiseVar = kwargs.get('noiseVar', None)
+            if noiseVar is not None:
+                noiseStd = np.sqrt(noiseVar)
+        if noiseStd is None:
+            snrDb = kwargs.get('snrDb', None)
+            if snrDb is None:
+                raise ValueError("You must specify the noise power using 'snrDb', 'noiseVar', or 'noiseStd'!")
+            snr = toLinear(snrDb)
+            if kwargs.get('useRxPower', False):
+                noiseStd = self.getNoiseStd(snr)
+            else:
+                noiseStd = np.sqrt(1 / (snr * self.shape[0]))       # Matlab convention (grid.py:1182-1185)
+        # host PCG64 stream in the reference's draw order; scaled + added on the device
+        z = ranGen.normal(0, 1, self.shape + (2,))
+        zc = z[..., 0] + 1j * z[..., 1]
+        out = ops.add_noise(D(self.grid[None]), D(zc[None]), D(np.float64([noiseStd])))
+        g = self._like(N(out)[0], noiseVar=noiseStd * noiseStd)
+        g.reTypeIds = self.reTypeIds.copy()
+        return g
+
+    def drawMap(self, *a, **k):
+        raise NotImplementedError("drawMap (matplotlib plotting) is out of scope of neoradium_amd")

@@ -128,14 +128,15 @@ def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False):
 
 
 def ldpc_crc_merge(dec, cfg, want_tb=True):
-    """ldpc.py:1584-1619 checkCrcAndMerge (+ TB CRC24A check): (n_tb*C, K) -> tb_out (n_tb,B), cb_ok (n_tb,C), tb_ok."""
+    """ldpc.py:1584-1619 checkCrcAndMerge (+ TB CRC24A check): (n_tb*C, K) -> tb_out (n_tb,M>=B), cb_ok (n_tb,C), tb_ok."""
     dec = _u8(dec)
     if dec.dim() != 2 or dec.shape[1] != cfg.K or dec.shape[0] % cfg.C:
         raise ValueError(f"decoded blocks must be (n_tb*C, K={cfg.K}), got {tuple(dec.shape)}")
     n_tb = dec.shape[0] // cfg.C
     dev = _dev(dec)
     cb_ok = torch.empty((n_tb, cfg.C), dtype=torch.uint8, device=dev)
-    tb_out = torch.empty((n_tb, cfg.B), dtype=torch.uint8, device=dev) if want_tb else None
+    width = cfg.C * (cfg.cb_len - 24) if cfg.C > 1 else cfg.B
+    tb_out = torch.empty((n_tb, width), dtype=torch.uint8, device=dev) if want_tb else None
     tb_ok = torch.empty((n_tb,), dtype=torch.uint8, device=dev) if want_tb else None
     check(lib().nrx_ldpc_crc_merge(ptr(dec), n_tb, C.byref(cfg), ptr(tb_out), ptr(cb_ok), ptr(tb_ok), stream()))
     return tb_out, cb_ok, tb_ok
@@ -455,3 +456,45 @@ def chest_ls(rx, pilots, port_ks, dmrs_syms, l_cdm=1, k_cdm=2, pil_set=None):
     check(fn(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), _host_i32(dmrs_syms), nds, l_cdm, k_cdm, nk, L, K, nr, P, ptr(hest),
              n, stream()))
     return hest
+
+
+def channel_matrix_sub(cir_t, off, nc, K, nfft, k0, n_k):
+    """H at subcarriers [k0, k0+n_k) only: (n,nc,n_k,Nr,Nt)."""
+    cir_t = cir_t.contiguous()
+    n, T, nr, nt, cl = cir_t.shape
+    dev = _dev(cir_t)
+    H = torch.empty((n, nc, n_k, nr, nt), dtype=torch.complex128, device=dev)
+    check(lib().nrx_channel_matrix_sub_f64(ptr(cir_t), n, T, nc, nr, nt, cl, ptr(_i32(off, dev)), K, nfft, k0, n_k, ptr(H),
+                                           stream()))
+    return H
+
+
+def svd_precoder(h_block, n_layers):
+    """PDSCH.getPrecodingMatrix for one group: h_block (n, ..., Nr, Nt) averaged over the middle axes -> F (n,Nt,Nl)."""
+    h_block = h_block.to(torch.complex128).contiguous()
+    n, nr, nt = h_block.shape[0], h_block.shape[-2], h_block.shape[-1]
+    n_avg = h_block[0].numel() // (nr * nt)
+    F = torch.empty((n, nt, n_layers), dtype=torch.complex128, device=_dev(h_block))
+    check(lib().nrx_svd_precoder_f64(ptr(h_block), n, n_avg, nr, nt, n_layers, ptr(F), stream()))
+    return F
+
+
+def effective_channel(H, F):
+    """H (n,L,K,Nr,Nt) @ F (n,Nt,Nl) or (Nt,Nl) -> (n,L,K,Nr,Nl)."""
+    H = H.to(torch.complex128).contiguous()
+    F = F.to(torch.complex128).contiguous()
+    n, L, K, nr, nt = H.shape
+    shared = F.dim() == 2
+    nl = F.shape[-1]
+    if F.shape[-2] != nt:
+        raise ValueError("precoder / channel antenna count mismatch")
+    out = torch.empty((n, L, K, nr, nl), dtype=torch.complex128, device=_dev(H))
+    check(lib().nrx_effective_channel_f64(ptr(H), ptr(F), 0 if shared else nt * nl, n, L * K, nr, nt, nl, ptr(out), stream()))
+    return out
+
+
+def random_bits(n_batch, n_per, seed, device, stream_id=0, batch_offset=0):
+    """(n_batch, n_per) uniform random bits from the counter-based device generator."""
+    out = torch.empty((n_batch, n_per), dtype=torch.uint8, device=device)
+    check(lib().nrx_random_bits(ptr(out), n_per, n_batch, int(seed), int(stream_id), int(batch_offset), stream()))
+    return out

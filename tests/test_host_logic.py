@@ -1,0 +1,179 @@
+"""CPU: host-side logic of neoradium_amd (no GPU compute) against fixtures produced by the reference, plus the
+C-ABI load/export check (every symbol include/nrx.h declares is exported by libnrx.so and bound by ctypes)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import neoradium_amd as ma
+from neoradium_amd import _lib
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROOT = os.path.dirname(GOLD.rstrip('/').rsplit('/tests', 1)[0] + '/x')
+
+
+def test_abi_exports_match_header():
+    hdr = open(os.path.join(os.path.dirname(GOLD), '..', 'include', 'nrx.h')).read()
+    declared = set(re.findall(r'\b(nrx_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.lib()                                   # raises if the .so is missing / a symbol is absent
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.nrx_version() >= 100
+
+
+def test_host_only_entry_points():
+    cfg = _lib.ldpc_config(1, 606504 + 24)            # the metric configuration
+    assert (cfg.C, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F) == (72, 384, 1, 8448, 25344, 0)
+    g = np.load(os.path.join(GOLD, 'coding.npz'))
+    for bg, B, C, Zc, iLS, K in g['seg_anchors']:
+        c = _lib.ldpc_config(int(bg), int(B))
+        assert (c.C, c.Zc, c.iLS, c.K) == (C, Zc, iLS, K)
+    assert _lib.ldpc_cb_lens(943488, 72, 4, 6) == [13104] * 72
+    assert _lib.ldpc_cb_lens(100, 3, 2, 2) == [32, 32, 36]
+    with pytest.raises(ValueError):
+        _lib.ldpc_config(3, 100)
+    fx = np.load(os.path.join(GOLD, 'phy.npz'))
+    for ci in (32769, 1, 123456789):
+        assert np.array_equal(_lib.gold_sequence(ci, 2000), fx[f'gold_{ci}'])
+
+
+def _build(c):
+    kw = dict(numRbs=c['numRbs'], spacing=c['spacing'])
+    if 'startRb' in c:
+        kw['startRb'] = c['startRb']
+    car = ma.Carrier(**kw)
+    p = ma.PDSCH(car.curBwp, numLayers=c['layers'], modulation=c['mod'], **c['pk'])
+    p.setDMRS(**c['dm'])
+    return car, p
+
+
+def test_carrier_pdsch_dmrs_vs_reference():
+    g = np.load(os.path.join(GOLD, 'host.npz'))
+    cfgs = json.loads(str(g['cfgs']))
+    for i, c in enumerate(cfgs):
+        car, p = _build(c)
+        bwp = car.curBwp
+        assert [bwp.nFFT] + bwp.symbolLens.tolist() == g[f'h{i}_numerology'].tolist()
+        for slot in (0, 7):
+            car.slotNo = slot
+            grid = p.getGrid()
+            assert np.array_equal(grid.reTypeIds, g[f'h{i}_s{slot}_types'])
+            idx = np.nonzero(grid.reTypeIds == grid.retNameToId['DMRS'])
+            assert np.abs(grid.grid[idx] - g[f'h{i}_s{slot}_dmrs']).max() < 1e-15
+            assert np.array_equal(np.int32(p.dataIndices), g[f'h{i}_s{slot}_data'])
+            assert np.array_equal(np.int32(p.getLayerMapIndexes(p.dataIndices)[0]), g[f'h{i}_s{slot}_lm'])
+            # the pilot table the estimator kernel consumes = the DMRS REs of the grid
+            pil, ks, ds = p.dmrs.getPilots()
+            for port in range(len(p.portSet)):
+                for li, l in enumerate(ds):
+                    assert np.array_equal(grid.grid[port, l, ks[port]], pil[port, li])
+        assert [p.getTxBlockSize(r)[0] for r in (0.2, 0.3, 0.5, 666 / 1024, 0.75, 0.92)] == g[f'h{i}_tbs'].tolist()
+        assert p.getBitSizes(grid) == g[f'h{i}_bits'].tolist()
+        assert p.dmrs.dataREs == g[f'h{i}_dataREs'].tolist()
+
+
+def test_273prb_extension_numerology():
+    """Beyond the reference (it raises for numRbs >= nFFT/12): nFFT and sample rate scale together."""
+    car = ma.Carrier(numRbs=273, spacing=30)
+    b = car.curBwp
+    assert (b.nFFT, b.sampleRate, b.getSlotLen(0)) == (4096, 122.88e6, 61440)
+    assert b.getCpLens(0).tolist() == [352] + [288] * 13
+    p = ma.PDSCH(b, numLayers=4, modulation='64QAM')
+    p.setDMRS(configType=1, additionalPos=1)
+    g = p.getGrid()
+    assert p.getTxBlockSize(666 / 1024) == [606504] and p.getBitSizes(g) == [943488]      # SURVEY 8 metric row
+    # inside the reference's range nothing changes
+    assert ma.Carrier(numRbs=84, spacing=30).curBwp.nFFT == 1024
+    assert ma.Carrier(numRbs=169, spacing=15).curBwp.nFFT == 2048
+
+
+def test_argument_errors_like_reference():
+    car = ma.Carrier(numRbs=25, spacing=15)
+    with pytest.raises(ValueError):
+        ma.Carrier(numRbs=25, spacing=17)
+    with pytest.raises(ValueError):
+        ma.PDSCH(car.curBwp, modulation='8PSK')
+    with pytest.raises(ValueError):
+        ma.PDSCH(car.curBwp, prgSize=3)
+    p = ma.PDSCH(car.curBwp, numLayers=2)
+    with pytest.raises(ValueError):
+        p.setDMRS(configType=3)
+    with pytest.raises(ValueError):
+        ma.LdpcEncoder(baseGraphNo=3)
+    with pytest.raises(ValueError):
+        ma.SnrScheduler(0, -1)
+
+
+def test_channel_static_coefficients_vs_reference(monkeypatch):
+    """CDL/TDL: the host-built static ray tensors reproduce the reference's per-slot gains (no GPU involved:
+    sum_m A exp(j 2 pi t nu) evaluated here in NumPy; the GPU kernel is checked against the same formula)."""
+    from neoradium_amd import channelmodel
+    monkeypatch.setattr(channelmodel.ChannelModel, 'prepareForNextSlot', lambda self: None)
+    g = np.load(os.path.join(GOLD, 'channels.npz'))
+    specs = [('cdl', 'C', dict(delaySpread=300, carrierFreq=4e9, dopplerShift=5), ([1, 2], [1, 2])),
+             ('cdl', 'D', dict(delaySpread=100, dopplerShift=50, ueDirAZ=[30, 80]), ([1, 2], [1, 1])),
+             ('cdl', 'A', dict(delaySpread=30, dopplerShift=100, angleScaling=([120, 200, 90, 95], [10, 30, 5, 8])), ([2, 2], [1, 1])),
+             ('tdl', 'A', dict(delaySpread=30, dopplerShift=5), None),
+             ('tdl', 'C', dict(delaySpread=300, dopplerShift=100, txAntennaCount=2, rxAntennaCount=2, mimoCorrelation='Medium'), None),
+             ('tdl', 'D', dict(delaySpread=100, dopplerShift=30, txAntennaCount=4, rxAntennaCount=2, mimoCorrelation='High'), None)]
+    for i, (kind, prof, kw, ant) in enumerate(specs):
+        ma.random.setSeed(100 + i)
+        car = ma.Carrier(numRbs=25, spacing=15)
+        if kind == 'cdl':
+            ch = ma.CdlChannel(car.curBwp, prof, txAntenna=ma.AntennaPanel(ant[0], polarization='x'),
+                               rxAntenna=ma.AntennaPanel(ant[1], polarization='x'), **kw)
+        else:
+            ch = ma.TdlChannel(car.curBwp, prof, **kw)
+        A, nu, Alos, nulos = ch.staticCoefficients()
+        t = g[f'ch{i}_samples'] / ch.sampleRate
+        gains = np.einsum('rtnm,cnm->crtn', A, np.exp(2j * np.pi * t[:, None, None] * nu[None]))
+        if Alos is not None:
+            los = Alos[None] * np.exp(2j * np.pi * t * nulos)[:, None, None]
+            gains = np.concatenate([los[..., None], gains], axis=3)
+        gains = gains * ch._normalisation()
+        ref = g[f'ch{i}_gains1']
+        assert np.abs(gains - ref).max() < 1e-12 * np.abs(ref).max()
+        assert np.array_equal(ch.getCoeffMatrix(), g[f'ch{i}_coeff'])
+        assert ch.getMaxDelay() == g[f'ch{i}_misc'][1]
+
+
+def test_snr_scheduler_walks():
+    g = np.load(os.path.join(GOLD, 'snr_walks.npz'))
+    for t, (mid, width, snr0, step, n) in enumerate(g['walk_params']):
+        walk = g[f'walk{t}']
+        s = ma.SnrScheduler(int(snr0), float(step))
+        seen = []
+        for snr in s:
+            row = walk[len(seen)]
+            assert abs(snr - row[0]) < 1e-9
+            seen.append(snr)
+            s.setData(float(row[1]))
+        assert len(seen) == int(n)
+
+
+def test_random_stream_is_numpy_pcg64():
+    """bits -> awgn draw order reproduces NumPy's PCG64 stream (the reproducibility contract)."""
+    ma.random.setSeed(123)
+    b = ma.random.bits(30216)
+    import hashlib
+    assert hashlib.sha256(b.tobytes()).hexdigest()[:16] == '86601f2723df4cb3'       # SURVEY 8c anchor
+    ref = np.random.Generator(np.random.PCG64(123))
+    assert np.array_equal(b, ref.integers(0, 2, 30216, dtype=np.int8))
+    z = ma.random.awgn((2, 3), 0.5)
+    zz = ref.normal(0, 0.5 / np.sqrt(2), (2, 3, 2))
+    assert np.array_equal(z, zz[..., 0] + 1j * zz[..., 1])
+
+
+def test_no_cpu_fallback():
+    """Product operators refuse to run without a GPU instead of silently falling back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises((RuntimeError, ValueError)):
+        ma.Modem('QPSK').modulate(np.int8([0, 1, 1, 0]))
+    with pytest.raises((RuntimeError, ValueError)):
+        ma.LdpcEncoder().getRateMatchedCodeBlocks(np.zeros(100, dtype=np.int8), 400)

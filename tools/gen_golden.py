@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ by running the REFERENCE (read-only /root/reference)
+in the development container.  The reference never travels to the GPU box; these small data files do.
+
+    python tools/gen_golden.py
+
+Outputs (all data: inputs + the reference's outputs, nothing of its source):
+  tests/golden/matlab_ldpc/*.mat, matlab_polar/*.mat   MATLAB 5G-Toolbox vectors the reference's own notebooks assert on
+  tests/golden/coding.npz        CRC / segmentation / encode / rate-match / rate-recover / decode at several configs
+  tests/golden/phy.npz           gold sequence, constellations, LLRs, equaliser, OFDM, FIR bank, LS estimate
+  tests/golden/host.npz          Carrier / PDSCH / DMRS index + pilot tables, TBS values, SnrScheduler walks
+  tests/golden/channels.npz      CDL / TDL per-slot gains + coefficient matrices for seeded channels
+  tests/golden/e2e_*.npz         whole PDSCH slots (inputs: seed-derived bits/noise; outputs: LLRs, bits, CRC)
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+
+sys.path.insert(0, '/root/reference')
+os.chdir('/tmp')
+import neoradium as nr                                   # noqa: E402
+from neoradium.utils import goldSequence                 # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+PLAY = '/root/reference/Playground/CompareWithMatlab'
+
+
+def copy_matlab():
+    for sub, dst in (('LDPC', 'matlab_ldpc'), ('Polar', 'matlab_polar')):
+        d = os.path.join(GOLD, dst)
+        os.makedirs(d, exist_ok=True)
+        src = os.path.join(PLAY, sub, 'MatlabFiles')
+        for f in sorted(os.listdir(src)):
+            if f.endswith('.mat'):
+                shutil.copyfile(os.path.join(src, f), os.path.join(d, f))
+
+
+def coding():
+    out = {}
+    rng = np.random.default_rng(2024)
+    cases = [(1, 10000, 22808, 1, 2, 'QPSK', 0), (2, 2408, 7800, 1, 2, 'QPSK', 0), (1, 30216, 63648, 2, 4, '16QAM', 0),
+             (2, 3817, 12000, 1, 6, '64QAM', 2), (1, 800, 2400, 2, 4, '16QAM', 3), (2, 100, 600, 1, 2, 'QPSK', 1),
+             (1, 8425, 26000, 1, 8, '256QAM', 1), (2, 641, 2000, 1, 2, 'QPSK', 0), (1, 1000, 2880, 1, 2, 'QPSK', 0)]
+    out['cases'] = np.int64([c[:5] + (c[6],) for c in cases])
+    for i, (bg, A, G, nl, qm, mod, rv) in enumerate(cases):
+        tb = rng.integers(0, 2, A).astype(np.int8)
+        enc = nr.LdpcEncoder(baseGraphNo=bg, modulation=mod, txLayers=nl)
+        tbc = enc.appendCrc(tb, '24A')
+        cbs = enc.doSegmentation(tbc)
+        coded = enc.encode(cbs)
+        rm = enc.rateMatch(coded, G, rv=rv)
+        dec = nr.LdpcDecoder(bg, mod, nl)
+        sigma = 0.8 if i % 2 == 0 else 1.05
+        llr = (1 - 2.0 * rm) * 2 / sigma ** 2 + rng.normal(0, 2 / sigma, len(rm))
+
+        class H:
+            pass
+        h = H()
+        h.decBuffer, h.rv = None, rv
+        rr = dec.recoverRate(llr, A, harq=h)
+        bel = dec.decode(rr, numIter=6, onlyInfoBits=False, outputBelief=True)
+        merged, crc = dec.checkCrcAndMerge(np.int8(bel[:, :enc.codeBlockSize] < 0))
+        p = f'c{i}_'
+        out[p + 'tb'], out[p + 'params'] = tb, np.int64([enc.numCodeBlocks, enc.liftingSize, enc.setIndex,
+                                                         enc.codeBlockSize, enc.numFillerBits])
+        out[p + 'cbs'], out[p + 'coded'], out[p + 'rm'] = np.packbits(cbs.astype(np.uint8)), np.packbits(coded.astype(np.uint8)), np.packbits(rm.astype(np.uint8))
+        out[p + 'llr'] = llr
+        out[p + 'rr_sum'] = np.float64([np.where(rr > 1e19, 0, rr).sum(), (rr > 1e19).sum()])
+        # all columns for the small cases, information columns only for the large ones (fixture size)
+        out[p + 'belief'] = bel if bel.size <= 20000 else bel[:, :enc.codeBlockSize]
+        out[p + 'merged'], out[p + 'crc'] = np.packbits(merged.astype(np.uint8)), np.asarray(crc, dtype=bool)
+    # HARQ-IR soft combining: 4 redundancy versions into one buffer
+    bg, A, G, nl, qm, mod = 1, 10000, 20900, 1, 4, '16QAM'
+    tb = rng.integers(0, 2, A).astype(np.int8)
+    enc = nr.LdpcEncoder(baseGraphNo=bg, modulation=mod, txLayers=nl)
+    coded = enc.encode(enc.doSegmentation(enc.appendCrc(tb, '24A')))
+    dec = nr.LdpcDecoder(bg, mod, nl)
+
+    class H:
+        pass
+    h = H()
+    h.decBuffer = None
+    out['harq_tb'] = tb
+    for t, rv in enumerate((0, 2, 3, 1)):
+        rm = enc.rateMatch(coded, G, rv=rv)
+        llr = (1 - 2.0 * rm) + rng.normal(0, 1.2, len(rm))
+        h.rv = rv
+        rr = dec.recoverRate(llr, A, harq=h)
+        out[f'harq_llr{t}'] = llr
+        out[f'harq_buf{t}'] = h.decBuffer.copy()
+    # CRC known answers for every polynomial
+    msg = rng.integers(0, 2, (3, 517)).astype(np.int8)
+    out['crc_msg'] = msg
+    for poly in ('6', '11', '16', '24A', '24B', '24C'):
+        out['crc_' + poly] = enc.getCrc(msg, poly)
+    # segmentation anchors B -> (C, Zc, iLS, K)   
+    anchors = []
+    for bg, B in ((1, 2432), (1, 30240), (1, 129152), (1, 606528), (1, 8449), (2, 2432), (2, 3841), (2, 641), (2, 192), (2, 561), (2, 3840)):
+        e = nr.LdpcEncoder(baseGraphNo=bg)
+        e.initialize(B)
+        anchors.append((bg, B, e.numCodeBlocks, e.liftingSize, e.setIndex, e.codeBlockSize))
+    out['seg_anchors'] = np.int64(anchors)
+    np.savez_compressed(os.path.join(GOLD, 'coding.npz'), **out)
+
+
+def phy():
+    out = {}
+    rng = np.random.default_rng(7)
+    for ci in (32769, 1, 123456789):
+        out[f'gold_{ci}'] = np.int8(goldSequence(ci, 2000))
+    for mod in ('BPSK', 'QPSK', '16QAM', '64QAM', '256QAM', '1024QAM'):
+        m = nr.Modem(mod)
+        out['const_' + mod] = m.constellation
+        b = rng.integers(0, 2, m.qm * 64).astype(np.int8)
+        y = m.modulate(b) + 0.12 * (rng.normal(size=64) + 1j * rng.normal(size=64))
+        out['bits_' + mod], out['rx_' + mod] = b, y
+        out['llr_' + mod] = m.getLLRsFromSymbols(y, 0.03)
+        if m.qm <= 6:
+            out['llrx_' + mod] = m.getLLRsFromSymbols(y, 0.3, useMax=False)
+    np.savez_compressed(os.path.join(GOLD, 'phy.npz'), **out)
+
+
+def host():
+    out = {}
+    cfgs = [dict(numRbs=25, spacing=15, layers=1, mod='QPSK', dm=dict(configType=1, additionalPos=1), pk={}),
+            dict(numRbs=51, spacing=30, layers=2, mod='16QAM', dm=dict(configType=2, additionalPos=2), pk={}),
+            dict(numRbs=52, spacing=30, layers=2, mod='16QAM', dm=dict(configType=1, additionalPos=1, symbols=2),
+                 pk=dict(interleavingBundleSize=2), startRb=1),
+            dict(numRbs=30, spacing=15, layers=4, mod='256QAM', dm=dict(configType=1, additionalPos=3), pk={}),
+            dict(numRbs=24, spacing=60, layers=3, mod='64QAM', dm=dict(configType=2, additionalPos=1, otherCdmGroups=[2]),
+                 pk=dict(symStart=2, symLen=10, mappingType='B', prbSet=list(range(4, 20))))]
+    import json
+    out['cfgs'] = np.array(json.dumps(cfgs))
+    for i, c in enumerate(cfgs):
+        kw = dict(numRbs=c['numRbs'], spacing=c['spacing'])
+        if 'startRb' in c:
+            kw['startRb'] = c['startRb']
+        car = nr.Carrier(**kw)
+        bwp = car.curBwp
+        p = nr.PDSCH(bwp, numLayers=c['layers'], modulation=c['mod'], **c['pk'])
+        p.setDMRS(**c['dm'])
+        out[f'h{i}_numerology'] = np.int64([bwp.nFFT] + bwp.symbolLens.tolist())
+        for slot in (0, 7):
+            car.slotNo = slot
+            g = p.getGrid()
+            idx = np.nonzero(g.reTypeIds == g.retNameToId['DMRS'])
+            out[f'h{i}_s{slot}_types'] = g.reTypeIds
+            out[f'h{i}_s{slot}_dmrs'] = g.grid[idx]
+            out[f'h{i}_s{slot}_data'] = np.int32(p.dataIndices)
+            out[f'h{i}_s{slot}_lm'] = np.int32(p.getLayerMapIndexes(p.dataIndices)[0])
+        out[f'h{i}_tbs'] = np.int64([p.getTxBlockSize(r)[0] for r in (0.2, 0.3, 0.5, 666 / 1024, 0.75, 0.92)])
+        out[f'h{i}_bits'] = np.int64(p.getBitSizes(g))
+        out[f'h{i}_dataREs'] = np.int64(p.dmrs.dataREs)
+    np.savez_compressed(os.path.join(GOLD, 'host.npz'), **out)
+
+
+def channels():
+    out = {}
+    specs = [('cdl', 'C', dict(delaySpread=300, carrierFreq=4e9, dopplerShift=5), ([1, 2], [1, 2])),
+             ('cdl', 'D', dict(delaySpread=100, dopplerShift=50, ueDirAZ=[30, 80]), ([1, 2], [1, 1])),
+             ('cdl', 'A', dict(delaySpread=30, dopplerShift=100, angleScaling=([120, 200, 90, 95], [10, 30, 5, 8])), ([2, 2], [1, 1])),
+             ('tdl', 'A', dict(delaySpread=30, dopplerShift=5), None),
+             ('tdl', 'C', dict(delaySpread=300, dopplerShift=100, txAntennaCount=2, rxAntennaCount=2, mimoCorrelation='Medium'), None),
+             ('tdl', 'D', dict(delaySpread=100, dopplerShift=30, txAntennaCount=4, rxAntennaCount=2, mimoCorrelation='High'), None)]
+    for i, (kind, prof, kw, ant) in enumerate(specs):
+        nr.random.setSeed(100 + i)
+        car = nr.Carrier(numRbs=25, spacing=15)
+        if kind == 'cdl':
+            ch = nr.CdlChannel(car.curBwp, prof, txAntenna=nr.AntennaPanel(ant[0], polarization='x'),
+                               rxAntenna=nr.AntennaPanel(ant[1], polarization='x'), **kw)
+        else:
+            ch = nr.TdlChannel(car.curBwp, prof, **kw)
+        ch.goNext()
+        ch.goNext()                                    # slot 2: non-trivial absolute time
+        ch.prepareForNextSlot()
+        out[f'ch{i}_samples'] = ch.chanGainSamples
+        out[f'ch{i}_gains1'] = ch.chanGains1
+        out[f'ch{i}_coeff'] = ch.coeffMatrix
+        out[f'ch{i}_misc'] = np.int64([ch.chanOffset, ch.getMaxDelay()])
+        H = ch.getChannelMatrix()
+        out[f'ch{i}_H'] = H[::6, ::25]                 # sub-sampled channel matrix
+    np.savez_compressed(os.path.join(GOLD, 'channels.npz'), **out)
+
+
+def e2e():
+    """Whole slots.  The random stream (bits -> channel construction -> noise) is reproducible from the seed with
+    NumPy's PCG64, so only outputs are stored."""
+    def one(name, seed, numRbs, spacing, mod, layers, rate, bg, chan, dm, numIter, snr, freqDomain, perfect, slot0):
+        nr.random.setSeed(seed)
+        car = nr.Carrier(numRbs=numRbs, spacing=spacing)
+        bwp = car.curBwp
+        p = nr.PDSCH(bwp, numLayers=layers, nID=car.cellId, modulation=mod)
+        p.setDMRS(**dm)
+        if chan[0] == 'cdl':
+            ch = nr.CdlChannel(bwp, chan[1], delaySpread=chan[2], carrierFreq=4e9, dopplerShift=chan[3],
+                               txAntenna=nr.AntennaPanel(chan[4], polarization='x'),
+                               rxAntenna=nr.AntennaPanel(chan[5], polarization='x'))
+        else:
+            ch = nr.TdlChannel(bwp, chan[1], delaySpread=chan[2], dopplerShift=chan[3], txAntennaCount=chan[4], rxAntennaCount=chan[5])
+        for _ in range(slot0):
+            ch.goNext()
+        enc = nr.LdpcEncoder(baseGraphNo=bg, modulation=mod, txLayers=layers, targetRate=rate)
+        dec = enc.getDecoder()
+        g = p.getGrid()
+        tbs = p.getTxBlockSize(rate)
+        tb = nr.random.bits(tbs[0])
+        nb = p.getBitSizes(g)
+        rm = enc.getRateMatchedCodeBlocks(tb, nb[0])
+        p.populateGrid(g, rm)
+        idx = p.getReIndexes(g, "PDSCH")
+        H = ch.getChannelMatrix()
+        F = p.getPrecodingMatrix(H)
+        pg = g.precode(F)
+        if freqDomain:
+            rx = pg.applyChannel(H).addNoise(snrDb=snr, useRxPower=True)
+        else:
+            w = pg.ofdmModulate().pad(ch.getMaxDelay())
+            r = ch.applyToSignal(w).addNoise(snrDb=snr, bwp=bwp, useRxPower=True)
+            rx = r.sync(ch.getTimingOffset()).ofdmDemodulate(bwp)
+        hest = (H @ F[None, ...]) if perfect else rx.estimateChannelLS(p.dmrs, polarInt=False, kernel='linear')[0]
+        eq, sc = rx.equalize(hest)
+        llr = p.getLLRsFromGrid(eq, idx, sc)[0]
+        rr = dec.recoverRate(llr, tbs[0])
+        db = dec.decode(rr, numIter=numIter)
+        out_tb, crc = dec.checkCrcAndMerge(db)
+        np.savez_compressed(os.path.join(GOLD, f'e2e_{name}.npz'),
+                            cfg=np.array(repr(dict(seed=seed, numRbs=numRbs, spacing=spacing, mod=mod, layers=layers,
+                                                   rate=rate, bg=bg, chan=chan, dm=dm, numIter=numIter, snr=snr,
+                                                   freqDomain=freqDomain, perfect=perfect, slot0=slot0))),
+                            tbs=np.int64(tbs), G=np.int64(nb), tb=np.packbits(tb.astype(np.uint8)), F=F,
+                            noise_var=np.float64(rx.noiseVar), llr=llr, eq_sample=eq.grid[:, ::3, ::7],
+                            hest_sample=hest[::3, ::7], decoded=np.packbits(np.uint8(out_tb)), crc=np.asarray(crc, bool),
+                            t_off=np.int64(ch.getTimingOffset()), max_delay=np.int64(ch.getMaxDelay()))
+        print(name, 'TBS', tbs, 'G', nb, 'crc', np.asarray(crc), 'bit errors', int(np.abs(out_tb[:-24] - tb).sum()))
+
+    dm1 = dict(configType=1, additionalPos=1)
+    # BASELINE cfg1: 25 PRB @15 kHz, QPSK, 1 layer, TDL-A SISO, BG2 R=0.3, 5 it, time domain, LS
+    one('cfg1_tdl_siso', 123, 25, 15, 'QPSK', 1, 0.3, 2, ('tdl', 'A', 30, 5, 1, 1), dm1, 5, 4.0, False, False, 0)
+    # MIMO CDL-C 4x2, 2 layers 16QAM, TD + LS, slot 3
+    one('cdl_mimo_td_ls', 321, 25, 15, '16QAM', 2, 490 / 1024, 1, ('cdl', 'C', 300, 5, [1, 2], [1, 1]), dm1, 10, 24.0, False, False, 3)
+    # same channel family, frequency domain + perfect CSI (the BLER notebook's default path), 4x4 4 layers 64QAM
+    one('cdl_mimo_fd_perfect', 55, 24, 30, '64QAM', 4, 0.5, 1, ('cdl', 'C', 100, 5, [1, 2], [1, 2]), dm1, 10, 26.0, True, True, 1)
+    # a failing slot (low SNR) -- CRC failures must match too
+    one('cdl_fail_td_ls', 77, 25, 15, '16QAM', 2, 0.6, 1, ('cdl', 'D', 100, 30, [1, 2], [1, 1]), dm1, 8, 6.0, False, False, 0)
+
+
+def harq_loop():
+    """Playground/HARQ/Harq.ipynb cell 7 with both random streams seeded (60 transmissions, Eb/No 0.5 dB)."""
+    from neoradium.utils import toLinear
+    mod, rate = "16QAM", 490 / 1024
+    enc = nr.LdpcEncoder(baseGraphNo=1, modulation=mod, txLayers=1, targetRate=rate)
+    harq = nr.HarqEntity(enc, "IR", 16)
+    snr = toLinear(0.5 + 10 * np.log10(enc.qm * rate))
+    std = np.sqrt(1 / snr)
+    nr.random.setSeed(123)
+    rangen = nr.random.getGenerator(456)
+    modem = nr.Modem(mod)
+    errs = []
+    for t in range(60):
+        tbs = [nr.random.bits(10000) if harq.needNewData[0] else None]
+        rm = harq.getRateMatchedCodeBlocks(tbs)
+        y = modem.modulate(rm[0])
+        y = y + rangen.awgn(y.shape, std)
+        _, be = harq.decodeLLRs([modem.getLLRsFromSymbols(y, std ** 2)], [10000])
+        errs.append(be[0])
+        harq.goNext()
+    np.savez_compressed(os.path.join(GOLD, 'harq_loop.npz'), noise_std=np.float64(std), block_errors=np.int64(errs),
+                        txBlocks=harq.txBlocks, rxBlocks=harq.rxBlocks, txBits=harq.txBits, rxBits=harq.rxBits,
+                        timeouts=np.int64(harq.numTimeouts), throughput=np.float64(harq.throughput))
+    print('harq loop: txBlocks', harq.txBlocks, 'rxBlocks', harq.rxBlocks, 'throughput %.2f' % harq.throughput)
+
+
+def snr_walks():
+    out = {}
+    rng = np.random.default_rng(5)
+    walks = []
+    for t in range(40):
+        mid, width, snr0, step = rng.uniform(-5, 20), rng.uniform(0.2, 2.5), int(rng.integers(-5, 20)), float(rng.choice([0.2, 0.5, 1.0]))
+        s = nr.SnrScheduler(snr0, step)
+        seq = []
+        for snr in s:
+            v = 100 / (1 + np.exp(4 * (snr - mid) / width))
+            v = 100.0 if v > 99.7 else (0.0 if v < 0.3 else float(np.round(v, 1)))
+            seq.append((snr, v))
+            s.setData(v)
+        walks.append((mid, width, snr0, step, len(seq)))
+        out[f'walk{t}'] = np.float64(seq)
+    out['walk_params'] = np.float64(walks)
+    np.savez_compressed(os.path.join(GOLD, 'snr_walks.npz'), **out)
+
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    copy_matlab()
+    coding()
+    phy()
+    host()
+    channels()
+    snr_walks()
+    harq_loop()
+    e2e()
+    print('fixtures written to', GOLD)
