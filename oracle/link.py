@@ -1,0 +1,109 @@
+"""Oracle (CPU, NumPy float64) for one whole PDSCH slot: the loop body of the reference's BLER harness
+(Playground/PDSCH/PDSCH-BLER.ipynb cell 2), restated on top of oracle/coding.py and oracle/phy.py.
+TEST INFRASTRUCTURE -- see oracle/__init__.py: used by tests, smoke() and bench.py's cpu_baseline leg only.
+
+Configuration-only data (DMRS template grid, RE index order, scrambling sequence, pilot table, static ray
+coefficients of the channel, tap matrix, CP lengths) is passed in as plain arrays in ``static``; every arithmetic
+stage of the slot is done here in NumPy in the order the reference performs it.
+"""
+import numpy as np
+
+from . import coding as oc
+from . import phy as op
+
+
+def static_from_link(link):
+    """Plain-array description of a configured neoradium_amd.engine.PdschLink (host data only, no GPU results)."""
+    ch = link.channel
+    A, nu, Alos, nulos = ch.staticCoefficients()
+    s = ch._normalisation()
+    return dict(
+        templates=link.templates.cpu().numpy(), pilots=link.pilots.cpu().numpy(), port_ks=np.asarray(link.port_ks),
+        dmrs_syms=list(link.dmrs_syms), l_cdm=link.l_cdm, k_cdm=link.k_cdm, re_index=link.re_index.cpu().numpy(),
+        scr=link.scr.cpu().numpy(), tbs=link.tbs, G=link.G, nl=link.nl, qm=link.qm, bg=link.cfg.bg, nr=link.nr, nt=link.nt,
+        K=link.K, L=link.L, nfft=link.nfft, n_rb=link.bwp.numRbs, slots_per_frame=link.bwp.slotsPerFrame,
+        slots_per_subframe=link.bwp.slotsPerSubFrame, sym_lens=[np.asarray(v) for v in link.sym_lens], fs=link.fs,
+        A=A * s, nu=nu, Alos=None if Alos is None else Alos * s, nulos=nulos, coeff=ch.getCoeffMatrix(),
+        max_delay=link.max_delay, first_prb=link.first_prb, num_iter=link.numIter, freq_domain=link.freqDomain,
+        perfect=link.chanEst == "Perfect", window=link.window != "NONE",
+        gain_times=lambda slot: link.gain_times([slot])[0])
+
+
+def run_slot(st, slot, snr_db, tb, z, F=None):
+    """One slot.  tb: (TBS,) bits; z: standard-normal complex array shaped like the noisy signal
+    ((Nr,L,K) in frequency-domain mode, (Nr, slotLen+maxDelay) in time-domain mode).  Returns a dict with
+    the per-code-block CRC verdicts, the decoded transport block and the LLRs."""
+    nl, qm, K, L, nfft = st['nl'], st['qm'], st['K'], st['L'], st['nfft']
+    # ---- Tx: CRC24A, segmentation, LDPC encode, rate match (ldpc.py:1167-1204)
+    rm, d = oc.encode_chain(tb, st['bg'], st['G'], nl, qm)
+    p = d['p']
+    # ---- scramble, modulate, layer/RE map onto the DMRS-filled grid (pdsch.py:855-932)
+    grid = st['templates'][slot % st['slots_per_frame']].copy()
+    syms = op.modulate(rm ^ st['scr'][:len(rm)].astype(np.int8), qm)
+    grid.reshape(-1)[st['re_index']] = syms
+    # ---- channel state of the slot (cdl.py:641-645, channelmodel.py:321-354)
+    t = st['gain_times'](slot)
+    gains = np.einsum('rtnm,cnm->crtn', st['A'], np.exp(2j * np.pi * t[:, None, None] * st['nu'][None]))
+    if st['Alos'] is not None:
+        los = st['Alos'][None] * np.exp(2j * np.pi * t * st['nulos'])[:, None, None]
+        gains = np.concatenate([los[..., None], gains], axis=3)
+    cir, off = op.cir_from_gains(gains[:-1], st['coeff'])
+    H = op.channel_matrix(cir, off, nfft, K)
+    # ---- wideband SVD precoder over the first PRB (pdsch.py:1080-1165 incl. its grouping quirk)
+    if F is None:
+        k0 = 12 * st['first_prb']
+        _, _, vh = np.linalg.svd(H[:, k0:k0 + 12].mean(axis=(0, 1)))
+        F = np.conj(vh).T[:, :nl] / np.sqrt(nl)
+    pg = op.precode(grid, F)
+    snr = 10 ** (snr_db / 10)
+    sis = slot % st['slots_per_subframe']
+    if st['freq_domain']:
+        rx = op.apply_channel_fd(pg, H)
+        sigma = np.sqrt(np.var(rx) / snr)                                          # grid.py:1040-1046
+        rxg = rx + (sigma / np.sqrt(2)) * z
+        nv = sigma * sigma
+    else:
+        sl = st['sym_lens'][sis]
+        cps = sl[:-1] - nfft
+        w = op.ofdm_modulate(pg, nfft, cps, window=st['window'])
+        w = np.concatenate([w, np.zeros((w.shape[0], st['max_delay']))], axis=1)   # Waveform.pad
+        cir1, _ = op.cir_from_gains(gains, st['coeff'])
+        y = _apply_cir(w, cir1, sl)
+        sigma = op.noise_std_waveform(y, nfft, cps, st['n_rb'], snr_db)            # waveform.py:119-142
+        y = y + (sigma / np.sqrt(2)) * z
+        rxg = op.ofdm_demodulate(y[:, off:], nfft, cps, K)                         # sync + demodulate
+        nv = sigma * sigma * nfft                                                  # waveform.py:523
+    # ---- Rx: channel estimate, MMSE, demap, rate recovery, decode, CRC
+    if st['perfect']:
+        hest = H @ F[None, None]
+    else:
+        hest = op.estimate_channel_ls(rxg, st['pilots'][slot % st['slots_per_frame']], st['dmrs_syms'], st['port_ks'],
+                                      l_cdm=st['l_cdm'], k_cdm=st['k_cdm'])
+    eq, sc = op.equalize_mmse(rxg, hest, nv)
+    llr = op.pdsch_llrs(eq.reshape(-1)[st['re_index']], sc.reshape(-1)[st['re_index']], nv, qm, None, scr=st['scr'])
+    rr, _ = oc.rate_recover(llr, p, nl, qm)
+    dec = oc.decode(rr, st['bg'], p.iLS, p.Zc, st['num_iter'])
+    out, crc = oc.crc_check_and_merge(dec, p)
+    return dict(crc=crc, tb_out=out, llr=llr, F=F, off=off, nv=nv, p=p)
+
+
+def _apply_cir(x, cir1, sym_lens):
+    """channelmodel.py:403-448 applyToSignal in its per-(rx,tx) FIR form (identical to the reference's
+    per-path lfilter + gain mix to 1e-15): y[r,n] = sum_t sum_l cir1[sym(n),r,t,l] x[t,n-l]."""
+    nt, ns = x.shape
+    nsets, nr, _, cl = cir1.shape
+    idx = np.concatenate([np.full(int(n), i) for i, n in enumerate(sym_lens)])[:ns]
+    if ns > len(idx):
+        idx = np.append(idx, np.full(ns - len(idx), nsets - 1))
+    y = np.zeros((nr, ns), dtype=np.complex128)
+    bounds = np.concatenate([[0], np.nonzero(np.diff(idx))[0] + 1, [ns]])
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        c = cir1[idx[a]]
+        lo = max(0, a - cl + 1)
+        seg = x[:, lo:b]
+        for r in range(nr):
+            acc = np.zeros(b - a, dtype=np.complex128)
+            for t_ in range(nt):
+                acc += np.convolve(seg[t_], c[r, t_])[a - lo:a - lo + (b - a)]
+            y[r, a:b] = acc
+    return y

@@ -79,11 +79,13 @@ def pdsch_scramble_cinit(rnti, q, nid):
     return rnti * (1 << 15) + q * (1 << 14) + nid
 
 
-def pdsch_llrs(eq_syms, scales, noise_var, qm, c_init):
-    """pdsch.py:935-1005 getLLRsFromGrid on already layer-demapped symbols/scales (one codeword)."""
+def pdsch_llrs(eq_syms, scales, noise_var, qm, c_init, scr=None):
+    """pdsch.py:935-1005 getLLRsFromGrid on already layer-demapped symbols/scales (one codeword).
+    ``scr``: the scrambling bits if already generated (else derived from c_init)."""
     nv = max(noise_var, 1e-10)
     llr = demap_maxlog(eq_syms, nv, qm)
-    llr = llr * (1 - 2 * gold(c_init, len(llr)).astype(np.float64))
+    c = gold(c_init, len(llr)) if scr is None else np.asarray(scr)[:len(llr)]
+    llr = llr * (1 - 2 * c.astype(np.float64))
     if scales is not None:
         llr = llr * np.repeat(scales, qm)
     return llr
