@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libnrx.so')
+_LIB_PATH = os.environ.get('NRX_LIB', os.path.join(_HERE, 'libnrx.so'))    # NRX_LIB: developer override
 
 i32, i64, u64, vp = C.c_int32, C.c_int64, C.c_size_t, C.c_void_p
 

@@ -334,10 +334,12 @@ __global__ void svd_precoder_kernel(const cd* __restrict__ Hblk, int n_avg, int 
       U[i][j] = cd(i == j ? 1.0 : 0.0, 0.0);
     }
   for (int sweep = 0; sweep < 30; ++sweep) {
-    double offn = 0;
-    for (int p = 0; p < nr; ++p)
+    double offn = 0, diagn = 0;
+    for (int p = 0; p < nr; ++p) {
+      diagn += G[p][p].re * G[p][p].re;
       for (int q = p + 1; q < nr; ++q) offn += nrx::norm2(G[p][q]);
-    if (offn < 1e-300) break;
+    }
+    if (offn <= 1e-34 * diagn || offn < 1e-300) break;   // off-diagonal mass below double-precision resolution
     for (int p = 0; p < nr; ++p)
       for (int q = p + 1; q < nr; ++q) {
         const double apq = sqrt(nrx::norm2(G[p][q]));

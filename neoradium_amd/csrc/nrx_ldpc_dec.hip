@@ -13,6 +13,7 @@
 //     via scalar loads), one s_barrier per layer.
 // Reference quirks reproduced literally: clip to +-1e10, punctured columns start at 0, sign(0)=+1 through
 // (v < 0), first-index argmin, second minimum = min(|v_argmin + 1e5|, other |v|), 0.75 scaling, no early stop.
+#include <stdlib.h>
 #include <utility>
 #include "gen_ldpc_bg.h"
 #include "nrx_common.h"
@@ -339,6 +340,11 @@ int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int 
   return NRX_OK;
 }
 
+}  // namespace
+int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                    uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec2.hip
+namespace {
+
 template <typename T, bool EXACT>
 int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t out_cols,
                      uint8_t* hard, T* belief, void* ws, size_t ws_bytes, void* stream) {
@@ -353,6 +359,12 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
               "nrx_ldpc_decode: out_cols must be K (%d) or all %d columns", cfg->K, cols * cfg->Zc);
   NRX_REQUIRE(cfg->N == (cols - 2) * cfg->Zc, NRX_E_SHAPE, "nrx_ldpc_decode: cfg->N inconsistent");
   if (n_cb == 0) return NRX_OK;
+  if constexpr (!EXACT) {
+    // throughput kernel: hard decisions of the K information bits (what the link loop consumes)
+    static const bool force_v1 = getenv("NRX_LDPC_V1") != nullptr;
+    if (hard && !belief && out_cols == cfg->K && !force_v1)
+      return nrx_ldpc_decode_fast_launch((const float*)llr, n_cb, cfg, n_iter, hard, (hipStream_t)stream);
+  }
   int zi = -1;
   for (int i = 0; i < 51; ++i)
     if (kZList.z[i] == cfg->Zc) zi = i;

@@ -86,7 +86,7 @@ __device__ uint32_t block_crc(BitFn bit, int64_t n, int poly_id, uint32_t* red) 
 }
 
 // ---------------------------------------------------------------------------------------------- nrx_crc
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 crc_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, int poly_id,
                 uint8_t* __restrict__ out) {
   __shared__ uint32_t red[16];
@@ -99,7 +99,7 @@ crc_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_s
 // ------------------------------------------------------------------------------------- nrx_ldpc_segment
 // ldpc.py:981-1030.  One workgroup per (tb, code block): gathers the payload of block c from
 // [TB bits | TB CRC24A | zero pad], appends CRC24B when C>1, zero fillers.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 segment_kernel(const uint8_t* __restrict__ tb, int add_tb_crc, int A, int B, int C, int K, int cb_len,
                uint8_t* __restrict__ cbs) {
   __shared__ uint32_t red[16];
@@ -279,7 +279,7 @@ rate_recover_kernel(const T* __restrict__ llr, int n_tb, int llr_len, RmGeom g, 
 
 // ----------------------------------------------------------------------------------- nrx_ldpc_crc_merge
 // ldpc.py:1584-1619.  One workgroup per code block.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 crc_merge_kernel(const uint8_t* __restrict__ dec, int C, int K, int cb_len, int B, uint8_t* __restrict__ tb_out,
                  uint8_t* __restrict__ cb_ok) {
   __shared__ uint32_t red[16];
@@ -295,7 +295,7 @@ crc_merge_kernel(const uint8_t* __restrict__ dec, int C, int K, int cb_len, int 
   if (threadIdx.x == 0) cb_ok[blockIdx.x] = r == 0 ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 crc_ok_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, int poly_id,
                    uint8_t* __restrict__ ok) {
   __shared__ uint32_t red[16];
@@ -330,6 +330,13 @@ count_errors_kernel(const uint8_t* __restrict__ cb_ok, int n_ok, const uint8_t* 
   }
 }
 
+// threads per row for the workgroup-parallel CRC: ~512 bits per thread, 64..1024
+int crc_threads(int64_t n_bits) {
+  int t = 64;
+  while (t < 1024 && (int64_t)t * 512 < n_bits) t *= 2;
+  return t;
+}
+
 int fill_geom(const nrx_ldpc_cfg* cfg, int G, int nl, int qm, int rv, int n_ref, RmGeom* g) {
   static const int k0num[2][4] = {{0, 17, 33, 56}, {0, 13, 25, 43}};
   g->C = cfg->C; g->N = cfg->N; g->K = cfg->K; g->F = cfg->F; g->zc = cfg->Zc;
@@ -353,7 +360,7 @@ extern "C" int32_t nrx_crc(const uint8_t* bits, int32_t n_rows, int64_t row_len,
   NRX_REQUIRE(poly_id >= NRX_CRC6 && poly_id <= NRX_CRC24C, NRX_E_ARG, "nrx_crc: unknown polynomial id %d", poly_id);
   NRX_REQUIRE(n_rows >= 0 && row_len >= 0 && row_stride >= row_len, NRX_E_SHAPE, "nrx_crc: bad row geometry");
   if (n_rows == 0) return NRX_OK;
-  hipLaunchKernelGGL(crc_rows_kernel, dim3(n_rows), dim3(row_len > 4096 ? 256 : 64), 0, (hipStream_t)stream, bits,
+  hipLaunchKernelGGL(crc_rows_kernel, dim3(n_rows), dim3(crc_threads(row_len)), 0, (hipStream_t)stream, bits,
                      row_len, row_stride, poly_id, crc_out);
   NRX_CHECK_LAUNCH("nrx_crc");
   return NRX_OK;
@@ -367,7 +374,7 @@ extern "C" int32_t nrx_ldpc_segment(const uint8_t* tb, int32_t n_tb, int32_t A, 
               cfg->B, A);
   if (n_tb == 0) return NRX_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(segment_kernel, dim3(n_tb * cfg->C), dim3(256), 0, st, tb, add_tb_crc, A, cfg->B, cfg->C, cfg->K,
+  hipLaunchKernelGGL(segment_kernel, dim3(n_tb * cfg->C), dim3(crc_threads(A)), 0, st, tb, add_tb_crc, A, cfg->B, cfg->C, cfg->K,
                      cfg->cb_len, cbs);
   NRX_CHECK_LAUNCH("nrx_ldpc_segment");
   return NRX_OK;
@@ -451,10 +458,10 @@ extern "C" int32_t nrx_ldpc_crc_merge(const uint8_t* dec, int32_t n_tb, const nr
   NRX_REQUIRE(!tb_ok || tb_out, NRX_E_ARG, "nrx_ldpc_crc_merge: tb_ok needs tb_out");
   if (n_tb == 0) return NRX_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(crc_merge_kernel, dim3(n_tb * cfg->C), dim3(cfg->cb_len > 4096 ? 256 : 64), 0, st, dec, cfg->C,
+  hipLaunchKernelGGL(crc_merge_kernel, dim3(n_tb * cfg->C), dim3(crc_threads(cfg->cb_len)), 0, st, dec, cfg->C,
                      cfg->K, cfg->cb_len, cfg->B, tb_out, cb_ok);
   if (tb_ok)
-    hipLaunchKernelGGL(crc_ok_rows_kernel, dim3(n_tb), dim3(cfg->B > 4096 ? 256 : 64), 0, st, tb_out, (int64_t)cfg->B,
+    hipLaunchKernelGGL(crc_ok_rows_kernel, dim3(n_tb), dim3(crc_threads(cfg->B)), 0, st, tb_out, (int64_t)cfg->B,
                        (int64_t)cfg->C * (cfg->cb_len - (cfg->C > 1 ? 24 : 0)), NRX_CRC24A, tb_ok);
   NRX_CHECK_LAUNCH("nrx_ldpc_crc_merge");
   return NRX_OK;

@@ -205,7 +205,7 @@ class PdschLink:
                             llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
         rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm)
         dec = ops.ldpc_decode(rr, cfg, self.numIter)
-        tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg)
+        tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
         ops.count_errors(cb_ok, tb_out, tb, counters)
         if details:
             return dict(tb=tb, cb_ok=cb_ok, tb_out=tb_out, llr=llr, eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv,

@@ -127,7 +127,7 @@ def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False):
     return bel if belief else hard
 
 
-def ldpc_crc_merge(dec, cfg, want_tb=True):
+def ldpc_crc_merge(dec, cfg, want_tb=True, want_tb_crc=True):
     """ldpc.py:1584-1619 checkCrcAndMerge (+ TB CRC24A check): (n_tb*C, K) -> tb_out (n_tb,M>=B), cb_ok (n_tb,C), tb_ok."""
     dec = _u8(dec)
     if dec.dim() != 2 or dec.shape[1] != cfg.K or dec.shape[0] % cfg.C:
@@ -137,7 +137,7 @@ def ldpc_crc_merge(dec, cfg, want_tb=True):
     cb_ok = torch.empty((n_tb, cfg.C), dtype=torch.uint8, device=dev)
     width = cfg.C * (cfg.cb_len - 24) if cfg.C > 1 else cfg.B
     tb_out = torch.empty((n_tb, width), dtype=torch.uint8, device=dev) if want_tb else None
-    tb_ok = torch.empty((n_tb,), dtype=torch.uint8, device=dev) if want_tb else None
+    tb_ok = torch.empty((n_tb,), dtype=torch.uint8, device=dev) if (want_tb and want_tb_crc) else None
     check(lib().nrx_ldpc_crc_merge(ptr(dec), n_tb, C.byref(cfg), ptr(tb_out), ptr(cb_ok), ptr(tb_ok), stream()))
     return tb_out, cb_ok, tb_ok
 
