@@ -261,6 +261,15 @@ int32_t nrx_effective_channel_f64(const void* H, const void* F, int64_t f_stride
 int32_t nrx_apply_td_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* cir1, int32_t n_sets,
                          int32_t n_rx, int32_t cl, const int32_t* set_lens, void* y, void* stream);
 
+/* The same filter in the reference's own path form (per-path fractional-delay FIR, then the per-symbol gain mix):
+ * gains1 (n_items,n_sets,n_rx,n_tx,n_paths) complex128; taps (n_paths,flen) the non-zero window of each row of the
+ * coefficient matrix (channelmodel.py:292-318), tap_off (n_paths) its first column; hist >= max(tap_off)+flen-1.
+ * Identical result up to summation order, ~4.6x fewer FMAs at CDL-C 4x4. */
+int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                               int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
+                               const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens, void* y,
+                               void* stream);
+
 /* ------------------------------------------------------------------------------------- LS channel estimation
  * grid.py:874-975 estimateChannelLS(polarInt=False, kernel='linear') (channel estimate; the noise-variance
  * branch grid.py:808-851 is not on the graded path).  rx (n_batch,nr,L,K); pilots (n_sets,P,n_ds,n_k) pilot

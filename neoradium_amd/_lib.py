@@ -68,6 +68,7 @@ SIGNATURES.update({
     'nrx_cir_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_channel_matrix_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     'nrx_apply_td_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, _i32p, vp, vp]),
+    'nrx_apply_td_paths_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, vp, vp, i32, i32, _i32p, vp, vp]),
     'nrx_random_bits': (i32, [vp, i64, i32, u64_, u64_, i64, vp]),
     'nrx_channel_matrix_sub_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp]),
     'nrx_svd_precoder_f64': (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),

@@ -174,7 +174,8 @@ class ChannelModel:
             raise ValueError(f"The inputSignal is too short. It must be at least {slotLen} samples.")
         if ns > self.symLens.sum():
             print("WARNING: The delays are larger than symbol size! Extending gains to match delays!")
-        y = ops.apply_td(D(np.complex128(x)[None]), self._dev['cir1'], [int(v) for v in self.symLens])
+        taps, offs = ops.path_taps(self.coeffMatrix, self.filterLen)
+        y = ops.apply_td_paths(D(np.complex128(x)[None]), self._dev['gains1'], D(taps), offs, [int(v) for v in self.symLens])
         return Waveform(N(y)[0])
 
     def applyKFactorScaling(self):

@@ -175,6 +175,55 @@ apply_td_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restri
   for (int r = 0; r < NR; ++r) y[((size_t)b * NR + r) * ns + n] = acc[r];
 }
 
+// Path form of the same filter (what the reference literally does, channelmodel.py:431-447): every path p is a
+// flen-tap fractional-delay FIR at integer offset off_p, shared by all receive antennas; the per-symbol gains mix
+// the filtered signals:  y[r][n] = sum_t sum_p g[sym(n)][r][t][p] * ( sum_k taps[p][k] * x[t][n - off_p - k] ).
+// P*(2*flen + 4*Nr) real FMAs per (t, n) instead of 4*Nr*cl for the dense CIR form (4.6x fewer at CDL-C, 4x4).
+template <int NR>
+__global__ void __launch_bounds__(TD_TILE)
+apply_td_paths_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ gains1, int n_paths,
+                      const double* __restrict__ taps, const int32_t* __restrict__ tap_off, int flen, int hist, TdGeom g,
+                      cd* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cd* xs = (cd*)smem;  // [nt][TD_TILE + hist]
+  const int b = blockIdx.y;
+  const int set = blockIdx.x / g.tiles_per_set, tile = blockIdx.x % g.tiles_per_set;
+  const int n0 = g.start[set] + tile * TD_TILE;
+  const int n_end = g.start[set + 1];
+  if (n0 >= n_end) return;
+  const int span = TD_TILE + hist;
+  for (int i = threadIdx.x; i < nt * span; i += blockDim.x) {
+    const int t = i / span, j = i - t * span;
+    const int64_t n = (int64_t)n0 - hist + j;
+    xs[i] = (n >= 0 && n < ns) ? x[((size_t)b * nt + t) * ns + n] : cd(0, 0);
+  }
+  __syncthreads();
+  const int n = n0 + threadIdx.x;
+  if (n >= n_end) return;
+  cd acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = cd(0, 0);
+  const cd* gb = gains1 + ((size_t)b * g.n_sets + set) * NR * nt * n_paths;
+  for (int t = 0; t < nt; ++t) {
+    const cd* xr = xs + t * span + hist + threadIdx.x;
+    for (int p = 0; p < n_paths; ++p) {
+      const int off = tap_off[p];
+      const double* c = taps + (size_t)p * flen;
+      double fr = 0, fi = 0;
+      for (int k = 0; k < flen; ++k) {
+        const cd xv = xr[-(off + k)];
+        fr += c[k] * xv.re;
+        fi += c[k] * xv.im;
+      }
+      const cd f(fr, fi);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) nrx::cmac(acc[r], gb[((size_t)r * nt + t) * n_paths + p], f);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) y[((size_t)b * NR + r) * ns + n] = acc[r];
+}
+
 int ilog2(int n) {
   int l = 0;
   while ((1 << l) < n) ++l;
@@ -440,5 +489,55 @@ extern "C" int32_t nrx_effective_channel_f64(const void* H, const void* F, int64
   hipLaunchKernelGGL(eff_channel_kernel, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const cd*)H, (const cd*)F, f_stride, lk, n_rx, n_tx, n_layers, (cd*)out, total);
   NRX_CHECK_LAUNCH("nrx_effective_channel");
+  return NRX_OK;
+}
+
+static int32_t td_geom(const int32_t* set_lens, int32_t n_sets, int64_t ns, TdGeom* g) {
+  g->n_sets = n_sets;
+  int64_t s = 0;
+  int maxlen = 0;
+  for (int i = 0; i < n_sets; ++i) {
+    g->start[i] = (int32_t)(s < ns ? s : ns);
+    s += set_lens[i];
+  }
+  g->start[n_sets] = (int32_t)ns;  // samples past the listed symbols keep the last gain set (channelmodel.py:443-446)
+  for (int i = 0; i < n_sets; ++i) {
+    const int len = g->start[i + 1] - g->start[i];
+    maxlen = len > maxlen ? len : maxlen;
+  }
+  g->tiles_per_set = (maxlen + TD_TILE - 1) / TD_TILE;
+  if (g->tiles_per_set < 1) g->tiles_per_set = 1;
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                                          int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
+                                          const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
+                                          void* y, void* stream) {
+  NRX_REQUIRE(x && gains1 && taps && tap_off && set_lens && y, NRX_E_ARG, "nrx_apply_td_paths: NULL buffer");
+  NRX_REQUIRE(n_sets >= 1 && n_sets <= 16 && n_tx >= 1 && n_paths >= 1 && flen >= 1 && hist >= 0 && ns > 0 && n_items >= 0,
+              NRX_E_ARG, "nrx_apply_td_paths: bad sizes");
+  NRX_REQUIRE(n_rx == 1 || n_rx == 2 || n_rx == 4 || n_rx == 8, NRX_E_UNSUPPORTED, "nrx_apply_td_paths: Nr must be 1, 2, 4 or 8 (got %d)", n_rx);
+  if (n_items == 0) return NRX_OK;
+  TdGeom g;
+  td_geom(set_lens, n_sets, ns, &g);
+  const size_t lds = sizeof(cd) * (size_t)n_tx * (TD_TILE + hist);
+  NRX_REQUIRE(lds <= 160 * 1024, NRX_E_UNSUPPORTED, "nrx_apply_td_paths: Nt*delay too large for LDS staging (%zu B)", lds);
+  const dim3 grid(g.tiles_per_set * n_sets, n_items);
+  hipStream_t st = (hipStream_t)stream;
+#define NRX_TDP_CASE(NR)                                                                                                  \
+  case NR:                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)apply_td_paths_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(apply_td_paths_kernel<NR>, grid, dim3(TD_TILE), lds, st, (const cd*)x, n_tx, ns, (const cd*)gains1,  \
+                       n_paths, taps, tap_off, flen, hist, g, (cd*)y);                                                   \
+    break;
+  switch (n_rx) {
+    NRX_TDP_CASE(1)
+    NRX_TDP_CASE(2)
+    NRX_TDP_CASE(4)
+    NRX_TDP_CASE(8)
+  }
+#undef NRX_TDP_CASE
+  NRX_CHECK_LAUNCH("nrx_apply_td_paths");
   return NRX_OK;
 }

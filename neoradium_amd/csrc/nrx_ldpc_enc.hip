@@ -97,30 +97,41 @@ crc_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_s
 }
 
 // ------------------------------------------------------------------------------------- nrx_ldpc_segment
-// ldpc.py:981-1030.  One workgroup per (tb, code block): gathers the payload of block c from
-// [TB bits | TB CRC24A | zero pad], appends CRC24B when C>1, zero fillers.
+// ldpc.py:981-1030 in two launches:
+//  1. tb_crc_scatter_kernel: one workgroup (up to 1024 threads) per transport block computes CRC24A
+//     (chancodebase.py:161-189 appendCrc('24A')) and writes its 24 bits straight to their final place inside the
+//     code-block buffer (bits A..A+23 of the segmented stream: tail of the last block, possibly straddling two);
+//  2. segment_kernel: one small workgroup per (tb, code block) copies the payload from the TB, leaves the TB-CRC
+//     bits that are already in place, zero-pads, appends CRC24B (C>1) and the zero filler bits.
 __global__ void __launch_bounds__(1024)
-segment_kernel(const uint8_t* __restrict__ tb, int add_tb_crc, int A, int B, int C, int K, int cb_len,
-               uint8_t* __restrict__ cbs) {
+tb_crc_scatter_kernel(const uint8_t* __restrict__ tb, int A, int C, int K, int per, uint8_t* __restrict__ cbs) {
+  __shared__ uint32_t red[16];
+  const int t = blockIdx.x;
+  const uint8_t* src = tb + (size_t)t * A;
+  const uint32_t crc = block_crc([&](int64_t i) { return src[i] & 1; }, A, NRX_CRC24A, red);
+  if (threadIdx.x < 24) {
+    const int64_t g = (int64_t)A + threadIdx.x;
+    const int c = (int)(g / per), o = (int)(g - (int64_t)c * per);
+    cbs[((size_t)t * C + c) * K + o] = (crc >> (23 - threadIdx.x)) & 1u;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+segment_kernel(const uint8_t* __restrict__ tb, int A, int B, int C, int K, int cb_len, uint8_t* __restrict__ cbs) {
   __shared__ uint32_t red[16];
   const int t = blockIdx.x / C, c = blockIdx.x % C;
   const int per = (B + C - 1) / C;  // payload bits per block before its CRC
   const uint8_t* src = tb + (size_t)t * A;
   uint8_t* dst = cbs + (size_t)blockIdx.x * K;
-  // The (at most two) blocks that hold TB-CRC bits compute the CRC24A of the whole TB themselves
-  // (chancodebase.py:161-189 appendCrc('24A')); no scratch buffer, no extra launch.
-  uint32_t tbcrc = 0;
-  if (add_tb_crc && (int64_t)(c + 1) * per > A)
-    tbcrc = block_crc([&](int64_t i) { return src[i] & 1; }, A, NRX_CRC24A, red);
-  auto payload = [&](int64_t i) -> int {
+  for (int i = threadIdx.x; i < per; i += blockDim.x) {
     const int64_t g = (int64_t)c * per + i;
-    if (g < A) return src[g] & 1;
-    if (g < B) return (int)((tbcrc >> (23 - (int)(g - A))) & 1u);
-    return 0;  // zero padding at the end of the last block (ldpc.py:1014-1016)
-  };
-  for (int i = threadIdx.x; i < per; i += blockDim.x) dst[i] = (uint8_t)payload(i);
+    if (g < A) dst[i] = src[g] & 1;
+    else if (g >= B) dst[i] = 0;  // zero padding at the end of the last block (ldpc.py:1014-1016)
+    // A <= g < B: TB-CRC bit, already written by tb_crc_scatter_kernel (or part of the caller's TB when B == A)
+  }
+  __syncthreads();
   if (C > 1) {
-    const uint32_t r = block_crc(payload, per, NRX_CRC24B, red);
+    const uint32_t r = block_crc([&](int64_t i) { return dst[i] & 1; }, per, NRX_CRC24B, red);
     if (threadIdx.x < 24) dst[per + threadIdx.x] = (r >> (23 - threadIdx.x)) & 1u;
   }
   for (int i = cb_len + threadIdx.x; i < K; i += blockDim.x) dst[i] = 0;  // fillers are ZERO bits (ldpc.py:1025-1028)
@@ -374,8 +385,12 @@ extern "C" int32_t nrx_ldpc_segment(const uint8_t* tb, int32_t n_tb, int32_t A, 
               cfg->B, A);
   if (n_tb == 0) return NRX_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(segment_kernel, dim3(n_tb * cfg->C), dim3(crc_threads(A)), 0, st, tb, add_tb_crc, A, cfg->B, cfg->C, cfg->K,
-                     cfg->cb_len, cbs);
+  const int per = (cfg->B + cfg->C - 1) / cfg->C;
+  if (add_tb_crc)
+    hipLaunchKernelGGL(tb_crc_scatter_kernel, dim3(n_tb), dim3(crc_threads(A)), 0, st, tb, A, cfg->C, cfg->K, per, cbs);
+  int th = crc_threads(per);
+  if (th > 256) th = 256;
+  hipLaunchKernelGGL(segment_kernel, dim3(n_tb * cfg->C), dim3(th), 0, st, tb, A, cfg->B, cfg->C, cfg->K, cfg->cb_len, cbs);
   NRX_CHECK_LAUNCH("nrx_ldpc_segment");
   return NRX_OK;
 }

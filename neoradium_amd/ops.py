@@ -498,3 +498,43 @@ def random_bits(n_batch, n_per, seed, device, stream_id=0, batch_offset=0):
     out = torch.empty((n_batch, n_per), dtype=torch.uint8, device=device)
     check(lib().nrx_random_bits(ptr(out), n_per, n_batch, int(seed), int(stream_id), int(batch_offset), stream()))
     return out
+
+
+def path_taps(coeff, filter_len=16):
+    """Split a (P, cl) coefficient matrix (ChannelModel.getCoeffMatrix) into its (P, flen) non-zero windows + offsets."""
+    import numpy as np
+    coeff = np.asarray(coeff)
+    P, cl = coeff.shape
+    offs = np.zeros(P, dtype=np.int32)
+    taps = np.zeros((P, filter_len))
+    for p in range(P):
+        nz = np.nonzero(coeff[p])[0]
+        lo = int(nz[0]) if len(nz) else 0
+        lo = min(lo, max(cl - filter_len, 0))
+        if len(nz) and nz[-1] - lo >= filter_len:
+            raise ValueError("coefficient row has more than filter_len consecutive taps")
+        w = coeff[p, lo:lo + filter_len]
+        taps[p, :len(w)] = w
+        offs[p] = lo
+    return taps, offs
+
+
+def apply_td_paths(x, gains1, taps, tap_off, set_lens):
+    """ChannelModel.applyToSignal, path form: x (n,Nt,ns), gains1 (n,nc+1,Nr,Nt,P), taps (P,flen), tap_off (P) -> (n,Nr,ns)."""
+    x = x.to(torch.complex128).contiguous()
+    gains1 = gains1.to(torch.complex128).contiguous()
+    n, nt, ns = x.shape
+    if gains1.shape[0] != n or gains1.shape[3] != nt or gains1.shape[1] != len(set_lens):
+        raise ValueError("The number of transmit antennas in the signal does not match the channel.")
+    nr, P = gains1.shape[2], gains1.shape[4]
+    dev = _dev(x)
+    taps = taps.to(device=dev, dtype=torch.float64).contiguous()
+    tap_off = _i32(tap_off, dev)
+    if taps.shape[0] != P or tap_off.numel() != P:
+        raise ValueError("tap table / path count mismatch")
+    flen = taps.shape[1]
+    hist = int(tap_off.max()) + flen - 1
+    y = torch.empty((n, nr, ns), dtype=torch.complex128, device=dev)
+    check(lib().nrx_apply_td_paths_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen,
+                                       hist, _host_i32(set_lens), ptr(y), stream()))
+    return y

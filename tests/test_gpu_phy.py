@@ -187,8 +187,11 @@ def test_tdl_chain(dev):
     x = crandn(rng, n, nt, ns)
     x[..., slot_len:] = 0
     y = ops.apply_td(T(x, dev), cir, list(cps + nfft)).cpu().numpy()
+    taps, offs = ops.path_taps(coeff)
+    y2 = ops.apply_td_paths(T(x, dev), gains, T(taps, dev), offs, list(cps + nfft)).cpu().numpy()   # path form
     for b in range(n):
-        assert rel(y[b], op.apply_td(x[b], ref_g[b], coeff, cps + nfft)) < 1e-11
+        ref_y = op.apply_td(x[b], ref_g[b], coeff, cps + nfft)
+        assert rel(y[b], ref_y) < 1e-11 and rel(y2[b], ref_y) < 1e-11
 
 
 @pytest.mark.parametrize("P,l_cdm,ds,ctype", [(1, 1, [2], 1), (2, 1, [2, 11], 1), (4, 1, [2, 7, 11], 1), (4, 2, [2, 3, 10, 11], 1),
