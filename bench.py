@@ -143,6 +143,12 @@ def main():
         # algorithmic HBM bytes of the dominant kernel (layered min-sum decoder), SURVEY 8d: C*N*4 in + C*K/8 out per slot
         alg_bytes = B * (cfg.C * cfg.N * 4 + cfg.C * cfg.K / 8)
         achieved = alg_bytes / (dec_ms * 1e-3) / 1e9
+        traffic = None
+        try:                                              # HBM bytes per launch from the committed PMC passes
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r1_decoder_traffic.json')))
+            traffic = (tr['FETCH_SIZE_KB_per_launch'] + tr['WRITE_SIZE_KB_per_launch']) * 1024.0 * B / tr['batch_slots']
+        except Exception:
+            pass
         edge_visits = B * cfg.C * link.numIter * 316 * cfg.Zc
         out = {
             "metric": "PDSCH slots/sec at 273 PRB 64-QAM 4x4 LDPC-BG1; BLER match vs CPU ref",
@@ -155,7 +161,7 @@ def main():
                        "slots_per_step_per_gpu": B, "snr_db": args.snr, "sharding": "slot ranges per rank, 1 all-reduce"},
             "bler": {"block_errors": int(c[0]), "blocks": int(c[1]), "bit_errors": int(c[2]), "bits": int(c[3])},
             "roofline": {"bound": "hbm", "kernel": "ldpc_dec_kernel<%s,BG1>" % ("float" if args.decoder == "f32" else "double"),
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": dec_ms, "launch_share_of_step": dec_ms / (dt / K * 1e3),
                          "note": "decoder re-uses its LDS/VGPR-resident working set 50x: it is VALU/LDS-issue bound, "
                                  "HBM only at entry/exit (SURVEY 8d)",
