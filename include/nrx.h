@@ -283,6 +283,36 @@ int32_t nrx_chest_ls_f64(const void* rx, const void* pilots, const int32_t* pil_
                          const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
                          int32_t K, int32_t nr, int32_t P, void* hest, int32_t n_batch, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ Polar
+ * Control-channel codec (DCI / PBCH / UCI).  The code construction (polar.py:298-408 PolarBase.initialize) is
+ * integer bookkeeping done by the host binding; the kernels take its index tables.
+ *
+ * nrx_polar_encode -- polar.py:527-564 PolarEncoder.encode.  cbs: n_cw x K bits (CRC attached), in_il: K input
+ *   interleaver indices or NULL, msg_pos: K message-bit positions, pc_pos: n_pc parity-check positions.
+ *   coded: n_cw x N.
+ * nrx_polar_rate_match -- polar.py:567-603 rateMatch; gather[e] = index into the N coded bits (sub-block
+ *   interleave o bit selection o coded-bit interleave composed by the host).
+ * nrx_polar_rate_recover_f64 -- polar.py:882-928 recoverRate; deinterleave = inverse coded-bit interleaver (E) or
+ *   NULL, inv_subblock = inverse sub-block interleaver (N).  E >= N adds the repeated LLRs (TS 38.212 5.4.1.2; the
+ *   reference raises there, polar.py:914-915).
+ * nrx_polar_scl_decode_f64 -- polar.py:606-720 SclDecoder + :931-982 PolarDecoder.decode: clip to +-20, min-sum
+ *   SCL with list_size <= 8, CRC-aided pick.  info_mask: N bytes, 1 = non-frozen leaf (message or parity-check
+ *   bit), n_info of them; msg_src[m]: which non-frozen leaf (in leaf order) carries message bit m after input
+ *   de-interleaving (K entries).  msg_out: n_cw x K (first CRC-passing candidate, else the cheapest), crc_ok: n_cw;
+ *   optional cand_out: n_cw x list_size x K and cost_out: n_cw x list_size (all candidates, cheapest first).
+ *   crc_poly_id -1 = no CRC (cheapest candidate). */
+int32_t nrx_polar_encode(const uint8_t* cbs, int32_t n_cw, int32_t K, int32_t N, const int32_t* in_il,
+                         const int32_t* msg_pos, const int32_t* pc_pos, int32_t n_pc, uint8_t* coded, void* stream);
+int32_t nrx_polar_rate_match(const uint8_t* coded, int32_t n_cw, int32_t N, int32_t E, const int32_t* gather,
+                             uint8_t* out, void* stream);
+int32_t nrx_polar_rate_recover_f64(const double* llr, int32_t n_cw, int32_t N, int32_t E, int32_t K,
+                                   const int32_t* deinterleave, const int32_t* inv_subblock, double* out,
+                                   void* stream);
+int32_t nrx_polar_scl_decode_f64(const double* llr, int32_t n_cw, int32_t N, int32_t list_size,
+                                 const uint8_t* info_mask, int32_t n_info, const int32_t* msg_src, int32_t K,
+                                 int32_t crc_poly_id, uint8_t* msg_out, uint8_t* crc_ok, uint8_t* cand_out,
+                                 double* cost_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

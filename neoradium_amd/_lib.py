@@ -73,6 +73,10 @@ SIGNATURES.update({
     'nrx_channel_matrix_sub_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp]),
     'nrx_svd_precoder_f64': (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_effective_channel_f64': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
+    'nrx_polar_encode': (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
+    'nrx_polar_rate_match': (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    'nrx_polar_rate_recover_f64': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    'nrx_polar_scl_decode_f64': (i32, [vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]),
 })
 
 _lib = None

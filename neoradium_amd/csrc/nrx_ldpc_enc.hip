@@ -5,30 +5,14 @@
 // kernel.  Bits are one uint8 per bit (the reference's int8 arrays).
 #include "gen_ldpc_bg.h"
 #include "nrx_common.h"
+#include "nrx_crc.h"
 
 namespace {
 
 constexpr int ZMAX = 384;
 
-// chancodebase.py:37-44 -- generator polynomials, MSB first incl. the leading one.
-__host__ __device__ inline uint32_t crc_poly(int id) {
-  switch (id) {
-    case NRX_CRC6: return 0x61u;
-    case NRX_CRC11: return 0xE21u;
-    case NRX_CRC16: return 0x11021u;
-    case NRX_CRC24A: return 0x1864CFBu;
-    case NRX_CRC24B: return 0x1800063u;
-    default: return 0x1B2B117u;  // 24C
-  }
-}
-__host__ __device__ inline int crc_len(int id) {
-  switch (id) {
-    case NRX_CRC6: return 6;
-    case NRX_CRC11: return 11;
-    case NRX_CRC16: return 16;
-    default: return 24;
-  }
-}
+using nrx::crc_len;
+using nrx::crc_poly;
 
 // (a * b) mod g over GF(2), degrees < L.
 __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t low, int L) {

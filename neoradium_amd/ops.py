@@ -538,3 +538,66 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens):
     check(lib().nrx_apply_td_paths_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen,
                                        hist, _host_i32(set_lens), ptr(y), stream()))
     return y
+
+
+# ----------------------------------------------------------------------------------------------------- polar
+def _i32(t, n, what):
+    if t is None:
+        return None
+    if t.dtype != torch.int32 or t.numel() != n:
+        raise ValueError(f"{what} must be int32 with {n} entries")
+    return t.contiguous()
+
+
+def polar_encode(cbs, N, msg_pos, in_il=None, pc_pos=None):
+    """polar.py:527-564 encode: (n_cw, K) bits -> (n_cw, N).  msg_pos/in_il/pc_pos: int32 device index tables."""
+    cbs = _u8(cbs)
+    n_cw, K = cbs.shape
+    n_pc = 0 if pc_pos is None else pc_pos.numel()
+    out = torch.empty((n_cw, N), dtype=torch.uint8, device=_dev(cbs))
+    check(lib().nrx_polar_encode(ptr(cbs), n_cw, K, N, ptr(_i32(in_il, K, 'in_il')), ptr(_i32(msg_pos, K, 'msg_pos')),
+                                 ptr(pc_pos), n_pc, ptr(out), stream()))
+    return out
+
+
+def polar_rate_match(coded, gather):
+    """polar.py:567-603 rateMatch as one gather: (n_cw, N) -> (n_cw, E)."""
+    coded = _u8(coded)
+    n_cw, N = coded.shape
+    E = gather.numel()
+    out = torch.empty((n_cw, E), dtype=torch.uint8, device=_dev(coded))
+    check(lib().nrx_polar_rate_match(ptr(coded), n_cw, N, E, ptr(_i32(gather, E, 'gather')), ptr(out), stream()))
+    return out
+
+
+def polar_rate_recover(llr, N, K, inv_subblock, deinterleave=None):
+    """polar.py:882-928 recoverRate: (n_cw, E) float64 LLRs -> (n_cw, N)."""
+    if llr.dtype != torch.float64:
+        raise ValueError("polar LLRs are float64")
+    llr = llr.contiguous()
+    n_cw, E = llr.shape
+    out = torch.empty((n_cw, N), dtype=torch.float64, device=_dev(llr))
+    check(lib().nrx_polar_rate_recover_f64(ptr(llr), n_cw, N, E, K, ptr(_i32(deinterleave, E, 'deinterleave')),
+                                           ptr(_i32(inv_subblock, N, 'inv_subblock')), ptr(out), stream()))
+    return out
+
+
+def polar_scl_decode(llr, info_mask, n_info, msg_src, list_size=8, crc_poly=None, want_candidates=False):
+    """polar.py:606-720 + :931-982: (n_cw, N) float64 -> msg (n_cw, K), crc_ok (n_cw,) [, cands (n_cw,L,K), costs]."""
+    if llr.dtype != torch.float64:
+        raise ValueError("polar LLRs are float64")
+    llr = llr.contiguous()
+    n_cw, N = llr.shape
+    if info_mask.dtype != torch.uint8 or info_mask.numel() != N:
+        raise ValueError(f"info_mask must be uint8 with N={N} entries")
+    K = msg_src.numel()
+    dev = _dev(llr)
+    msg = torch.empty((n_cw, K), dtype=torch.uint8, device=dev)
+    ok = torch.empty((n_cw,), dtype=torch.uint8, device=dev)
+    cands = torch.empty((n_cw, list_size, K), dtype=torch.uint8, device=dev) if want_candidates else None
+    costs = torch.empty((n_cw, list_size), dtype=torch.float64, device=dev) if want_candidates else None
+    crc_id = -1 if crc_poly is None else CRC_ID[crc_poly]
+    check(lib().nrx_polar_scl_decode_f64(ptr(llr), n_cw, N, int(list_size), ptr(info_mask.contiguous()), int(n_info),
+                                         ptr(_i32(msg_src, K, 'msg_src')), K, crc_id, ptr(msg), ptr(ok), ptr(cands),
+                                         ptr(costs), stream()))
+    return (msg, ok, cands, costs) if want_candidates else (msg, ok)

@@ -10,6 +10,7 @@ Outputs (all data: inputs + the reference's outputs, nothing of its source):
   tests/golden/phy.npz           gold sequence, constellations, LLRs, equaliser, OFDM, FIR bank, LS estimate
   tests/golden/host.npz          Carrier / PDSCH / DMRS index + pilot tables, TBS values, SnrScheduler walks
   tests/golden/channels.npz      CDL / TDL per-slot gains + coefficient matrices for seeded channels
+  tests/golden/polar.npz         polar DCI/PBCH/UCI chains: bits, LLRs, SCL candidate lists and path costs
   tests/golden/e2e_*.npz         whole PDSCH slots (inputs: seed-derived bits/noise; outputs: LLRs, bits, CRC)
 """
 import os
@@ -292,6 +293,46 @@ def snr_walks():
     np.savez_compressed(os.path.join(GOLD, 'snr_walks.npz'), **out)
 
 
+def polar():
+    """Polar DCI / PBCH / UCI chains (BASELINE cfg4).  Per case: payload, segmented blocks, coded and rate-matched
+    bits, noisy LLRs, rate-recovered LLRs, the decoder's output and the SCL list (message bits + path costs)."""
+    from neoradium.polar import PolarEncoder, PolarDecoder, SclDecoder
+    rng = np.random.default_rng(2024)
+    cases = [('dci', 30, 120), ('dci', 40, 216), ('dci', 60, 432), ('dci', 100, 200), ('dci', 12, 108),
+             ('dci', 70, 108), ('dci', 140, 432), ('pbch', 32, 432), ('uci', 12, 60), ('uci', 19, 100),
+             ('uci', 20, 80), ('uci', 64, 150), ('uci', 200, 600), ('uci', 400, 1200), ('uci', 401, 1300)]
+    out = {'cases': np.array(['%s,%d,%d' % c for c in cases])}
+    for ci, (typ, A, E) in enumerate(cases):
+        enc, dec = PolarEncoder(A, E, typ), PolarDecoder(A, E, typ, sclListSize=8)
+        tb = rng.integers(0, 2, A).astype(np.int8)
+        cbs = enc.doSegmentation(tb)
+        coded = enc.encode(cbs)
+        rm = enc.rateMatch(coded)
+        p = f'c{ci}_'
+        out.update({p + 'tb': tb, p + 'cbs': cbs, p + 'coded': coded, p + 'rm': rm,
+                    p + 'params': np.int64([enc.codeBlockSize, enc.polarCodeSize, enc.rateMatchedBlockLen, enc.nPC]),
+                    p + 'msgBits': np.int32(enc.msgBits), p + 'frozenBits': np.int32(enc.frozenBits),
+                    p + 'pcBits': np.int32(enc.pcBits)})
+        for si, snr in enumerate((-1.0, 3.0)):
+            sig = 10 ** (-snr / 20)
+            llr = 2 * (1 - 2.0 * rm + sig * rng.standard_normal(rm.shape)) / sig ** 2
+            rr = dec.recoverRate(llr)
+            bits, nerr = dec.decode(rr)
+            q = p + f's{si}_'
+            out.update({q + 'llr': llr, q + 'rr': rr, q + 'bits': bits, q + 'nerr': np.int64(nerr)})
+            cands, costs = [], []
+            for row in np.clip(rr, -20, 20):
+                sd = SclDecoder(dec.frozenBits, 8)
+                u = sd.decode(row)
+                m = u[:, dec.msgBits]
+                if dec.iIL:
+                    m = m[:, dec.inInterleaveIndexes]
+                cands.append(m)
+                costs.append(sd.pathCosts.copy())
+            out.update({q + 'cands': np.int8(cands), q + 'costs': np.float64(costs)})
+    np.savez_compressed(os.path.join(GOLD, 'polar.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     copy_matlab()
@@ -301,5 +342,6 @@ if __name__ == '__main__':
     channels()
     snr_walks()
     harq_loop()
+    polar()
     e2e()
     print('fixtures written to', GOLD)
