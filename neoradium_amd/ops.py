@@ -541,7 +541,7 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens):
 
 
 # ----------------------------------------------------------------------------------------------------- polar
-def _i32(t, n, what):
+def _idx32(t, n, what):
     if t is None:
         return None
     if t.dtype != torch.int32 or t.numel() != n:
@@ -555,7 +555,7 @@ def polar_encode(cbs, N, msg_pos, in_il=None, pc_pos=None):
     n_cw, K = cbs.shape
     n_pc = 0 if pc_pos is None else pc_pos.numel()
     out = torch.empty((n_cw, N), dtype=torch.uint8, device=_dev(cbs))
-    check(lib().nrx_polar_encode(ptr(cbs), n_cw, K, N, ptr(_i32(in_il, K, 'in_il')), ptr(_i32(msg_pos, K, 'msg_pos')),
+    check(lib().nrx_polar_encode(ptr(cbs), n_cw, K, N, ptr(_idx32(in_il, K, 'in_il')), ptr(_idx32(msg_pos, K, 'msg_pos')),
                                  ptr(pc_pos), n_pc, ptr(out), stream()))
     return out
 
@@ -566,7 +566,7 @@ def polar_rate_match(coded, gather):
     n_cw, N = coded.shape
     E = gather.numel()
     out = torch.empty((n_cw, E), dtype=torch.uint8, device=_dev(coded))
-    check(lib().nrx_polar_rate_match(ptr(coded), n_cw, N, E, ptr(_i32(gather, E, 'gather')), ptr(out), stream()))
+    check(lib().nrx_polar_rate_match(ptr(coded), n_cw, N, E, ptr(_idx32(gather, E, 'gather')), ptr(out), stream()))
     return out
 
 
@@ -577,8 +577,8 @@ def polar_rate_recover(llr, N, K, inv_subblock, deinterleave=None):
     llr = llr.contiguous()
     n_cw, E = llr.shape
     out = torch.empty((n_cw, N), dtype=torch.float64, device=_dev(llr))
-    check(lib().nrx_polar_rate_recover_f64(ptr(llr), n_cw, N, E, K, ptr(_i32(deinterleave, E, 'deinterleave')),
-                                           ptr(_i32(inv_subblock, N, 'inv_subblock')), ptr(out), stream()))
+    check(lib().nrx_polar_rate_recover_f64(ptr(llr), n_cw, N, E, K, ptr(_idx32(deinterleave, E, 'deinterleave')),
+                                           ptr(_idx32(inv_subblock, N, 'inv_subblock')), ptr(out), stream()))
     return out
 
 
@@ -598,6 +598,6 @@ def polar_scl_decode(llr, info_mask, n_info, msg_src, list_size=8, crc_poly=None
     costs = torch.empty((n_cw, list_size), dtype=torch.float64, device=dev) if want_candidates else None
     crc_id = -1 if crc_poly is None else CRC_ID[crc_poly]
     check(lib().nrx_polar_scl_decode_f64(ptr(llr), n_cw, N, int(list_size), ptr(info_mask.contiguous()), int(n_info),
-                                         ptr(_i32(msg_src, K, 'msg_src')), K, crc_id, ptr(msg), ptr(ok), ptr(cands),
+                                         ptr(_idx32(msg_src, K, 'msg_src')), K, crc_id, ptr(msg), ptr(ok), ptr(cands),
                                          ptr(costs), stream()))
     return (msg, ok, cands, costs) if want_candidates else (msg, ok)

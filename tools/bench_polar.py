@@ -31,7 +31,6 @@ def main():
     from neoradium_amd import ops
     dev = torch.device('cuda:0')
     enc, dec = PolarEncoder(a.A, a.E, 'dci'), PolarDecoder(a.A, a.E, 'dci', sclListSize=a.L)
-    tb = ops.random_bits((a.n, a.A), seed=1, device=dev) if hasattr(ops, 'random_bits') else None
     rng = np.random.default_rng(0)
     tbn = rng.integers(0, 2, (a.n, a.A)).astype(np.uint8)
     tb = torch.from_numpy(tbn).to(dev)
