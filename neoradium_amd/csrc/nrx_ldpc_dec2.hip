@@ -161,8 +161,11 @@ typedef const int32_t __attribute__((address_space(4))) * ctab_t;
 
 // ZI >= 0: specialised for lifting size kZ.z[ZI] (every rotation a compile-time immediate, columns stored twice
 // back to back so that reads at lane+delta never wrap: zero address arithmetic per edge).  ZI < 0: any Zc.
-template <int BG, int ZI>
-__global__ void __launch_bounds__(ZMAX, 3)
+// NS = code blocks per workgroup.  A 5- or 6-wave workgroup lands 2,2,1,1 on the four SIMDs and, at 168 VGPRs
+// (3 waves per SIMD), the hardware never co-schedules a second one (measured: tools/ubench/occ_test.hip), so a CU
+// would run 1.5 waves per SIMD.  Two code blocks side by side in one 10-/12-wave workgroup fill 3 waves per SIMD.
+template <int BG, int ZI, int NS>
+__global__ void __launch_bounds__(ZMAX * NS, 3)
 ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_iter, uint8_t* __restrict__ hard,
                      ctab_t tab0, ctab_t tab1, ctab_t rho4) {
   static_assert(ext_shifts_are_zero<BG>(), "extension columns are expected to be unshifted");
@@ -173,10 +176,14 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
   constexpr int CSTR = SPEC ? 2 * ZC : ZMAX;              // column stride in floats
   // Core-column posteriors, column c rotated by its last layer's shift.  Static allocation: the LDS base is a
   // compile-time constant, so column offsets (and, when SPEC, the rotations) fold into the DS immediates.
-  __shared__ float P[B::CORE * CSTR];
+  __shared__ float P[NS * B::CORE * CSTR];
   const int zc = SPEC ? ZC : zc_rt;
-  const int z = threadIdx.x;
-  const bool active = z < zc;
+  // slot = which of the workgroup's NS code blocks this wave works on (wave-uniform: slots are whole waves)
+  const int tz = (int)blockDim.x / NS;
+  const int slot = NS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / tz);
+  const int z = (int)threadIdx.x - slot * tz;
+  const uint32_t sb = (uint32_t)slot * (uint32_t)(B::CORE * CSTR * 4);   // byte offset of the slot's columns
+  float* const Ps = P + slot * (B::CORE * CSTR);
   const uint32_t zc4 = 4u * (uint32_t)zc;
   const int N = (B::COLS - 2) * zc, K = B::KB * zc;
   constexpr int PFN = pfn<BG>();
@@ -187,8 +194,10 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
   uint32_t sgn[(Y::n_narrow() + 1) / 2];  // two 16-bit fields per word
 
-  for (int cb = blockIdx.x; cb < n_cb; cb += gridDim.x) {
-    const float* in = llr + (size_t)cb * N;
+  for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
+    const int cb = cb0 + slot;
+    const bool active = z < zc && cb < n_cb;
+    const float* in = llr + (size_t)(cb < n_cb ? cb : 0) * N;
     if (active) {
       static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
@@ -197,10 +206,10 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           // stored pre-rotated by the column's end-of-iteration rotation, so iteration 0 uses the steady-state deltas
           constexpr uint32_t r4 = (uint32_t)ctab_rho4<BG>(SPEC ? ZI : 0, c);
           const float v = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + (int)(wrap4(4u * (uint32_t)z + r4, zc4) >> 2)]) + 0.0f;
-          P[c * CSTR + z] = v;
-          P[c * CSTR + ZC + z] = v;
+          Ps[c * CSTR + z] = v;
+          Ps[c * CSTR + ZC + z] = v;
         } else {
-          P[c * CSTR + z] = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + z]) + 0.0f;
+          Ps[c * CSTR + z] = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + z]) + 0.0f;
         }
       });
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
@@ -240,7 +249,8 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         uint32_t z4 = 4u * (uint32_t)z;
         ctab_t d4 = tab_it;
         asm volatile("" : "+v"(z4), "+s"(d4));
-        uint32_t z4hi = z4 + HI;
+        uint32_t z4s = z4 + sb;                                 // lane's byte address inside its slot's columns
+        uint32_t z4hi = z4s + HI;
         if constexpr (SPEC) asm volatile("" : "+v"(z4hi));
         if (active) {
           // ---- pass 1a: issue every LDS read of the layer
@@ -250,11 +260,11 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             constexpr int col = B::col(E0 + j);
             if constexpr (SPEC) {
               constexpr uint32_t off = (uint32_t)(col * CSTR * 4 + ctab_d4<BG>(SPEC ? ZI : 0, 1, E0 + j));
-              if constexpr (off < 65536) t[j] = *(const float*)((const char*)P + z4 + off);
+              if constexpr (off < 65536) t[j] = *(const float*)((const char*)P + z4s + off);
               else t[j] = *(const float*)((const char*)P + z4hi + (off - HI));
             } else {
               const uint32_t a = wrap4(z4 + (uint32_t)d4[E0 + j], zc4);
-              t[j] = *(const float*)((const char*)P + col * CSTR * 4 + a);
+              t[j] = *(const float*)((const char*)Ps + col * CSTR * 4 + a);
             }
           });
           __builtin_amdgcn_sched_barrier(0);
@@ -321,11 +331,11 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
               const float r = t[j] + sign_from(sx, mag);
               if constexpr (SPEC) {
                 constexpr uint32_t off = (uint32_t)(col * CSTR * 4);
-                float* w = (float*)((char*)P + (off < 49152 ? z4 : z4hi) + (off < 49152 ? off : off - HI));
+                float* w = (float*)((char*)P + (off < 49152 ? z4s : z4hi) + (off < 49152 ? off : off - HI));
                 w[0] = r;
                 w[ZC] = r;                                    // second copy (reads at lane+delta never wrap)
               } else {
-                *(float*)((char*)P + col * CSTR * 4 + z4) = r;
+                *(float*)((char*)Ps + col * CSTR * 4 + z4) = r;
               }
             }
           });
@@ -348,7 +358,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         constexpr int c = decltype(cc)::value;
         const uint32_t r4 = SPEC ? (uint32_t)ctab_rho4<BG>(SPEC ? ZI : 0, c) : (uint32_t)rho4[c];
         const uint32_t e4 = wrap4(4u * (uint32_t)z + r4, zc4);
-        hard[(size_t)cb * K + c * zc + (e4 >> 2)] = P[c * CSTR + z] < 0.0f ? 1 : 0;
+        hard[(size_t)cb * K + c * zc + (e4 >> 2)] = Ps[c * CSTR + z] < 0.0f ? 1 : 0;
       });
     }
     __syncthreads();
@@ -375,8 +385,11 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   using namespace nrx_dec2;
   const int zi = zindex(cfg->Zc, cfg->iLS);
   NRX_REQUIRE(zi >= 0, NRX_E_ARG, "nrx_ldpc_decode: (Zc=%d, iLS=%d) is not a lifting size", cfg->Zc, cfg->iLS);
-  const int threads = ((cfg->Zc + 63) / 64) * 64;
-  const int grid = n_cb < 1024 ? n_cb : 1024;
+  const int tz = ((cfg->Zc + 63) / 64) * 64;     // threads per code block (whole waves)
+  const int ns = tz >= 320 ? 2 : 1;              // 5-/6-wave code blocks go two to a workgroup (see the kernel)
+  const int threads = tz * ns;
+  const int n_wg = (n_cb + ns - 1) / ns;
+  const int grid = n_wg < 1024 ? n_wg : 1024;
   // device address of the per-(BG) constant table (resolved once per process and device)
   static const FastTab* base[2] = {nullptr, nullptr};
   const int bi = cfg->bg - 1;
@@ -390,19 +403,21 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   const int32_t* t1 = &base[bi]->d4[zi][1][0];
   const int32_t* rh = &base[bi]->rho4[zi][0];
   static const bool no_spec = getenv("NRX_LDPC_NOSPEC") != nullptr;
-#define NRX_DEC2_LAUNCH(BGN, ZIV)                                                                                    \
-  hipLaunchKernelGGL((ldpc_dec_fast_kernel<BGN, ZIV>), dim3(grid), dim3(threads), 0, st, llr, n_cb, cfg->Zc, n_iter, hard, \
-                     (ctab_t)t0, (ctab_t)t1, (ctab_t)rh)
+#define NRX_DEC2_LAUNCH(BGN, ZIV, NSV)                                                                               \
+  hipLaunchKernelGGL((ldpc_dec_fast_kernel<BGN, ZIV, NSV>), dim3(grid), dim3(threads), 0, st, llr, n_cb, cfg->Zc, n_iter, \
+                     hard, (ctab_t)t0, (ctab_t)t1, (ctab_t)rh)
   // lifting sizes with a specialised instantiation (the sizes of the BASELINE configurations); everything else
   // runs the generic kernel
   constexpr int ZI384 = zindex_c(384), ZI352 = zindex_c(352), ZI256 = zindex_c(256);
   if (cfg->bg == 1) {
-    if (!no_spec && zi == ZI384) NRX_DEC2_LAUNCH(1, ZI384);
-    else if (!no_spec && zi == ZI352) NRX_DEC2_LAUNCH(1, ZI352);
-    else NRX_DEC2_LAUNCH(1, -1);
+    if (!no_spec && zi == ZI384) NRX_DEC2_LAUNCH(1, ZI384, 2);
+    else if (!no_spec && zi == ZI352) NRX_DEC2_LAUNCH(1, ZI352, 2);
+    else if (ns == 2) NRX_DEC2_LAUNCH(1, -1, 2);
+    else NRX_DEC2_LAUNCH(1, -1, 1);
   } else {
-    if (!no_spec && zi == ZI256) NRX_DEC2_LAUNCH(2, ZI256);
-    else NRX_DEC2_LAUNCH(2, -1);
+    if (!no_spec && zi == ZI256) NRX_DEC2_LAUNCH(2, ZI256, 1);
+    else if (ns == 2) NRX_DEC2_LAUNCH(2, -1, 2);
+    else NRX_DEC2_LAUNCH(2, -1, 1);
   }
 #undef NRX_DEC2_LAUNCH
   NRX_CHECK_LAUNCH("nrx_ldpc_decode_f32(fast)");
