@@ -160,7 +160,7 @@ def main():
                                    "TBS 606504 (72 CB, Zc 384), time-domain channel, DMRS-LS + MMSE, 50-iteration min-sum",
                        "slots_per_step_per_gpu": B, "snr_db": args.snr, "sharding": "slot ranges per rank, 1 all-reduce"},
             "bler": {"block_errors": int(c[0]), "blocks": int(c[1]), "bit_errors": int(c[2]), "bits": int(c[3])},
-            "roofline": {"bound": "hbm", "kernel": "ldpc_dec_kernel<%s,BG1>" % ("float" if args.decoder == "f32" else "double"),
+            "roofline": {"bound": "hbm", "kernel": ("ldpc_dec_fast_kernel<1,Zc384,2>" if args.decoder == "f32" else "ldpc_dec_kernel<double,1,true>"),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": dec_ms, "launch_share_of_step": dec_ms / (dt / K * 1e3),
                          "note": "decoder re-uses its LDS/VGPR-resident working set 50x: it is VALU/LDS-issue bound, "
