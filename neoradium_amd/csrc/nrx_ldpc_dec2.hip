@@ -268,25 +268,33 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             }
           });
           __builtin_amdgcn_sched_barrier(0);
-          // ---- old state
+          // ---- old state.  Sign/argmin word of the layer: sign of edge j at bit j of its field, argmin above.
           const float om1 = m1[L], om2 = m2[L];
           uint32_t word, oidx;
-          int sh0;  // left shift that brings edge 0's sign bit to bit 31
+          int top;   // left shift that brings bit 0 of the field to bit 31
           if constexpr (WIDE) {
             word = sgw[Y::wide_idx(L)];
             oidx = word >> 24;
-            sh0 = 32 - D;
+            top = 31;
           } else {
             constexpr int ni = Y::narrow_idx(L);
             word = sgn[ni / 2];
             oidx = (ni & 1) ? (word >> 28) : ((word >> 12) & 15u);
-            sh0 = (ni & 1) ? (16 - D) : (32 - D);
+            top = (ni & 1) ? 15 : 31;
           }
-          // ---- pass 1b: t_j = r_j - msg_old_j
+          asm volatile("" : "+v"(oidx));   // keep it a plain VGPR compare (no SDWA byte-select + constant moves)
+          // ---- pass 1b: t_j = r_j - msg_old_j.  All "was edge j the minimum" tests first, into SGPR pairs: a VALU
+          // write of VCC/SGPR needs two wait states before a v_cndmask may read it, batching avoids the s_nops.
+          bool was_min[DC > 0 ? DC : 1];
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            const float mag = (oidx == (uint32_t)j) ? om2 : om1;
-            t[j] = t[j] - sign_from(word << (sh0 + j), mag);
+            was_min[j] = oidx == (uint32_t)j;
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<DC>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const float mag = was_min[j] ? om2 : om1;
+            t[j] = t[j] - sign_from(word << (top - j), mag);
           });
           if constexpr (EXT) {
             constexpr int slot = Y::ext_idx(L) % PFN;
@@ -294,24 +302,23 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             constexpr int Ln = Y::next_ext(L, PFN);
             epf[slot] = ext_load(Ln, z4);
           }
-          // ---- min-sum
+          // ---- min-sum: two smallest magnitudes and the sign parity; no compares, no argmin here
           float a1 = __builtin_fabsf(t[0]), a2 = 3.0e38f;
-          uint32_t idx = 0, px = __float_as_uint(t[0]);
+          uint32_t px = __float_as_uint(t[0]);
           static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value + 1;
             const float a = __builtin_fabsf(t[j]);
-            a2 = __builtin_amdgcn_fmed3f(a1, a2, a);                 // second minimum so far
-            idx = a < a1 ? (uint32_t)j : idx;                        // strict: ties keep the first index
-            a1 = a < a1 ? a : a1;
+            a2 = __builtin_amdgcn_fmed3f(a1, a2, a);                       // second minimum so far
+            a1 = __builtin_amdgcn_fmed3f(a1, a, -__builtin_inff());        // min(a1, a) without a canonicalising max
             px ^= __float_as_uint(t[j]);
           });
           // QUIRK ldpc.py:1563 (second minimum taken after adding +100000 to the signed argmin entry): it can
           // only bite when every other entry exceeds ~5e4 (filler / saturated LLRs) -- wave-uniform cold path.
           if (__builtin_amdgcn_ballot_w64(a2 > 5.0e4f) != 0) {
-            float v = t[0];
+            float v = t[D - 1];
             static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
-              constexpr int j = decltype(jc)::value + 1;
-              v = idx == (uint32_t)j ? t[j] : v;
+              constexpr int j = D - 2 - decltype(jc)::value;
+              v = __builtin_fabsf(t[j]) == a1 ? t[j] : v;     // ends at the first index holding the minimum
             });
             const float q = __builtin_fabsf(v + 100000.0f);
             a2 = (a2 > 5.0e4f && q < a2) ? q : a2;
@@ -319,15 +326,24 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           const float nm1 = a1 * 0.75f, nm2 = a2 * 0.75f;
           m1[L] = nm1;
           m2[L] = nm2;
-          // ---- pass 2: r_j = t_j + msg_new_j, written at the lane's own index (column now rotated by this shift)
-          uint32_t nsg = 0;
+          // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written at the lane's own index (the column is now
+          // rotated by this layer's shift).  The minimum's position falls out of the magnitude test: an entry equal
+          // to min1 gets min2 (with ties min2 == min1, so every tied entry may take it); first such index = argmin.
+          bool is_min[D];
           static_for<D>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
+            is_min[j] = __builtin_fabsf(t[j]) == a1;
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          uint32_t nsg = 0, idx = 0;
+          static_for<D>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = D - 1 - decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
             const uint32_t sx = px ^ __float_as_uint(t[j]);   // bit 31 = parity ^ sign(t_j)
-            nsg = __builtin_amdgcn_alignbit(nsg, sx, 31);     // (nsg << 1) | (sx >> 31)
+            nsg = __builtin_amdgcn_alignbit(nsg, sx, 31);     // (nsg << 1) | (sx >> 31): edge j ends at bit j
+            idx = is_min[j] ? (uint32_t)j : idx;
             if constexpr (col < B::CORE) {
-              const float mag = (idx == (uint32_t)j) ? nm2 : nm1;
+              const float mag = is_min[j] ? nm2 : nm1;
               const float r = t[j] + sign_from(sx, mag);
               if constexpr (SPEC) {
                 constexpr uint32_t off = (uint32_t)(col * CSTR * 4);
