@@ -137,6 +137,44 @@ template <int BG> struct Lay {  // compile-time layer facts
   static constexpr int ext_idx(int L) { int n = 0; for (int l = 0; l < L; ++l) n += has_ext(l) ? 1 : 0; return n; }
   static constexpr int n_ext() { return ext_idx(B::ROWS); }
   static constexpr int first_ext() { for (int l = 0; l < B::ROWS; ++l) if (has_ext(l)) return l; return -1; }
+  // Core columns of layer L as a bit mask (every column of a layer is both read and written by it).
+  static constexpr uint32_t core_mask(int L) {
+    uint32_t m = 0;
+    for (int e = B::row_start(L); e < B::row_start(L + 1); ++e)
+      if (B::col(e) < B::CORE) m |= 1u << B::col(e);
+    return m;
+  }
+  // A workgroup barrier is needed before layer L only if L touches a column that some layer since the previous
+  // barrier touched.  Most extension rows of both base graphs meet their neighbour in no core column at all, so
+  // about a third of the barriers go (BG1: 32 of 46 remain).  Steady-state placement, computed over the cyclic
+  // layer order; `barriers_ok` re-checks it from a cold start.
+  struct BarPlan { bool need[B::ROWS]; bool ok; int count; };
+  static constexpr BarPlan make_plan() {
+    BarPlan p{};
+    uint32_t mask[B::ROWS] = {};
+    for (int l = 0; l < B::ROWS; ++l) mask[l] = core_mask(l);
+    uint32_t touched = 0;
+    for (int it = 0; it < 3; ++it)
+      for (int l = 0; l < B::ROWS; ++l) {
+        const bool need = (mask[l] & touched) != 0;
+        touched = need ? mask[l] : (touched | mask[l]);
+        if (it == 2) p.need[l] = need;
+      }
+    p.ok = true;
+    p.count = 0;
+    touched = 0;   // cold start: the initial fill is followed by a barrier
+    for (int it = 0; it < 3; ++it)
+      for (int l = 0; l < B::ROWS; ++l) {
+        if (p.need[l]) touched = 0;
+        if (mask[l] & touched) p.ok = false;
+        touched |= mask[l];
+      }
+    for (int l = 0; l < B::ROWS; ++l) p.count += p.need[l] ? 1 : 0;
+    return p;
+  }
+  static constexpr BarPlan plan = make_plan();
+  static constexpr bool barrier_before(int L) { return plan.need[L]; }
+  static constexpr bool barriers_ok() { return plan.ok; }
   // the k-th layer (cyclically) with an extension column after layer L
   static constexpr int next_ext(int L, int k) {
     int l = L;
@@ -188,6 +226,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
   const int N = (B::COLS - 2) * zc, K = B::KB * zc;
   constexpr int PFN = pfn<BG>();
   static_assert(Y::n_ext() % PFN == 0, "prefetch ring must divide the number of extension layers");
+  static_assert(Y::barriers_ok(), "barrier placement leaves a column hazard");
   constexpr uint32_t HI = 49152;                          // second DS base: immediates are 16 bit
 
   float m1[B::ROWS], m2[B::ROWS];
@@ -252,9 +291,13 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         uint32_t z4s = z4 + sb;                                 // lane's byte address inside its slot's columns
         uint32_t z4hi = z4s + HI;
         if constexpr (SPEC) asm volatile("" : "+v"(z4hi));
+        float t[D];
+        bool was_min[DC > 0 ? DC : 1];
+        float om1 = 0.0f, om2 = 0.0f;
+        uint32_t word = 0;
+        int top = 31;   // left shift that brings bit 0 of the layer's sign field to bit 31
         if (active) {
           // ---- pass 1a: issue every LDS read of the layer
-          float t[D];
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
@@ -269,9 +312,9 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           });
           __builtin_amdgcn_sched_barrier(0);
           // ---- old state.  Sign/argmin word of the layer: sign of edge j at bit j of its field, argmin above.
-          const float om1 = m1[L], om2 = m2[L];
-          uint32_t word, oidx;
-          int top;   // left shift that brings bit 0 of the field to bit 31
+          om1 = m1[L];
+          om2 = m2[L];
+          uint32_t oidx;
           if constexpr (WIDE) {
             word = sgw[Y::wide_idx(L)];
             oidx = word >> 24;
@@ -283,14 +326,19 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             top = (ni & 1) ? 15 : 31;
           }
           asm volatile("" : "+v"(oidx));   // keep it a plain VGPR compare (no SDWA byte-select + constant moves)
-          // ---- pass 1b: t_j = r_j - msg_old_j.  All "was edge j the minimum" tests first, into SGPR pairs: a VALU
-          // write of VCC/SGPR needs two wait states before a v_cndmask may read it, batching avoids the s_nops.
-          bool was_min[DC > 0 ? DC : 1];
+          // All "was edge j the minimum" tests first, into SGPR pairs: a VALU write of VCC/SGPR needs two wait
+          // states before a v_cndmask may read it, batching avoids the s_nops (and fills the LDS latency).
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             was_min[j] = oidx == (uint32_t)j;
           });
-          __builtin_amdgcn_sched_barrier(0);
+        }
+        // READ -> WRITE barrier.  Columns are stored rotated: a lane writes its own index but reads lane + delta, i.e.
+        // elements other waves are about to overwrite in this very layer.  Every wave's reads of the layer must have
+        // returned before any wave writes.  (It sits where the wave would wait for its LDS data anyway.)
+        __syncthreads();
+        if (active) {
+          // ---- pass 1b: t_j = r_j - msg_old_j
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             const float mag = was_min[j] ? om2 : om1;
@@ -364,9 +412,12 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             else sgn[ni / 2] = (word & 0xffff0000u) | f;
           }
         }
-        __syncthreads();
+        // WRITE -> READ barrier only where the next layer reads a column this one wrote; a later layer is already
+        // separated from this one's writes by the read->write barrier in between.
+        if constexpr ((Y::core_mask(L) & Y::core_mask((L + 1) % B::ROWS)) != 0) __syncthreads();
       });
     }
+    __syncthreads();   // the last layers may have run without one
 
     // ---- hard decisions of the information columns, un-rotating each column (ldpc.py:1578-1581)
     if (active) {

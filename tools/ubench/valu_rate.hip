@@ -58,6 +58,22 @@ DEF_KERNEL(perm_b32, "v_perm_b32 %0,%0,%8,%9\n v_perm_b32 %1,%1,%8,%9\n v_perm_b
 DEF_KERNEL(sub_u32, "v_sub_u32 %0,%0,%8\n v_sub_u32 %1,%1,%8\n v_sub_u32 %2,%2,%8\n v_sub_u32 %3,%3,%8\n v_sub_u32 %4,%4,%8\n v_sub_u32 %5,%5,%8\n v_sub_u32 %6,%6,%8\n v_sub_u32 %7,%7,%8\n")
 DEF_KERNEL(min_u32, "v_min_u32 %0,%0,%8\n v_min_u32 %1,%1,%8\n v_min_u32 %2,%2,%8\n v_min_u32 %3,%3,%8\n v_min_u32 %4,%4,%8\n v_min_u32 %5,%5,%8\n v_min_u32 %6,%6,%8\n v_min_u32 %7,%7,%8\n")
 
+DEF_KERNEL(dep1_add_f32, "v_add_f32 %0,%0,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %0,%0,%8\n ")
+DEF_KERNEL(dep2_add_f32, "v_add_f32 %0,%0,%8\n v_add_f32 %1,%1,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %1,%1,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %1,%1,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %1,%1,%8\n ")
+DEF_KERNEL(dep4_add_f32, "v_add_f32 %0,%0,%8\n v_add_f32 %1,%1,%8\n v_add_f32 %2,%2,%8\n v_add_f32 %3,%3,%8\n v_add_f32 %0,%0,%8\n v_add_f32 %1,%1,%8\n v_add_f32 %2,%2,%8\n v_add_f32 %3,%3,%8\n ")
+DEF_KERNEL(dep1_med3_f32, "v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %0,%0,%8,%9\n ")
+DEF_KERNEL(dep2_med3_f32, "v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %1,%1,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %1,%1,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %1,%1,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %1,%1,%8,%9\n ")
+DEF_KERNEL(dep4_med3_f32, "v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %1,%1,%8,%9\n v_med3_f32 %2,%2,%8,%9\n v_med3_f32 %3,%3,%8,%9\n v_med3_f32 %0,%0,%8,%9\n v_med3_f32 %1,%1,%8,%9\n v_med3_f32 %2,%2,%8,%9\n v_med3_f32 %3,%3,%8,%9\n ")
+DEF_KERNEL(dep1_xor_b32, "v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n ")
+DEF_KERNEL(dep2_xor_b32, "v_xor_b32 %0,%0,%8\n v_xor_b32 %1,%1,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %1,%1,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %1,%1,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %1,%1,%8\n ")
+DEF_KERNEL(dep4_xor_b32, "v_xor_b32 %0,%0,%8\n v_xor_b32 %1,%1,%8\n v_xor_b32 %2,%2,%8\n v_xor_b32 %3,%3,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %1,%1,%8\n v_xor_b32 %2,%2,%8\n v_xor_b32 %3,%3,%8\n ")
+DEF_KERNEL(dep1_min_f32, "v_min_f32 %0,%0,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %0,%0,%8\n ")
+DEF_KERNEL(dep2_min_f32, "v_min_f32 %0,%0,%8\n v_min_f32 %1,%1,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %1,%1,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %1,%1,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %1,%1,%8\n ")
+DEF_KERNEL(dep4_min_f32, "v_min_f32 %0,%0,%8\n v_min_f32 %1,%1,%8\n v_min_f32 %2,%2,%8\n v_min_f32 %3,%3,%8\n v_min_f32 %0,%0,%8\n v_min_f32 %1,%1,%8\n v_min_f32 %2,%2,%8\n v_min_f32 %3,%3,%8\n ")
+DEF_KERNEL(dep1_and_or_b32, "v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n ")
+DEF_KERNEL(dep2_and_or_b32, "v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %1,%1,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %1,%1,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %1,%1,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %1,%1,%8,%9\n ")
+DEF_KERNEL(dep4_and_or_b32, "v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %1,%1,%8,%9\n v_and_or_b32 %2,%2,%8,%9\n v_and_or_b32 %3,%3,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %1,%1,%8,%9\n v_and_or_b32 %2,%2,%8,%9\n v_and_or_b32 %3,%3,%8,%9\n ")
+
 typedef void (*kern_t)(unsigned long long*, float*, int);
 struct Case { const char* name; kern_t k; int per_iter; };
 
@@ -79,6 +95,7 @@ int main(int argc, char** argv) {
       C(cmp_vcc, 32), C(cmp_sgpr, 32), C(cmp_cnd_pair, 32), C(cmp_cnd_sgpr_pair, 32), C(mov_b32, 32),
       C(pk_add_f16, 32), C(pk_min_f16, 32), C(pk_min_i16, 32), C(pk_sub_i16, 32), C(pk_mul_lo_u16, 32),
       C(pk_ashrrev_i16, 32), C(perm_b32, 32), C(sub_u32, 32), C(min_u32, 32),
+      C(dep1_add_f32, 32), C(dep2_add_f32, 32), C(dep4_add_f32, 32), C(dep1_med3_f32, 32), C(dep2_med3_f32, 32), C(dep4_med3_f32, 32), C(dep1_xor_b32, 32), C(dep2_xor_b32, 32), C(dep4_xor_b32, 32), C(dep1_min_f32, 32), C(dep2_min_f32, 32), C(dep4_min_f32, 32), C(dep1_and_or_b32, 32), C(dep2_and_or_b32, 32), C(dep4_and_or_b32, 32),
   };
   printf("%-20s %8s %8s %8s %8s   cycles per wave64 instruction per SIMD at W waves/SIMD\n", "op", "W=1", "W=2", "W=3", "W=4");
   for (auto& c : cases) {
