@@ -103,6 +103,27 @@ __constant__ FastTab kTab2 = kTabC2;
 template <int BG> constexpr int ctab_d4(int zi, int cls, int e) { return BG == 1 ? kTabC1.d4[zi][cls][e] : kTabC2.d4[zi][cls][e]; }
 template <int BG> constexpr int ctab_rho4(int zi, int c) { return BG == 1 ? kTabC1.rho4[zi][c] : kTabC2.rho4[zi][c]; }
 
+// Wrap masks of the specialised kernels: m[w][e] = lanes of wave w (of a code block) whose read of edge e, element
+// (z + delta_e), runs past the end of the column and wraps to (z + delta_e - Zc).  Wave-uniform 64-bit values: the
+// kernel fetches a layer's masks with one scalar load and uses them directly as v_cndmask selectors.
+struct WrapTab {
+  uint64_t m[ZMAX / 64][ESTRIDE];
+};
+template <int BG, int ZI> constexpr WrapTab make_wrap() {
+  WrapTab t{};
+  const int zc = kZ.z[ZI];
+  for (int w = 0; w < ZMAX / 64; ++w)
+    for (int e = 0; e < G<BG>::EDGES; ++e) {
+      const int d = ctab_d4<BG>(ZI, 1, e) / 4;
+      uint64_t m = 0;
+      for (int l = 0; l < 64; ++l)
+        if (64 * w + l + d >= zc) m |= 1ull << l;
+      t.m[w][e] = m;
+    }
+  return t;
+}
+typedef const uint64_t __attribute__((address_space(4))) * mtab_t;
+
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
@@ -148,14 +169,33 @@ template <int BG> struct Lay {  // compile-time layer facts
   // barrier touched.  Most extension rows of both base graphs meet their neighbour in no core column at all, so
   // about a third of the barriers go (BG1: 32 of 46 remain).  Steady-state placement, computed over the cyclic
   // layer order; `barriers_ok` re-checks it from a cold start.
-  struct BarPlan { bool need[B::ROWS]; bool ok; int count; };
+  // Ping-pong buffers: the k-th layer of an iteration that touches column c reads buffer (k & 1) and writes the other.
+  static constexpr int touch_par(int L, int c) {
+    int k = 0;
+    for (int l = 0; l < L; ++l) k += (core_mask(l) >> c) & 1u;
+    return k & 1;
+  }
+  // columns touched an odd number of times per iteration end up in buffer 1 and are copied back (step ROWS)
+  static constexpr uint32_t odd_mask() {
+    uint32_t m = 0;
+    for (int c = 0; c < B::CORE; ++c) m |= (uint32_t)touch_par(B::ROWS, c) << c;
+    return m;
+  }
+  static constexpr uint32_t step_mask(int s) { return s < B::ROWS ? core_mask(s) : odd_mask(); }
+  // A workgroup barrier goes before step s (layers 0..ROWS-1, then the copy-back) only if s touches a column that
+  // some step since the previous barrier touched: then both hazards between two touchers of a column (the later
+  // one reads what the earlier wrote, and overwrites what the earlier read) are closed, and inside a layer reads and
+  // writes hit different buffers.  Most extension rows meet their neighbours in no core column, so about a third of
+  // the barriers go (BG1: 33 of 47 steps).  Steady-state placement over the cyclic order, re-checked from a cold start.
+  static constexpr int STEPS = B::ROWS + 1;
+  struct BarPlan { bool need[B::ROWS + 1]; bool ok; int count; };
   static constexpr BarPlan make_plan() {
     BarPlan p{};
-    uint32_t mask[B::ROWS] = {};
-    for (int l = 0; l < B::ROWS; ++l) mask[l] = core_mask(l);
+    uint32_t mask[STEPS] = {};
+    for (int l = 0; l < STEPS; ++l) mask[l] = step_mask(l);
     uint32_t touched = 0;
     for (int it = 0; it < 3; ++it)
-      for (int l = 0; l < B::ROWS; ++l) {
+      for (int l = 0; l < STEPS; ++l) {
         const bool need = (mask[l] & touched) != 0;
         touched = need ? mask[l] : (touched | mask[l]);
         if (it == 2) p.need[l] = need;
@@ -164,16 +204,16 @@ template <int BG> struct Lay {  // compile-time layer facts
     p.count = 0;
     touched = 0;   // cold start: the initial fill is followed by a barrier
     for (int it = 0; it < 3; ++it)
-      for (int l = 0; l < B::ROWS; ++l) {
+      for (int l = 0; l < STEPS; ++l) {
         if (p.need[l]) touched = 0;
         if (mask[l] & touched) p.ok = false;
         touched |= mask[l];
       }
-    for (int l = 0; l < B::ROWS; ++l) p.count += p.need[l] ? 1 : 0;
+    for (int l = 0; l < STEPS; ++l) p.count += p.need[l] ? 1 : 0;
     return p;
   }
   static constexpr BarPlan plan = make_plan();
-  static constexpr bool barrier_before(int L) { return plan.need[L]; }
+  static constexpr bool barrier_before(int s) { return plan.need[s]; }
   static constexpr bool barriers_ok() { return plan.ok; }
   // the k-th layer (cyclically) with an extension column after layer L
   static constexpr int next_ext(int L, int k) {
@@ -197,37 +237,48 @@ template <int BG> constexpr bool ext_shifts_are_zero() {
 // pointers into the __constant__ tables, typed as constant address space so that loads are scalar (s_load)
 typedef const int32_t __attribute__((address_space(4))) * ctab_t;
 
-// ZI >= 0: specialised for lifting size kZ.z[ZI] (every rotation a compile-time immediate, columns stored twice
-// back to back so that reads at lane+delta never wrap: zero address arithmetic per edge).  ZI < 0: any Zc.
+// One workgroup = NS code blocks; lane z of a code block's waves = check row z of every layer.
+//
+// LDS holds the core-column posteriors, column c stored ROTATED by the shift of the last layer that wrote it: a layer
+// reads element (z + delta) mod Zc and writes element z, so no address survives from the read pass to the write pass.
+// Because reads cross lanes, every column has two buffers used in ping-pong (a layer reads one and writes the other):
+// inside a layer no wave can overwrite what another wave still has to read, and barriers are only needed between
+// layers that share a column (Lay::plan).
+// ZI >= 0: specialised for lifting size kZ.z[ZI]: every rotation is a compile-time DS immediate and the wrap-around
+// is one compare + select between two base registers.  ZI < 0: any Zc, rotations from the constant tables.
 // NS = code blocks per workgroup.  A 5- or 6-wave workgroup lands 2,2,1,1 on the four SIMDs and, at 168 VGPRs
 // (3 waves per SIMD), the hardware never co-schedules a second one (measured: tools/ubench/occ_test.hip), so a CU
 // would run 1.5 waves per SIMD.  Two code blocks side by side in one 10-/12-wave workgroup fill 3 waves per SIMD.
 template <int BG, int ZI, int NS>
 __global__ void __launch_bounds__(ZMAX * NS, 3)
 ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_iter, uint8_t* __restrict__ hard,
-                     ctab_t tab0, ctab_t tab1, ctab_t rho4) {
+                     ctab_t tab0, ctab_t tab1, ctab_t rho4, mtab_t wtab) {
   static_assert(ext_shifts_are_zero<BG>(), "extension columns are expected to be unshifted");
   using B = G<BG>;
   using Y = Lay<BG>;
   constexpr bool SPEC = ZI >= 0;
   constexpr int ZC = SPEC ? kZ.z[SPEC ? ZI : 0] : ZMAX;   // compile-time lifting size (SPEC)
-  constexpr int CSTR = SPEC ? 2 * ZC : ZMAX;              // column stride in floats
-  // Core-column posteriors, column c rotated by its last layer's shift.  Static allocation: the LDS base is a
-  // compile-time constant, so column offsets (and, when SPEC, the rotations) fold into the DS immediates.
-  __shared__ float P[NS * B::CORE * CSTR];
+  constexpr int ZS = (ZC + 63) / 64 * 64;                  // column stride in floats (whole waves, see `live`)
+  constexpr int BUF = B::CORE * ZS;                        // one buffer of one code block, floats
+  constexpr int SLOT = 2 * BUF;                            // both buffers
+  // Static allocation: the LDS base is a compile-time constant, so buffer/column offsets (and, when SPEC, the
+  // rotations) fold into the DS immediates.  ZS floats of padding in front keep "base - Zc" addresses non-negative.
+  __shared__ float Praw[ZS + NS * SLOT];
   const int zc = SPEC ? ZC : zc_rt;
   // slot = which of the workgroup's NS code blocks this wave works on (wave-uniform: slots are whole waves)
   const int tz = (int)blockDim.x / NS;
   const int slot = NS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / tz);
   const int z = (int)threadIdx.x - slot * tz;
-  const uint32_t sb = (uint32_t)slot * (uint32_t)(B::CORE * CSTR * 4);   // byte offset of the slot's columns
-  float* const Ps = P + slot * (B::CORE * CSTR);
+  const uint32_t sb = (uint32_t)(ZS + slot * SLOT) * 4u;   // byte offset of the slot's buffer 0 inside Praw
+  const mtab_t wm = wtab + __builtin_amdgcn_readfirstlane(z >> 6) * ESTRIDE;   // this wave's row of wrap masks
+  float* const Ps = Praw + ZS + slot * SLOT;
   const uint32_t zc4 = 4u * (uint32_t)zc;
   const int N = (B::COLS - 2) * zc, K = B::KB * zc;
   constexpr int PFN = pfn<BG>();
   static_assert(Y::n_ext() % PFN == 0, "prefetch ring must divide the number of extension layers");
   static_assert(Y::barriers_ok(), "barrier placement leaves a column hazard");
-  constexpr uint32_t HI = 49152;                          // second DS base: immediates are 16 bit
+  constexpr uint32_t HI = 49152;                           // second DS base: immediates are 16 bit
+  static_assert(SLOT * 4 - (int)HI + 4 * ZS < 65536, "DS immediates out of range");
 
   float m1[B::ROWS], m2[B::ROWS];
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
@@ -235,8 +286,12 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
 
   for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
     const int cb = cb0 + slot;
-    const bool active = z < zc && cb < n_cb;
-    const float* in = llr + (size_t)(cb < n_cb ? cb : 0) * N;
+    // live: wave-uniform, this wave's code block exists.  Inside the layer loop the lanes z >= Zc of a partial last
+    // wave simply run along: their LDS writes land in the padding of their own column (stride = whole waves), their
+    // reads are never used, their global reads are clamped.  That keeps the loop free of EXEC masking.
+    const bool live = cb < n_cb;
+    const bool active = z < zc && live;
+    const float* in = llr + (size_t)(live ? cb : 0) * N;
     if (active) {
       static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
@@ -244,11 +299,9 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         if constexpr (SPEC) {
           // stored pre-rotated by the column's end-of-iteration rotation, so iteration 0 uses the steady-state deltas
           constexpr uint32_t r4 = (uint32_t)ctab_rho4<BG>(SPEC ? ZI : 0, c);
-          const float v = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + (int)(wrap4(4u * (uint32_t)z + r4, zc4) >> 2)]) + 0.0f;
-          Ps[c * CSTR + z] = v;
-          Ps[c * CSTR + ZC + z] = v;
+          Ps[c * ZS + z] = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + (int)(wrap4(4u * (uint32_t)z + r4, zc4) >> 2)]) + 0.0f;
         } else {
-          Ps[c * CSTR + z] = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + z]) + 0.0f;
+          Ps[c * ZS + z] = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + z]) + 0.0f;
         }
       });
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
@@ -263,14 +316,25 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
     float epf[PFN];
     auto ext_load = [&](int L, uint32_t zb) __attribute__((always_inline)) -> float {
       // zb = 4*lane, opaque to the optimiser: keeps the 42 (loop-invariant) addresses from being hoisted
-      const char* col = (const char*)(in + (Y::ext_col(L) - 2) * zc);
-      return active ? __builtin_amdgcn_fmed3f(*(const float*)(col + zb), -1e10f, 1e10f) + 0.0f : 0.0f;
+      // (scalar base + 32-bit lane offset: no per-column 64-bit pointers to keep in SGPRs)
+      const uint32_t zq = (SPEC && ZC % 64 == 0) ? zb : (zb < zc4 ? zb : zc4 - 4u);   // partial last wave: stay inside
+      const uint32_t off = zq + (uint32_t)(Y::ext_col(L) - 2) * zc4;
+      return __builtin_amdgcn_fmed3f(*(const float*)((const char*)in + off), -1e10f, 1e10f) + 0.0f;
     };
     static_for<PFN>([&](auto k) __attribute__((always_inline)) {
       constexpr int Lk = Y::next_ext(Y::first_ext() == 0 ? B::ROWS - 1 : Y::first_ext() - 1, decltype(k)::value + 1);
       epf[decltype(k)::value] = ext_load(Lk, 4u * (uint32_t)z);
     });
     __syncthreads();
+
+    // wrap masks of the layer about to run (SGPR pairs), fetched one layer ahead
+    constexpr int WN = SPEC ? 19 : 1;
+    uint64_t wcur[WN];
+    if constexpr (SPEC) {
+      static_for<(Y::has_ext(0) ? Y::deg(0) - 1 : Y::deg(0))>([&](auto jc) __attribute__((always_inline)) {
+        wcur[decltype(jc)::value] = wm[B::row_start(0) + decltype(jc)::value];
+      });
+    }
 
     for (int it = 0; it < n_iter; ++it) {
       ctab_t tab_it = (SPEC || it != 0) ? tab1 : tab0;
@@ -287,34 +351,35 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         // opaque copies keep the (loop-invariant) address arithmetic and the scalar table loads inside the layer
         uint32_t z4 = 4u * (uint32_t)z;
         ctab_t d4 = tab_it;
-        asm volatile("" : "+v"(z4), "+s"(d4));
-        uint32_t z4s = z4 + sb;                                 // lane's byte address inside its slot's columns
-        uint32_t z4hi = z4s + HI;
-        if constexpr (SPEC) asm volatile("" : "+v"(z4hi));
-        float t[D];
-        bool was_min[DC > 0 ? DC : 1];
-        float om1 = 0.0f, om2 = 0.0f;
-        uint32_t word = 0;
-        int top = 31;   // left shift that brings bit 0 of the layer's sign field to bit 31
-        if (active) {
+        int wo = 0;   // opaque zero: keeps the layer's mask loads inside the layer (readfirstlane: provably uniform)
+        asm volatile("" : "+v"(z4), "+s"(d4), "+s"(wo));
+        const mtab_t wml = wm + __builtin_amdgcn_readfirstlane(wo);
+        // byte addresses of element z of column 0 / buffer 0 of this slot: plain, wrapped (- Zc), and both + HI
+        uint32_t zb = z4 + sb, zbw = zb - zc4, zbh = zb + HI, zbwh = zbw + HI;
+        if constexpr (SPEC) asm volatile("" : "+v"(zb), "+v"(zbw), "+v"(zbh), "+v"(zbwh));
+        if (live) {
           // ---- pass 1a: issue every LDS read of the layer
+          float t[D];
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
+            constexpr uint32_t cof = (uint32_t)((Y::touch_par(L, col) * B::CORE + col) * ZS * 4);   // read buffer
             if constexpr (SPEC) {
-              constexpr uint32_t off = (uint32_t)(col * CSTR * 4 + ctab_d4<BG>(SPEC ? ZI : 0, 1, E0 + j));
-              if constexpr (off < 65536) t[j] = *(const float*)((const char*)P + z4s + off);
-              else t[j] = *(const float*)((const char*)P + z4hi + (off - HI));
+              constexpr uint32_t dl4 = (uint32_t)ctab_d4<BG>(SPEC ? ZI : 0, 1, E0 + j);   // 4 * rotation
+              constexpr uint32_t off = cof + dl4;
+              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + delta >= Zc
+              if constexpr (off < 65536) t[j] = *(const float*)((const char*)Praw + (wraps ? zbw : zb) + off);
+              else t[j] = *(const float*)((const char*)Praw + (wraps ? zbwh : zbh) + (off - HI));
             } else {
               const uint32_t a = wrap4(z4 + (uint32_t)d4[E0 + j], zc4);
-              t[j] = *(const float*)((const char*)Ps + col * CSTR * 4 + a);
+              t[j] = *(const float*)((const char*)Ps + cof + a);
             }
           });
           __builtin_amdgcn_sched_barrier(0);
           // ---- old state.  Sign/argmin word of the layer: sign of edge j at bit j of its field, argmin above.
-          om1 = m1[L];
-          om2 = m2[L];
-          uint32_t oidx;
+          const float om1 = m1[L], om2 = m2[L];
+          uint32_t word, oidx;
+          int top;   // left shift that brings bit 0 of the field to bit 31
           if constexpr (WIDE) {
             word = sgw[Y::wide_idx(L)];
             oidx = word >> 24;
@@ -326,24 +391,30 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             top = (ni & 1) ? 15 : 31;
           }
           asm volatile("" : "+v"(oidx));   // keep it a plain VGPR compare (no SDWA byte-select + constant moves)
-          // All "was edge j the minimum" tests first, into SGPR pairs: a VALU write of VCC/SGPR needs two wait
-          // states before a v_cndmask may read it, batching avoids the s_nops (and fills the LDS latency).
+          // ---- pass 1b: t_j = r_j - msg_old_j.  All "was edge j the minimum" tests first, into SGPR pairs: a VALU
+          // write of VCC/SGPR needs two wait states before a v_cndmask may read it, batching avoids the s_nops.
+          bool was_min[DC > 0 ? DC : 1];
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             was_min[j] = oidx == (uint32_t)j;
           });
-        }
-        // READ -> WRITE barrier.  Columns are stored rotated: a lane writes its own index but reads lane + delta, i.e.
-        // elements other waves are about to overwrite in this very layer.  Every wave's reads of the layer must have
-        // returned before any wave writes.  (It sits where the wave would wait for its LDS data anyway.)
-        __syncthreads();
-        if (active) {
-          // ---- pass 1b: t_j = r_j - msg_old_j
+          __builtin_amdgcn_sched_barrier(0);
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             const float mag = was_min[j] ? om2 : om1;
             t[j] = t[j] - sign_from(word << (top - j), mag);
           });
+          if constexpr (SPEC) {
+            // every LDS read of this layer has been consumed: fetch the next layer's wrap masks (scalar loads share
+            // the LDS counter and return out of order, so they must not overlap the counted waits above)
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int Ln = (L + 1) % B::ROWS;
+            constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
+            static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
+              wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if constexpr (EXT) {
             constexpr int slot = Y::ext_idx(L) % PFN;
             t[D - 1] = epf[slot];
@@ -374,9 +445,10 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           const float nm1 = a1 * 0.75f, nm2 = a2 * 0.75f;
           m1[L] = nm1;
           m2[L] = nm2;
-          // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written at the lane's own index (the column is now
-          // rotated by this layer's shift).  The minimum's position falls out of the magnitude test: an entry equal
-          // to min1 gets min2 (with ties min2 == min1, so every tied entry may take it); first such index = argmin.
+          // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written at the lane's own index of the column's
+          // other buffer (the column is now rotated by this layer's shift).  The minimum's position falls out of
+          // the magnitude test: an entry equal to min1 gets min2 (with ties min2 == min1, so every tied entry may
+          // take it); first such index = argmin.
           bool is_min[D];
           static_for<D>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
@@ -393,13 +465,12 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             if constexpr (col < B::CORE) {
               const float mag = is_min[j] ? nm2 : nm1;
               const float r = t[j] + sign_from(sx, mag);
+              constexpr uint32_t wof = (uint32_t)(((Y::touch_par(L, col) ^ 1) * B::CORE + col) * ZS * 4);   // write buffer
               if constexpr (SPEC) {
-                constexpr uint32_t off = (uint32_t)(col * CSTR * 4);
-                float* w = (float*)((char*)P + (off < 49152 ? z4s : z4hi) + (off < 49152 ? off : off - HI));
-                w[0] = r;
-                w[ZC] = r;                                    // second copy (reads at lane+delta never wrap)
+                if constexpr (wof < 65536) *(float*)((char*)Praw + zb + wof) = r;
+                else *(float*)((char*)Praw + zbh + (wof - HI)) = r;
               } else {
-                *(float*)((char*)Ps + col * CSTR * 4 + z4) = r;
+                *(float*)((char*)Ps + wof + z4) = r;
               }
             }
           });
@@ -412,20 +483,26 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             else sgn[ni / 2] = (word & 0xffff0000u) | f;
           }
         }
-        // WRITE -> READ barrier only where the next layer reads a column this one wrote; a later layer is already
-        // separated from this one's writes by the read->write barrier in between.
-        if constexpr ((Y::core_mask(L) & Y::core_mask((L + 1) % B::ROWS)) != 0) __syncthreads();
+        if constexpr (Y::barrier_before(L + 1)) __syncthreads();
       });
+      // ---- copy-back: columns touched an odd number of times sit in buffer 1 now (own lane, no cross-lane access)
+      if (live) {
+        static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
+          constexpr int c = decltype(cc)::value;
+          if constexpr ((Y::odd_mask() >> c) & 1u) Ps[c * ZS + z] = Ps[BUF + c * ZS + z];
+        });
+      }
+      if constexpr (Y::barrier_before(0)) __syncthreads();
     }
-    __syncthreads();   // the last layers may have run without one
+    __syncthreads();
 
-    // ---- hard decisions of the information columns, un-rotating each column (ldpc.py:1578-1581)
+    // ---- hard decisions of the information columns (buffer 0), un-rotating each column (ldpc.py:1578-1581)
     if (active) {
       static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
         const uint32_t r4 = SPEC ? (uint32_t)ctab_rho4<BG>(SPEC ? ZI : 0, c) : (uint32_t)rho4[c];
         const uint32_t e4 = wrap4(4u * (uint32_t)z + r4, zc4);
-        hard[(size_t)cb * K + c * zc + (e4 >> 2)] = Ps[c * CSTR + z] < 0.0f ? 1 : 0;
+        hard[(size_t)cb * K + c * zc + (e4 >> 2)] = Ps[c * ZS + z] < 0.0f ? 1 : 0;
       });
     }
     __syncthreads();
@@ -437,6 +514,10 @@ constexpr int zindex_c(int zc) {
     if (kZ.z[i] == zc) return i;
   return -1;
 }
+
+__constant__ WrapTab kWrap1_384 = make_wrap<1, zindex_c(384)>();
+__constant__ WrapTab kWrap1_352 = make_wrap<1, zindex_c(352)>();
+__constant__ WrapTab kWrap2_256 = make_wrap<2, zindex_c(256)>();
 
 int zindex(int zc, int ils) {
   for (int i = 0; i < NZ; ++i)
@@ -470,19 +551,32 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   const int32_t* t1 = &base[bi]->d4[zi][1][0];
   const int32_t* rh = &base[bi]->rho4[zi][0];
   static const bool no_spec = getenv("NRX_LDPC_NOSPEC") != nullptr;
+  static const uint64_t* wrap[3] = {nullptr, nullptr, nullptr};   // device addresses of the wrap-mask tables
+  if (!wrap[0]) {
+    void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+    const hipError_t e0 = hipGetSymbolAddress(&p0, HIP_SYMBOL(kWrap1_384));
+    const hipError_t e1 = hipGetSymbolAddress(&p1, HIP_SYMBOL(kWrap1_352));
+    const hipError_t e2 = hipGetSymbolAddress(&p2, HIP_SYMBOL(kWrap2_256));
+    NRX_REQUIRE(e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess && p0 && p1 && p2, NRX_E_HIP,
+                "nrx_ldpc_decode: hipGetSymbolAddress(wrap masks) failed");
+    wrap[1] = (const uint64_t*)p1;
+    wrap[2] = (const uint64_t*)p2;
+    wrap[0] = (const uint64_t*)p0;
+  }
+  const uint64_t* wt = nullptr;
 #define NRX_DEC2_LAUNCH(BGN, ZIV, NSV)                                                                               \
   hipLaunchKernelGGL((ldpc_dec_fast_kernel<BGN, ZIV, NSV>), dim3(grid), dim3(threads), 0, st, llr, n_cb, cfg->Zc, n_iter, \
-                     hard, (ctab_t)t0, (ctab_t)t1, (ctab_t)rh)
+                     hard, (ctab_t)t0, (ctab_t)t1, (ctab_t)rh, (mtab_t)wt)
   // lifting sizes with a specialised instantiation (the sizes of the BASELINE configurations); everything else
   // runs the generic kernel
   constexpr int ZI384 = zindex_c(384), ZI352 = zindex_c(352), ZI256 = zindex_c(256);
   if (cfg->bg == 1) {
-    if (!no_spec && zi == ZI384) NRX_DEC2_LAUNCH(1, ZI384, 2);
-    else if (!no_spec && zi == ZI352) NRX_DEC2_LAUNCH(1, ZI352, 2);
+    if (!no_spec && zi == ZI384) { wt = wrap[0]; NRX_DEC2_LAUNCH(1, ZI384, 2); }
+    else if (!no_spec && zi == ZI352) { wt = wrap[1]; NRX_DEC2_LAUNCH(1, ZI352, 2); }
     else if (ns == 2) NRX_DEC2_LAUNCH(1, -1, 2);
     else NRX_DEC2_LAUNCH(1, -1, 1);
   } else {
-    if (!no_spec && zi == ZI256) NRX_DEC2_LAUNCH(2, ZI256, 1);
+    if (!no_spec && zi == ZI256) { wt = wrap[2]; NRX_DEC2_LAUNCH(2, ZI256, 1); }
     else if (ns == 2) NRX_DEC2_LAUNCH(2, -1, 2);
     else NRX_DEC2_LAUNCH(2, -1, 1);
   }
