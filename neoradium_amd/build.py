@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libnrx.so')
-FLAGS = ['-std=c++20', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-Wno-comment',
+FLAGS = ['-std=c++20', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-mllvm', '-amdgpu-sdwa-peephole=0', '-fPIC', '-Wno-comment',
          '-Wno-unused-value']
 
 

@@ -271,6 +271,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
   const int z = (int)threadIdx.x - slot * tz;
   const uint32_t sb = (uint32_t)(ZS + slot * SLOT) * 4u;   // byte offset of the slot's buffer 0 inside Praw
   const mtab_t wm = wtab + __builtin_amdgcn_readfirstlane(z >> 6) * ESTRIDE;   // this wave's row of wrap masks
+  const uint32_t zb0 = 4u * (uint32_t)z + sb;
   float* const Ps = Praw + ZS + slot * SLOT;
   const uint32_t zc4 = 4u * (uint32_t)zc;
   const int N = (B::COLS - 2) * zc, K = B::KB * zc;
@@ -289,10 +290,14 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
     // live: wave-uniform, this wave's code block exists.  Inside the layer loop the lanes z >= Zc of a partial last
     // wave simply run along: their LDS writes land in the padding of their own column (stride = whole waves), their
     // reads are never used, their global reads are clamped.  That keeps the loop free of EXEC masking.
-    const bool live = cb < n_cb;
+    // (for NS == 1 `cb < n_cb` is a tautology; an opaque 1 keeps the per-layer `if (live)` below a real branch:
+    //  without those block boundaries the 46 unrolled layers form one region and the register allocator spills)
+    int one = 1;
+    asm volatile("" : "+s"(one));
+    const bool live = cb < n_cb && one != 0;
     const bool active = z < zc && live;
-    const float* in = llr + (size_t)(live ? cb : 0) * N;
-    if (active) {
+    const float* in = llr + (size_t)(live ? cb : n_cb - 1) * N;
+    if (z < zc) {
       static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
         // + 0.0f turns an input -0.0 into +0.0 (the reference's sign test is (v < 0))
@@ -355,9 +360,9 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         asm volatile("" : "+v"(z4), "+s"(d4), "+s"(wo));
         const mtab_t wml = wm + __builtin_amdgcn_readfirstlane(wo);
         // byte addresses of element z of column 0 / buffer 0 of this slot: plain, wrapped (- Zc), and both + HI
-        uint32_t zb = z4 + sb, zbw = zb - zc4, zbh = zb + HI, zbwh = zbw + HI;
-        if constexpr (SPEC) asm volatile("" : "+v"(zb), "+v"(zbw), "+v"(zbh), "+v"(zbwh));
-        if (live) {
+        // (four live registers; everything else of an address is a DS immediate)
+        const uint32_t zb = zb0, zbw = zb0 - zc4, zbh = zb0 + HI, zbwh = zb0 - zc4 + HI;
+        if (live) {   // (wave-uniform; the per-layer branch also keeps each layer its own scheduling region)
           // ---- pass 1a: issue every LDS read of the layer
           float t[D];
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
@@ -390,7 +395,6 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             oidx = (ni & 1) ? (word >> 28) : ((word >> 12) & 15u);
             top = (ni & 1) ? 15 : 31;
           }
-          asm volatile("" : "+v"(oidx));   // keep it a plain VGPR compare (no SDWA byte-select + constant moves)
           // ---- pass 1b: t_j = r_j - msg_old_j.  All "was edge j the minimum" tests first, into SGPR pairs: a VALU
           // write of VCC/SGPR needs two wait states before a v_cndmask may read it, batching avoids the s_nops.
           bool was_min[DC > 0 ? DC : 1];
@@ -446,9 +450,9 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           m1[L] = nm1;
           m2[L] = nm2;
           // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written at the lane's own index of the column's
-          // other buffer (the column is now rotated by this layer's shift).  The minimum's position falls out of
-          // the magnitude test: an entry equal to min1 gets min2 (with ties min2 == min1, so every tied entry may
-          // take it); first such index = argmin.
+          // other buffer (the column is now rotated by this layer's shift).  The minimum's position falls out of a
+          // magnitude test: an entry equal to min1 gets min2 (with ties min2 == min1, so every tied entry may take
+          // it); first such index = argmin.
           bool is_min[D];
           static_for<D>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
@@ -484,9 +488,10 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           }
         }
         if constexpr (Y::barrier_before(L + 1)) __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);   // nothing migrates between layers (register pressure)
       });
       // ---- copy-back: columns touched an odd number of times sit in buffer 1 now (own lane, no cross-lane access)
-      if (live) {
+      {
         static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
           constexpr int c = decltype(cc)::value;
           if constexpr ((Y::odd_mask() >> c) & 1u) Ps[c * ZS + z] = Ps[BUF + c * ZS + z];

@@ -1,0 +1,31 @@
+"""Dev tool: the fast decoder must be deterministic and agree bit for bit with the in-place (v1) kernel and, on a
+sample, with the NumPy oracle in float32 -- on inputs where many blocks do NOT converge (values keep moving)."""
+import os, sys, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from neoradium_amd import ops, _lib
+
+dev = torch.device('cuda:0')
+cfg = _lib.ldpc_config(1, 606504 + 24)
+n_cb, n_iter = 2304, 50
+g = torch.Generator(device=dev); g.manual_seed(5)
+sig = float(os.environ.get('SIG', '1.3'))
+llr = (2 / sig**2 + (2 / sig) * torch.randn((n_cb, cfg.N), device=dev, generator=g)).float()
+outs = [ops.ldpc_decode(llr, cfg, n_iter).clone() for _ in range(4)]
+torch.cuda.synchronize()
+for i in range(1, 4):
+    print('run', i, 'differs from run 0 in', int((outs[i] != outs[0]).any(1).sum()), 'code blocks')
+if len(sys.argv) > 1 and sys.argv[1] == 'child':
+    np.save('/tmp/dec_v1.npy', outs[0].cpu().numpy())
+    sys.exit(0)
+env = dict(os.environ, NRX_LDPC_V1='1')
+subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=env, check=True, stdout=subprocess.DEVNULL)
+v1 = torch.from_numpy(np.load('/tmp/dec_v1.npy')).to(dev)
+print('fast vs in-place v1 kernel: differing code blocks', int((v1 != outs[0]).any(1).sum()), 'of', n_cb)
+from oracle import coding as oc
+k = 6
+ref = oc.decode(llr[:k].cpu().numpy().astype(np.float32), 1, cfg.iLS, cfg.Zc, n_iter, dtype=np.float32)
+print('fast vs oracle(float32) on', k, 'blocks: differing blocks', int((ref != outs[0][:k].cpu().numpy()).any(1).sum()))
+crc = ops.ldpc_crc_merge(outs[0], cfg, want_tb=False)[1]
+print('code blocks passing CRC:', int(crc.sum()), 'of', n_cb)
