@@ -15,7 +15,7 @@ using nrx::crc_len;
 using nrx::crc_poly;
 
 // (a * b) mod g over GF(2), degrees < L.
-__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t low, int L) {
+__host__ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t low, int L) {
   const uint32_t mask = (1u << L) - 1u;
   uint32_t r = 0;
   for (int i = L - 1; i >= 0; --i) {
@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b, uint32_t 
   return r;
 }
 // x^e mod g
-__device__ __forceinline__ uint32_t gf2_xpow(uint64_t e, uint32_t low, int L) {
+__host__ __device__ __forceinline__ uint32_t gf2_xpow(uint64_t e, uint32_t low, int L) {
   uint32_t result = 1u;          // x^0
   uint32_t base = (L > 1) ? 2u : low;  // x^1 (L>=6 always)
   while (e) {
@@ -37,46 +37,93 @@ __device__ __forceinline__ uint32_t gf2_xpow(uint64_t e, uint32_t low, int L) {
   return result;
 }
 
-// Workgroup-parallel CRC of `n` bits produced by bit(i): each thread runs the bit-serial register over a
-// contiguous chunk, then the chunk remainders are aligned with x^(bits after the chunk) and xor-reduced
-// (CRC is linear over GF(2)).  Result is identical to the reference's long division (chancodebase.py:119-128).
-// Returns the remainder to every thread.  `red` is >= blockDim.x/64 words of LDS.
-template <class BitFn>
-__device__ uint32_t block_crc(BitFn bit, int64_t n, int poly_id, uint32_t* red) {
-  const int L = crc_len(poly_id);
-  const uint32_t low = crc_poly(poly_id) & ((1u << L) - 1u);
-  const uint32_t mask = (1u << L) - 1u;
-  const int nt = blockDim.x, tid = threadIdx.x;
-  const int64_t chunk = (n + nt - 1) / nt;
-  const int64_t b0 = (int64_t)tid * chunk;
-  int64_t b1 = b0 + chunk;
-  if (b1 > n) b1 = n;
-  uint32_t reg = 0;
-  for (int64_t i = b0; i < b1; ++i) {
-    const uint32_t top = ((reg >> (L - 1)) ^ (uint32_t)bit(i)) & 1u;
-    reg = ((reg << 1) & mask) ^ (top ? low : 0u);
+// Workgroup-parallel CRC of one row of n bits (one byte per bit).  Thread t runs the bit-serial register over the
+// `chunk` bits that END at n - (T-1-t)*chunk (the front of the row is virtually padded with zero bits, which do not
+// change a CRC), reading 16 bytes at a time where the address allows it; the T chunk remainders are then combined in
+// a binary tree: at level k a pair is joined as  left * x^(chunk * 2^k) + right  (mod g).  The level multipliers
+// depend only on (chunk, polynomial) and are computed on the host (CrcPlan), so no thread ever exponentiates.
+// The result equals the reference's long division (chancodebase.py:119-128); every thread gets it.
+struct CrcPlan {
+  int32_t poly_id, L;
+  uint32_t low;
+  int32_t threads, chunk;  // threads: power of two, 64..1024
+  uint32_t mk[10];         // x^(chunk * 2^k) mod g
+};
+
+CrcPlan make_crc_plan(int64_t n_bits, int poly_id, int max_threads = 1024) {
+  CrcPlan p;
+  p.poly_id = poly_id;
+  p.L = crc_len(poly_id);
+  p.low = crc_poly(poly_id) & ((1u << p.L) - 1u);
+  int t = 64;
+  while (t < max_threads && (int64_t)t * 256 < n_bits) t *= 2;   // >= ~256 bits per thread before widening
+  p.threads = t;
+  int64_t c = (n_bits + t - 1) / t;
+  c = (c + 15) / 16 * 16;
+  if (c < 16) c = 16;
+  p.chunk = (int32_t)c;
+  uint32_t m = gf2_xpow((uint64_t)c, p.low, p.L);
+  for (int k = 0; k < 10; ++k) {
+    p.mk[k] = m;
+    m = gf2_mulmod(m, m, p.low, p.L);
   }
-  if (b0 < n && reg != 0 && b1 < n) reg = gf2_mulmod(reg, gf2_xpow((uint64_t)(n - b1), low, L), low, L);
-  if (b0 >= n) reg = 0;
-  // xor-reduce across the workgroup
-  for (int o = 32; o > 0; o >>= 1) reg ^= __shfl_xor(reg, o, 64);
+  return p;
+}
+
+__device__ __forceinline__ uint32_t crc_step(uint32_t reg, uint32_t bit, uint32_t low, uint32_t mask, int L) {
+  const uint32_t top = ((reg >> (L - 1)) ^ bit) & 1u;
+  return ((reg << 1) & mask) ^ (top ? low : 0u);
+}
+
+// `red`: >= 16 words of LDS.  Requires blockDim.x == plan.threads.
+__device__ uint32_t block_crc(const uint8_t* __restrict__ row, int64_t n, const CrcPlan& pl, uint32_t* red) {
+  const int L = pl.L;
+  const uint32_t low = pl.low, mask = (1u << L) - 1u;
+  const int nt = blockDim.x, tid = threadIdx.x;
+  const int64_t e = n - (int64_t)(nt - 1 - tid) * pl.chunk;   // end of this thread's chunk (exclusive)
+  int64_t i = e - pl.chunk;
+  if (i < 0) i = 0;
+  uint32_t reg = 0;
+  for (; i < e && ((uintptr_t)(row + i) & 15u); ++i) reg = crc_step(reg, row[i] & 1u, low, mask, L);
+  for (; i + 16 <= e; i += 16) {
+    const uint4 v = *reinterpret_cast<const uint4*>(row + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) reg = crc_step(reg, (w[q] >> (8 * b)) & 1u, low, mask, L);
+  }
+  for (; i < e; ++i) reg = crc_step(reg, row[i] & 1u, low, mask, L);
+  // tree inside the wave
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const uint32_t other = __shfl_xor(reg, 1 << k, 64);
+    const bool upper = (tid >> k) & 1;
+    reg = gf2_mulmod(upper ? other : reg, pl.mk[k], low, L) ^ (upper ? reg : other);
+  }
+  const int nw = nt >> 6;
+  if (nw == 1) return reg;
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = reg;
   __syncthreads();
-  uint32_t tot = 0;
-  for (int w = 0; w < (nt + 63) / 64; ++w) tot ^= red[w];
+  uint32_t tot = red[tid & (nw - 1)];   // every wave finishes the tree over the nw wave remainders
+  for (int k = 0; (1 << k) < nw; ++k) {
+    const uint32_t other = __shfl_xor(tot, 1 << k, 64);
+    const bool upper = (tid >> k) & 1;
+    tot = gf2_mulmod(upper ? other : tot, pl.mk[6 + k], low, L) ^ (upper ? tot : other);
+  }
   __syncthreads();
   return tot;
 }
 
 // ---------------------------------------------------------------------------------------------- nrx_crc
 __global__ void __launch_bounds__(1024)
-crc_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, int poly_id,
+crc_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, const CrcPlan pl,
                 uint8_t* __restrict__ out) {
   __shared__ uint32_t red[16];
   const uint8_t* row = bits + (size_t)blockIdx.x * row_stride;
-  const uint32_t r = block_crc([&](int64_t i) { return row[i] & 1; }, row_len, poly_id, red);
-  const int L = crc_len(poly_id);
+  const uint32_t r = block_crc(row, row_len, pl, red);
+  const int L = pl.L;
   if ((int)threadIdx.x < L) out[(size_t)blockIdx.x * L + threadIdx.x] = (r >> (L - 1 - threadIdx.x)) & 1u;
 }
 
@@ -88,11 +135,12 @@ crc_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_s
 //  2. segment_kernel: one small workgroup per (tb, code block) copies the payload from the TB, leaves the TB-CRC
 //     bits that are already in place, zero-pads, appends CRC24B (C>1) and the zero filler bits.
 __global__ void __launch_bounds__(1024)
-tb_crc_scatter_kernel(const uint8_t* __restrict__ tb, int A, int C, int K, int per, uint8_t* __restrict__ cbs) {
+tb_crc_scatter_kernel(const uint8_t* __restrict__ tb, int A, int C, int K, int per, uint8_t* __restrict__ cbs,
+                      const CrcPlan pl) {
   __shared__ uint32_t red[16];
   const int t = blockIdx.x;
   const uint8_t* src = tb + (size_t)t * A;
-  const uint32_t crc = block_crc([&](int64_t i) { return src[i] & 1; }, A, NRX_CRC24A, red);
+  const uint32_t crc = block_crc(src, A, pl, red);
   if (threadIdx.x < 24) {
     const int64_t g = (int64_t)A + threadIdx.x;
     const int c = (int)(g / per), o = (int)(g - (int64_t)c * per);
@@ -101,7 +149,8 @@ tb_crc_scatter_kernel(const uint8_t* __restrict__ tb, int A, int C, int K, int p
 }
 
 __global__ void __launch_bounds__(256)
-segment_kernel(const uint8_t* __restrict__ tb, int A, int B, int C, int K, int cb_len, uint8_t* __restrict__ cbs) {
+segment_kernel(const uint8_t* __restrict__ tb, int A, int B, int C, int K, int cb_len, uint8_t* __restrict__ cbs,
+               const CrcPlan pl) {
   __shared__ uint32_t red[16];
   const int t = blockIdx.x / C, c = blockIdx.x % C;
   const int per = (B + C - 1) / C;  // payload bits per block before its CRC
@@ -115,7 +164,7 @@ segment_kernel(const uint8_t* __restrict__ tb, int A, int B, int C, int K, int c
   }
   __syncthreads();
   if (C > 1) {
-    const uint32_t r = block_crc([&](int64_t i) { return dst[i] & 1; }, per, NRX_CRC24B, red);
+    const uint32_t r = block_crc(dst, per, pl, red);
     if (threadIdx.x < 24) dst[per + threadIdx.x] = (r >> (23 - threadIdx.x)) & 1u;
   }
   for (int i = cb_len + threadIdx.x; i < K; i += blockDim.x) dst[i] = 0;  // fillers are ZERO bits (ldpc.py:1025-1028)
@@ -276,7 +325,7 @@ rate_recover_kernel(const T* __restrict__ llr, int n_tb, int llr_len, RmGeom g, 
 // ldpc.py:1584-1619.  One workgroup per code block.
 __global__ void __launch_bounds__(1024)
 crc_merge_kernel(const uint8_t* __restrict__ dec, int C, int K, int cb_len, int B, uint8_t* __restrict__ tb_out,
-                 uint8_t* __restrict__ cb_ok) {
+                 uint8_t* __restrict__ cb_ok, const CrcPlan pl) {
   __shared__ uint32_t red[16];
   const int t = blockIdx.x / C, c = blockIdx.x % C;
   const uint8_t* row = dec + (size_t)blockIdx.x * K;
@@ -286,16 +335,16 @@ crc_merge_kernel(const uint8_t* __restrict__ dec, int C, int K, int cb_len, int 
     uint8_t* dst = tb_out + (size_t)t * C * payload + (size_t)c * payload;
     for (int i = threadIdx.x; i < payload; i += blockDim.x) dst[i] = row[i] & 1;
   }
-  const uint32_t r = block_crc([&](int64_t i) { return row[i] & 1; }, cb_len, C > 1 ? NRX_CRC24B : NRX_CRC24A, red);
+  const uint32_t r = block_crc(row, cb_len, pl, red);
   if (threadIdx.x == 0) cb_ok[blockIdx.x] = r == 0 ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(1024)
-crc_ok_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, int poly_id,
+crc_ok_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t row_stride, const CrcPlan pl,
                    uint8_t* __restrict__ ok) {
   __shared__ uint32_t red[16];
   const uint8_t* row = bits + (size_t)blockIdx.x * row_stride;
-  const uint32_t r = block_crc([&](int64_t i) { return row[i] & 1; }, row_len, poly_id, red);
+  const uint32_t r = block_crc(row, row_len, pl, red);
   if (threadIdx.x == 0) ok[blockIdx.x] = r == 0 ? 1 : 0;
 }
 
@@ -325,13 +374,6 @@ count_errors_kernel(const uint8_t* __restrict__ cb_ok, int n_ok, const uint8_t* 
   }
 }
 
-// threads per row for the workgroup-parallel CRC: ~512 bits per thread, 64..1024
-int crc_threads(int64_t n_bits) {
-  int t = 64;
-  while (t < 1024 && (int64_t)t * 512 < n_bits) t *= 2;
-  return t;
-}
-
 int fill_geom(const nrx_ldpc_cfg* cfg, int G, int nl, int qm, int rv, int n_ref, RmGeom* g) {
   static const int k0num[2][4] = {{0, 17, 33, 56}, {0, 13, 25, 43}};
   g->C = cfg->C; g->N = cfg->N; g->K = cfg->K; g->F = cfg->F; g->zc = cfg->Zc;
@@ -355,8 +397,9 @@ extern "C" int32_t nrx_crc(const uint8_t* bits, int32_t n_rows, int64_t row_len,
   NRX_REQUIRE(poly_id >= NRX_CRC6 && poly_id <= NRX_CRC24C, NRX_E_ARG, "nrx_crc: unknown polynomial id %d", poly_id);
   NRX_REQUIRE(n_rows >= 0 && row_len >= 0 && row_stride >= row_len, NRX_E_SHAPE, "nrx_crc: bad row geometry");
   if (n_rows == 0) return NRX_OK;
-  hipLaunchKernelGGL(crc_rows_kernel, dim3(n_rows), dim3(crc_threads(row_len)), 0, (hipStream_t)stream, bits,
-                     row_len, row_stride, poly_id, crc_out);
+  const CrcPlan pl = make_crc_plan(row_len, poly_id);
+  hipLaunchKernelGGL(crc_rows_kernel, dim3(n_rows), dim3(pl.threads), 0, (hipStream_t)stream, bits, row_len, row_stride,
+                     pl, crc_out);
   NRX_CHECK_LAUNCH("nrx_crc");
   return NRX_OK;
 }
@@ -370,11 +413,13 @@ extern "C" int32_t nrx_ldpc_segment(const uint8_t* tb, int32_t n_tb, int32_t A, 
   if (n_tb == 0) return NRX_OK;
   hipStream_t st = (hipStream_t)stream;
   const int per = (cfg->B + cfg->C - 1) / cfg->C;
-  if (add_tb_crc)
-    hipLaunchKernelGGL(tb_crc_scatter_kernel, dim3(n_tb), dim3(crc_threads(A)), 0, st, tb, A, cfg->C, cfg->K, per, cbs);
-  int th = crc_threads(per);
-  if (th > 256) th = 256;
-  hipLaunchKernelGGL(segment_kernel, dim3(n_tb * cfg->C), dim3(th), 0, st, tb, A, cfg->B, cfg->C, cfg->K, cfg->cb_len, cbs);
+  if (add_tb_crc) {
+    const CrcPlan pa = make_crc_plan(A, NRX_CRC24A);
+    hipLaunchKernelGGL(tb_crc_scatter_kernel, dim3(n_tb), dim3(pa.threads), 0, st, tb, A, cfg->C, cfg->K, per, cbs, pa);
+  }
+  const CrcPlan pb = make_crc_plan(per, NRX_CRC24B, 256);
+  hipLaunchKernelGGL(segment_kernel, dim3(n_tb * cfg->C), dim3(pb.threads), 0, st, tb, A, cfg->B, cfg->C, cfg->K,
+                     cfg->cb_len, cbs, pb);
   NRX_CHECK_LAUNCH("nrx_ldpc_segment");
   return NRX_OK;
 }
@@ -457,11 +502,14 @@ extern "C" int32_t nrx_ldpc_crc_merge(const uint8_t* dec, int32_t n_tb, const nr
   NRX_REQUIRE(!tb_ok || tb_out, NRX_E_ARG, "nrx_ldpc_crc_merge: tb_ok needs tb_out");
   if (n_tb == 0) return NRX_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(crc_merge_kernel, dim3(n_tb * cfg->C), dim3(crc_threads(cfg->cb_len)), 0, st, dec, cfg->C,
-                     cfg->K, cfg->cb_len, cfg->B, tb_out, cb_ok);
-  if (tb_ok)
-    hipLaunchKernelGGL(crc_ok_rows_kernel, dim3(n_tb), dim3(crc_threads(cfg->B)), 0, st, tb_out, (int64_t)cfg->B,
-                       (int64_t)cfg->C * (cfg->cb_len - (cfg->C > 1 ? 24 : 0)), NRX_CRC24A, tb_ok);
+  const CrcPlan pc = make_crc_plan(cfg->cb_len, cfg->C > 1 ? NRX_CRC24B : NRX_CRC24A, 256);
+  hipLaunchKernelGGL(crc_merge_kernel, dim3(n_tb * cfg->C), dim3(pc.threads), 0, st, dec, cfg->C, cfg->K, cfg->cb_len,
+                     cfg->B, tb_out, cb_ok, pc);
+  if (tb_ok) {
+    const CrcPlan pt = make_crc_plan(cfg->B, NRX_CRC24A);
+    hipLaunchKernelGGL(crc_ok_rows_kernel, dim3(n_tb), dim3(pt.threads), 0, st, tb_out, (int64_t)cfg->B,
+                       (int64_t)cfg->C * (cfg->cb_len - (cfg->C > 1 ? 24 : 0)), pt, tb_ok);
+  }
   NRX_CHECK_LAUNCH("nrx_ldpc_crc_merge");
   return NRX_OK;
 }
