@@ -224,6 +224,129 @@ apply_td_paths_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __
   for (int r = 0; r < NR; ++r) y[((size_t)b * NR + r) * ns + n] = acc[r];
 }
 
+// Register-tiled path form: every thread produces R = 4 consecutive output samples, so one window of flen + 3 input
+// samples feeds 4 FIR outputs (4.75 LDS reads per output sample and path instead of 16; the first version of this
+// kernel was bound by LDS bandwidth).  The input tile is staged transposed, xs[t][s mod 4][s div 4], so that the
+// 16-byte reads of neighbouring lanes (samples 4 apart) are contiguous.  Taps and gains are wave-uniform (scalar
+// loads); arithmetic is explicit fma (the summation order already differs from SciPy's lfilter).
+constexpr int TDP_R = 4;
+constexpr int TDP_TILE = 128;  // threads per antenna group -> 512 output samples per workgroup
+constexpr int TDP_GROUPS = 2;  // antenna groups per workgroup (more waves on the same staged tile)
+constexpr int TDP_FLEN = 16;   // channelmodel.py:249-289: 16-tap fractional-delay filters
+
+// One (tx antenna, path) term for the 4 samples of a thread.  U0 = (first window sample) mod 4 is a template
+// parameter so that the transposed-tile addresses are four base pointers + compile-time offsets.
+template <int NR, int U0>
+__device__ __forceinline__ void tdp4_term(const cd* __restrict__ p0, const cd* __restrict__ p1, const cd* __restrict__ p2,
+                                          const cd* __restrict__ p3, const double* __restrict__ c,
+                                          const cd* __restrict__ gv, int gstride, double (&ar)[NR][TDP_R],
+                                          double (&ai)[NR][TDP_R]) {
+  constexpr int R = TDP_R, W = TDP_FLEN + R - 1;
+  double wr[W], wi[W];
+#pragma unroll
+  for (int m = 0; m < W; ++m) {
+    constexpr int dummy = 0;
+    const int cc = (U0 + m) & (R - 1), qo = (U0 + m) >> 2;
+    const cd* pc = cc == 0 ? p0 : (cc == 1 ? p1 : (cc == 2 ? p2 : p3));
+    const cd v = pc[qo + dummy];
+    wr[m] = v.re;
+    wi[m] = v.im;
+  }
+  double fr[R], fi[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) fr[j] = fi[j] = 0.0;
+#pragma unroll
+  for (int k = 0; k < TDP_FLEN; ++k) {
+    const double ck = c[k];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {   // x[n + j - off - k] = window element 15 + j - k
+      fr[j] = fma(ck, wr[TDP_FLEN - 1 + j - k], fr[j]);
+      fi[j] = fma(ck, wi[TDP_FLEN - 1 + j - k], fi[j]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const cd g = gv[(size_t)r * gstride];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      ar[r][j] = fma(g.re, fr[j], fma(-g.im, fi[j], ar[r][j]));
+      ai[r][j] = fma(g.re, fi[j], fma(g.im, fr[j], ai[r][j]));
+    }
+  }
+}
+
+template <int NR>
+__global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS)
+apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ gains1, int n_paths,
+                       const double* __restrict__ taps, const int32_t* __restrict__ tap_off, int hist, TdGeom g,
+                       cd* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cd* xs = (cd*)smem;  // [nt][R][Q]
+  constexpr int R = TDP_R;
+  const int b = blockIdx.y;
+  const int set = blockIdx.x / g.tiles_per_set, tile = blockIdx.x % g.tiles_per_set;
+  const int n0 = g.start[set] + tile * (TDP_TILE * R);
+  const int n_end = g.start[set + 1];
+  if (n0 >= n_end) return;
+  const int span = TDP_TILE * R + hist;   // hist is a multiple of R (host)
+  const int Q = span / R;
+  for (int i = threadIdx.x; i < nt * span; i += blockDim.x) {
+    const int t = i / span, j = i - t * span;
+    const int64_t n = (int64_t)n0 - hist + j;
+    xs[(t * R + (j & (R - 1))) * Q + (j >> 2)] = (n >= 0 && n < ns) ? x[((size_t)b * nt + t) * ns + n] : cd(0, 0);
+  }
+  __syncthreads();
+  // the workgroup's waves split the transmit antennas between them (same staged tile, twice the waves per CU)
+  const int ts = (int)threadIdx.x % TDP_TILE, grp = (int)threadIdx.x / TDP_TILE;
+  const int n = n0 + R * ts;
+  double ar[NR][R], ai[NR][R];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int j = 0; j < R; ++j) ar[r][j] = ai[r][j] = 0.0;
+  const cd* gb = gains1 + ((size_t)b * g.n_sets + set) * NR * nt * n_paths;
+  if (n < n_end) {
+    for (int t = grp; t < nt; t += TDP_GROUPS) {
+      for (int p = 0; p < n_paths; ++p) {
+        const int u = hist - tap_off[p] - (TDP_FLEN - 1);   // window element m is sample  R*ts + u + m  of the tile
+        const double* c = taps + (size_t)p * TDP_FLEN;
+        const cd* base = xs + (size_t)t * R * Q + (u >> 2) + ts;
+        const cd *p0 = base, *p1 = base + Q, *p2 = base + 2 * Q, *p3 = base + 3 * Q;
+        const cd* gv = gb + (size_t)t * n_paths + p;
+        switch (u & 3) {   // wave-uniform
+          case 0: tdp4_term<NR, 0>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
+          case 1: tdp4_term<NR, 1>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
+          case 2: tdp4_term<NR, 2>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
+          default: tdp4_term<NR, 3>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
+        }
+      }
+    }
+  }
+  // sum the groups' partial results through LDS (the staged tile is dead now)
+  __syncthreads();
+  double* part = (double*)smem;   // [2 * NR * R][TDP_TILE]
+  if (grp == 1) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        part[((r * R + j) * 2 + 0) * TDP_TILE + ts] = ar[r][j];
+        part[((r * R + j) * 2 + 1) * TDP_TILE + ts] = ai[r][j];
+      }
+  }
+  __syncthreads();
+  if (grp == 0 && n < n_end) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const double re = ar[r][j] + part[((r * R + j) * 2 + 0) * TDP_TILE + ts];
+        const double im = ai[r][j] + part[((r * R + j) * 2 + 1) * TDP_TILE + ts];
+        if (n + j < n_end) y[((size_t)b * NR + r) * ns + n + j] = cd(re, im);
+      }
+  }
+}
+
 int ilog2(int n) {
   int l = 0;
   while ((1 << l) < n) ++l;
@@ -521,10 +644,39 @@ extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_
   if (n_items == 0) return NRX_OK;
   TdGeom g;
   td_geom(set_lens, n_sets, ns, &g);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    // register-tiled kernel: 4 output samples per thread
+    const int hist4 = (hist + TDP_R - 1) / TDP_R * TDP_R;
+    size_t lds4 = sizeof(cd) * (size_t)n_tx * (TDP_TILE * TDP_R + hist4);
+    const size_t part4 = sizeof(double) * 2 * (size_t)n_rx * TDP_R * TDP_TILE;   // group partial sums reuse the tile
+    if (lds4 < part4) lds4 = part4;
+    if (flen == TDP_FLEN && lds4 <= 80 * 1024 && n_rx <= 4) {
+      int maxlen = 0;
+      for (int i = 0; i < g.n_sets; ++i) maxlen = g.start[i + 1] - g.start[i] > maxlen ? g.start[i + 1] - g.start[i] : maxlen;
+      TdGeom g4 = g;
+      g4.tiles_per_set = (maxlen + TDP_TILE * TDP_R - 1) / (TDP_TILE * TDP_R);
+      if (g4.tiles_per_set < 1) g4.tiles_per_set = 1;
+      const dim3 grid4(g4.tiles_per_set * n_sets, n_items);
+#define NRX_TDP4_CASE(NR)                                                                                                  \
+  case NR:                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)apply_td_paths4_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
+    hipLaunchKernelGGL(apply_td_paths4_kernel<NR>, grid4, dim3(TDP_TILE * TDP_GROUPS), lds4, st, (const cd*)x, n_tx, ns,  \
+                       (const cd*)gains1, n_paths, taps, tap_off, hist4, g4, (cd*)y);                                      \
+    break;
+      switch (n_rx) {
+        NRX_TDP4_CASE(1)
+        NRX_TDP4_CASE(2)
+        NRX_TDP4_CASE(4)
+      }
+#undef NRX_TDP4_CASE
+      NRX_CHECK_LAUNCH("nrx_apply_td_paths");
+      return NRX_OK;
+    }
+  }
   const size_t lds = sizeof(cd) * (size_t)n_tx * (TD_TILE + hist);
   NRX_REQUIRE(lds <= 160 * 1024, NRX_E_UNSUPPORTED, "nrx_apply_td_paths: Nt*delay too large for LDS staging (%zu B)", lds);
   const dim3 grid(g.tiles_per_set * n_sets, n_items);
-  hipStream_t st = (hipStream_t)stream;
 #define NRX_TDP_CASE(NR)                                                                                                  \
   case NR:                                                                                                                \
     (void)hipFuncSetAttribute((const void*)apply_td_paths_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
