@@ -559,6 +559,132 @@ __global__ void svd_precoder_kernel(const cd* __restrict__ Hblk, int n_avg, int 
   }
 }
 
+// Same computation with compile-time antenna counts: one wavefront per batch item, the lanes share the averaging
+// (the only part with real memory traffic), every lane then runs the tiny Jacobi in registers (no scratch).
+template <int NR, int NT>
+__global__ void __launch_bounds__(64) svd_precoder_wave_kernel(const cd* __restrict__ Hblk, int n_avg, int nl,
+                                                               cd* __restrict__ F, int n_items) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  constexpr int E = NR * NT;
+  const cd* src = Hblk + (size_t)b * n_avg * E;
+  // lane l sums entries l, l+64, ... of the (n_avg x E) block in order; E divides 64 or is a multiple of it
+  cd Hm[NR][NT];
+  {
+    constexpr int GRP = E <= 64 ? 64 / E : 1;          // lanes per matrix entry
+    const int e = E <= 64 ? lane % E : 0, gi = E <= 64 ? lane / E : 0;
+    double sr[E > 64 ? E / 64 : 1], si[E > 64 ? E / 64 : 1];
+    if constexpr (E <= 64) {
+      double ar = 0, ai = 0;
+      for (int a = gi; a < n_avg; a += GRP) {
+        const cd v = src[(size_t)a * E + e];
+        ar += v.re;
+        ai += v.im;
+      }
+      // fold the GRP partial sums: lanes e, e+E, e+2E, ...
+      for (int o = 32; o >= E; o >>= 1) {
+        ar += __shfl_xor(ar, o, 64);
+        ai += __shfl_xor(ai, o, 64);
+      }
+      sr[0] = ar;
+      si[0] = ai;
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          Hm[r][t] = cd(__shfl(sr[0], r * NT + t, 64) / n_avg, __shfl(si[0], r * NT + t, 64) / n_avg);
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          double ar = 0, ai = 0;
+          for (int a = lane; a < n_avg; a += 64) {
+            const cd v = src[(size_t)a * E + r * NT + t];
+            ar += v.re;
+            ai += v.im;
+          }
+          for (int o = 32; o > 0; o >>= 1) {
+            ar += __shfl_xor(ar, o, 64);
+            ai += __shfl_xor(ai, o, 64);
+          }
+          Hm[r][t] = cd(ar / n_avg, ai / n_avg);
+        }
+    }
+  }
+  cd G[NR][NR], U[NR][NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      cd s(0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) nrx::cmacc(s, Hm[j][t], Hm[i][t]);
+      G[i][j] = s;
+      U[i][j] = cd(i == j ? 1.0 : 0.0, 0.0);
+    }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double offn = 0, diagn = 0;
+#pragma unroll
+    for (int p = 0; p < NR; ++p) {
+      diagn += G[p][p].re * G[p][p].re;
+#pragma unroll
+      for (int q = p + 1; q < NR; ++q) offn += nrx::norm2(G[p][q]);
+    }
+    if (offn <= 1e-34 * diagn || offn < 1e-300) break;
+#pragma unroll
+    for (int p = 0; p < NR; ++p)
+#pragma unroll
+      for (int q = p + 1; q < NR; ++q) {
+        const double apq = sqrt(nrx::norm2(G[p][q]));
+        if (apq >= 1e-300) {
+          const cd ph(G[p][q].re / apq, G[p][q].im / apq);
+          const double tau = (G[q][q].re - G[p][p].re) / (2.0 * apq);
+          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const cd gkp = G[k][p], gkq = G[k][q];
+            G[k][p] = cd(c * gkp.re - s * (gkq.re * ph.re + gkq.im * ph.im), c * gkp.im - s * (gkq.im * ph.re - gkq.re * ph.im));
+            G[k][q] = cd(s * (gkp.re * ph.re - gkp.im * ph.im) + c * gkq.re, s * (gkp.re * ph.im + gkp.im * ph.re) + c * gkq.im);
+            const cd ukp = U[k][p], ukq = U[k][q];
+            U[k][p] = cd(c * ukp.re - s * (ukq.re * ph.re + ukq.im * ph.im), c * ukp.im - s * (ukq.im * ph.re - ukq.re * ph.im));
+            U[k][q] = cd(s * (ukp.re * ph.re - ukp.im * ph.im) + c * ukq.re, s * (ukp.re * ph.im + ukp.im * ph.re) + c * ukq.im);
+          }
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const cd gpk = G[p][k], gqk = G[q][k];
+            G[p][k] = cd(c * gpk.re - s * (gqk.re * ph.re - gqk.im * ph.im), c * gpk.im - s * (gqk.re * ph.im + gqk.im * ph.re));
+            G[q][k] = cd(s * (gpk.re * ph.re + gpk.im * ph.im) + c * gqk.re, s * (gpk.im * ph.re - gpk.re * ph.im) + c * gqk.im);
+          }
+        }
+      }
+  }
+  // rank of each eigenvalue (descending, earlier index first on ties -- the selection order of the generic kernel)
+  const double inv_nl = 1.0 / sqrt((double)nl);
+#pragma unroll
+  for (int e = 0; e < NR; ++e) {
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) rank += (G[j][j].re > G[e][e].re || (G[j][j].re == G[e][e].re && j < e)) ? 1 : 0;
+    if (rank < nl) {
+      cd v[NT];
+      double nrm = 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        cd s(0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) nrx::cmacc(s, Hm[r][t], U[r][e]);
+        v[t] = s;
+        nrm += nrx::norm2(s);
+      }
+      const double sc = nrm > 0 ? inv_nl / sqrt(nrm) : 0.0;
+      if (lane == 0)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) F[((size_t)b * NT + t) * nl + rank] = cd(v[t].re * sc, v[t].im * sc);
+    }
+  }
+}
+
 // Hest[b][lk][r][p] = sum_t H[b][lk][r][t] * F[b][t][p]   ("perfect" CSI of the BLER notebook: H @ F)
 __global__ void __launch_bounds__(256)
 eff_channel_kernel(const cd* __restrict__ H, const cd* __restrict__ F, int64_t f_stride, int lk, int nr, int nt, int nl,
@@ -598,6 +724,16 @@ extern "C" int32_t nrx_svd_precoder_f64(const void* H_block, int32_t n_items, in
               "nrx_svd_precoder: Nr <= 8 and Nt <= 32 supported (got %dx%d)", n_rx, n_tx);
   NRX_REQUIRE(n_layers >= 1 && n_layers <= n_rx && n_layers <= n_tx, NRX_E_ARG, "nrx_svd_precoder: layers must be <= min(Nr,Nt)");
   if (n_items == 0) return NRX_OK;
+#define NRX_SVD_CASE(NR, NT)                                                                                        \
+  if (n_rx == NR && n_tx == NT) {                                                                                   \
+    hipLaunchKernelGGL((svd_precoder_wave_kernel<NR, NT>), dim3(n_items), dim3(64), 0, (hipStream_t)stream,         \
+                       (const cd*)H_block, n_avg, n_layers, (cd*)F, n_items);                                       \
+    NRX_CHECK_LAUNCH("nrx_svd_precoder");                                                                           \
+    return NRX_OK;                                                                                                  \
+  }
+  NRX_SVD_CASE(1, 1) NRX_SVD_CASE(1, 2) NRX_SVD_CASE(1, 4) NRX_SVD_CASE(2, 2) NRX_SVD_CASE(2, 4) NRX_SVD_CASE(4, 2)
+  NRX_SVD_CASE(4, 4) NRX_SVD_CASE(2, 8) NRX_SVD_CASE(4, 8) NRX_SVD_CASE(2, 1) NRX_SVD_CASE(4, 1)
+#undef NRX_SVD_CASE
   hipLaunchKernelGGL(svd_precoder_kernel, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const cd*)H_block,
                      n_avg, n_rx, n_tx, n_layers, (cd*)F, n_items);
   NRX_CHECK_LAUNCH("nrx_svd_precoder");

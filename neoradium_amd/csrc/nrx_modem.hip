@@ -65,16 +65,20 @@ qam_map_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, const uint
 // Max-log LLRs (useMax=True, the reference default).  The exhaustive max over the 2^qm points of
 // -|y-s|^2/s2 separates per axis for square QAM: bits on the real axis only see (Re y - a)^2 because the
 // imaginary-axis minimum is common to both hypotheses and cancels in the difference.
-template <typename T, typename TL>
+// QM is a template parameter: the per-axis minima live in registers and the level loop unrolls.  The float-output
+// (throughput) instantiation multiplies by 1/s2 instead of dividing twice per bit; the double-output one keeps the
+// reference's divisions so that it stays bit-identical to NumPy.
+template <typename T, typename TL, int QM>
 __global__ void __launch_bounds__(256)
 qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __restrict__ scales,
-                 const T* __restrict__ noise_var, int nv_stride, const uint8_t* __restrict__ scr, int qm,
-                 double scale, const int32_t* __restrict__ re_index, int n_sym, TL* __restrict__ llr,
-                 int64_t llr_stride, int n_batch, double nv_floor) {
-  __shared__ double lev[32];
-  const int h = qm / 2;
-  if (qm > 1 && (int)threadIdx.x < (1 << h)) lev[threadIdx.x] = (double)pam_level(threadIdx.x, h) * scale;
-  __syncthreads();
+                 const T* __restrict__ noise_var, int nv_stride, const uint8_t* __restrict__ scr, double scale,
+                 const int32_t* __restrict__ re_index, int n_sym, TL* __restrict__ llr, int64_t llr_stride,
+                 int n_batch, double nv_floor) {
+  constexpr int h = QM / 2;
+  constexpr bool RECIP = sizeof(TL) == 4;
+  double lev[h > 0 ? (1 << h) : 1];
+#pragma unroll
+  for (int a = 0; a < (1 << h); ++a) lev[a] = (double)pam_level(a, h) * scale;
   const int64_t total = (int64_t)n_batch * n_sym;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(g / n_sym), i = (int)(g - (int64_t)b * n_sym);
@@ -83,33 +87,49 @@ qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __
     double nv = (double)noise_var[(size_t)b * nv_stride];
     nv = nv > nv_floor ? nv : nv_floor;  // pdsch.py:966 max(noiseVar, 1e-10)
     const double sc = scales ? (double)scales[(size_t)b * sym_stride + src] : 1.0;
-    TL* dst = llr + (size_t)b * llr_stride + (size_t)i * qm;
-    if (qm == 1) {
+    const double rn = RECIP ? sc / nv : 0.0;
+    TL* dst = llr + (size_t)b * llr_stride + (size_t)i * QM;
+    if constexpr (QM == 1) {
       const double d0 = ((double)y.re - scale) * ((double)y.re - scale) + ((double)y.im - scale) * ((double)y.im - scale);
       const double d1 = ((double)y.re + scale) * ((double)y.re + scale) + ((double)y.im + scale) * ((double)y.im + scale);
       double l = (-d0 / nv) - (-d1 / nv);
       if (scr) l *= (double)(1 - 2 * (int)(scr[i] & 1));
       dst[0] = (TL)(l * sc);
-      continue;
-    }
-    for (int axis = 0; axis < 2; ++axis) {
-      const double yv = axis == 0 ? (double)y.re : (double)y.im;
-      double m0[5], m1[5];
-      for (int q = 0; q < h; ++q) m0[q] = m1[q] = 1e300;
-      for (int a = 0; a < (1 << h); ++a) {
-        const double d = yv - lev[a];
-        const double d2 = d * d;
+    } else {
+      TL out[QM];
+#pragma unroll
+      for (int axis = 0; axis < 2; ++axis) {
+        const double yv = axis == 0 ? (double)y.re : (double)y.im;
+        double m0[h], m1[h];
+#pragma unroll
+        for (int q = 0; q < h; ++q) m0[q] = m1[q] = 1e300;
+#pragma unroll
+        for (int a = 0; a < (1 << h); ++a) {
+          const double d = yv - lev[a];
+          const double d2 = d * d;
+#pragma unroll
+          for (int q = 0; q < h; ++q) {
+            if ((a >> (h - 1 - q)) & 1) m1[q] = d2 < m1[q] ? d2 : m1[q];
+            else m0[q] = d2 < m0[q] ? d2 : m0[q];
+          }
+        }
+#pragma unroll
         for (int q = 0; q < h; ++q) {
-          if ((a >> (h - 1 - q)) & 1) m1[q] = d2 < m1[q] ? d2 : m1[q];
-          else m0[q] = d2 < m0[q] ? d2 : m0[q];
+          const int pos = 2 * q + axis;  // bit index inside the symbol
+          double l;
+          if constexpr (RECIP) {
+            l = (m1[q] - m0[q]) * rn;                        // = ((-m0/nv) - (-m1/nv)) * sc up to rounding
+            if (scr) l = (scr[(size_t)i * QM + pos] & 1) ? -l : l;
+          } else {
+            l = (-m0[q] / nv) - (-m1[q] / nv);               // modulation.py:200-202, positive = bit 0
+            if (scr) l *= (double)(1 - 2 * (int)(scr[(size_t)i * QM + pos] & 1));  // pdsch.py:611-616
+            l = l * sc;                                                              // pdsch.py:1002-1003
+          }
+          out[pos] = (TL)l;
         }
       }
-      for (int q = 0; q < h; ++q) {
-        const int pos = 2 * q + axis;  // bit index inside the symbol
-        double l = (-m0[q] / nv) - (-m1[q] / nv);  // modulation.py:200-202, positive = bit 0
-        if (scr) l *= (double)(1 - 2 * (int)(scr[(size_t)i * qm + pos] & 1));  // pdsch.py:611-616
-        dst[pos] = (TL)(l * sc);                                               // pdsch.py:1002-1003
-      }
+#pragma unroll
+      for (int q = 0; q < QM; ++q) dst[q] = out[q];
     }
   }
 }
@@ -192,10 +212,24 @@ int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, co
     hipLaunchKernelGGL((qam_demap_exact_kernel<T, TL>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,
                        sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qm, qam_scale(qm), re_index,
                        n_sym, (TL*)llr, llr_stride, n_batch, nv_floor);
-  else
-    hipLaunchKernelGGL((qam_demap_kernel<T, TL>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,
-                       sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qm, qam_scale(qm), re_index,
-                       n_sym, (TL*)llr, llr_stride, n_batch, nv_floor);
+  else {
+#define NRX_DEMAP_CASE(Q)                                                                                              \
+  case Q:                                                                                                              \
+    hipLaunchKernelGGL((qam_demap_kernel<T, TL, Q>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,      \
+                       sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qam_scale(Q), re_index,      \
+                       n_sym, (TL*)llr, llr_stride, n_batch, nv_floor);                                                \
+    break;
+    switch (qm) {
+      NRX_DEMAP_CASE(1)
+      NRX_DEMAP_CASE(2)
+      NRX_DEMAP_CASE(4)
+      NRX_DEMAP_CASE(6)
+      NRX_DEMAP_CASE(8)
+      NRX_DEMAP_CASE(10)
+      default: NRX_REQUIRE(false, NRX_E_ARG, "nrx_qam_demap: unsupported qm=%d", qm);
+    }
+#undef NRX_DEMAP_CASE
+  }
   NRX_CHECK_LAUNCH("nrx_qam_demap");
   return NRX_OK;
 }
