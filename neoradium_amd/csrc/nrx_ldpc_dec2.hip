@@ -362,9 +362,11 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         // byte addresses of element z of column 0 / buffer 0 of this slot: plain, wrapped (- Zc), and both + HI
         // (four live registers; everything else of an address is a DS immediate)
         const uint32_t zb = zb0, zbw = zb0 - zc4, zbh = zb0 + HI, zbwh = zb0 - zc4 + HI;
+        float t[D];
+        float a1 = 0.0f, a2 = 0.0f;
+        uint32_t px = 0, word = 0;
         if (live) {   // (wave-uniform; the per-layer branch also keeps each layer its own scheduling region)
           // ---- pass 1a: issue every LDS read of the layer
-          float t[D];
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
@@ -383,7 +385,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           __builtin_amdgcn_sched_barrier(0);
           // ---- old state.  Sign/argmin word of the layer: sign of edge j at bit j of its field, argmin above.
           const float om1 = m1[L], om2 = m2[L];
-          uint32_t word, oidx;
+          uint32_t oidx;
           int top;   // left shift that brings bit 0 of the field to bit 31
           if constexpr (WIDE) {
             word = sgw[Y::wide_idx(L)];
@@ -426,8 +428,9 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             epf[slot] = ext_load(Ln, z4);
           }
           // ---- min-sum: two smallest magnitudes and the sign parity; no compares, no argmin here
-          float a1 = __builtin_fabsf(t[0]), a2 = 3.0e38f;
-          uint32_t px = __float_as_uint(t[0]);
+          a1 = __builtin_fabsf(t[0]);
+          a2 = 3.0e38f;
+          px = __float_as_uint(t[0]);
           static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value + 1;
             const float a = __builtin_fabsf(t[j]);
@@ -446,6 +449,8 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             const float q = __builtin_fabsf(v + 100000.0f);
             a2 = (a2 > 5.0e4f && q < a2) ? q : a2;
           }
+        }
+        if (live) {   // (second region: measured slightly faster than one region per layer)
           const float nm1 = a1 * 0.75f, nm2 = a2 * 0.75f;
           m1[L] = nm1;
           m2[L] = nm2;
