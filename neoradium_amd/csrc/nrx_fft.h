@@ -1,4 +1,5 @@
-// Workgroup FFT in LDS (radix-2 decimation-in-frequency, in place, bit-reversed output) for gfx950.
+// Workgroup FFT in LDS (radix-2 decimation-in-frequency with 4 stages fused per pass, in place, bit-reversed
+// output) for gfx950.
 // Shared by OFDM modulation/demodulation and the CIR -> channel-matrix transform.
 #pragma once
 #include "nrx_cplx.h"
@@ -15,24 +16,54 @@ __device__ __forceinline__ void fft_fill_twiddles(cx<T>* tw, int n) {
   }
 }
 
+// LG consecutive radix-2 DIF stages (starting at stage s) fused in registers: a thread loads the 2^LG points that
+// only interact with each other during those stages, runs the butterflies, stores them back.  Same arithmetic and
+// same (bit-reversed) result order as stage-by-stage radix-2, but one LDS round trip and one barrier per LG stages.
+template <typename T, int LG>
+__device__ __forceinline__ void fft_dif_fused(cx<T>* buf, const cx<T>* tw, int n, int log2n, int s, bool inverse) {
+  constexpr int P = 1 << LG;
+  const int lq = log2n - s - LG;   // log2 of the point spacing q
+  const int q = 1 << lq;
+  for (int gi = threadIdx.x; gi < (n >> LG); gi += blockDim.x) {
+    const int lo = gi & (q - 1);
+    const int a = ((gi >> lq) << (lq + LG)) | lo;
+    cx<T> x[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) x[m] = buf[a + (m << lq)];
+#pragma unroll
+    for (int t = 0; t < LG; ++t) {
+      constexpr int dummy = 0;
+      const int half = P >> (t + 1);   // partner distance in m
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        if (m & half) continue;        // m is the upper element of its pair
+        const int j = (lo + ((m & (half - 1)) << lq)) << (s + t + dummy);
+        cx<T> w = tw[j];
+        if (inverse) w.im = -w.im;
+        const cx<T> u = x[m], v = x[m + half];
+        x[m] = u + v;
+        x[m + half] = (u - v) * w;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < P; ++m) buf[a + (m << lq)] = x[m];
+  }
+  __syncthreads();
+}
+
 // In-place DIF FFT of buf[0..n): X[k] ends up at buf[bitrev(k)].  inverse: conjugated twiddles, no scaling.
 // All threads of the workgroup must call it; it ends with a barrier.
 template <typename T>
 __device__ __forceinline__ void fft_dif_lds(cx<T>* buf, const cx<T>* tw, int n, int log2n, bool inverse) {
-  for (int s = 0; s < log2n; ++s) {
-    const int hb = log2n - 1 - s;  // log2 of the half span
-    const int h = 1 << hb;
-    for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
-      const int j = i & (h - 1);
-      const int a = ((i >> hb) << (hb + 1)) + j, b = a + h;
-      const cx<T> u = buf[a], v = buf[b];
-      cx<T> w = tw[j << s];
-      if (inverse) w.im = -w.im;
-      buf[a] = u + v;
-      buf[b] = (u - v) * w;
-    }
-    __syncthreads();
+  int s = 0;
+  while (log2n - s >= 4) {
+    fft_dif_fused<T, 4>(buf, tw, n, log2n, s, inverse);
+    s += 4;
   }
+  const int rem = log2n - s;
+  if (rem == 3) fft_dif_fused<T, 3>(buf, tw, n, log2n, s, inverse);
+  else if (rem == 2) fft_dif_fused<T, 2>(buf, tw, n, log2n, s, inverse);
+  else if (rem == 1) fft_dif_fused<T, 1>(buf, tw, n, log2n, s, inverse);
 }
 
 __device__ __forceinline__ int fft_bitrev(int k, int log2n) { return (int)(__brev((unsigned)k) >> (32 - log2n)); }

@@ -267,7 +267,19 @@ random_bits_kernel(uint8_t* __restrict__ out, int64_t n_per, int n_batch, uint64
     philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     uint8_t* dst = out + (size_t)b * n_per + w * 128;
     const int64_t lim = n_per - w * 128 < 128 ? n_per - w * 128 : 128;
-    for (int i = 0; i < lim; ++i) dst[i] = (uint8_t)((c[i >> 5] >> (i & 31)) & 1u);
+    if (lim == 128 && ((uintptr_t)dst & 7u) == 0) {
+      // 8 bits -> 8 bytes per store: nibble * 0x00204081 puts bit k of the nibble at bit 8k
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const uint32_t byte = (c[q >> 2] >> (8 * (q & 3))) & 0xffu;
+        uint2 v;
+        v.x = ((byte & 15u) * 0x00204081u) & 0x01010101u;
+        v.y = ((byte >> 4) * 0x00204081u) & 0x01010101u;
+        *reinterpret_cast<uint2*>(dst + 8 * q) = v;
+      }
+    } else {
+      for (int i = 0; i < lim; ++i) dst[i] = (uint8_t)((c[i >> 5] >> (i & 31)) & 1u);
+    }
   }
 }
 

@@ -352,23 +352,44 @@ crc_ok_rows_kernel(const uint8_t* __restrict__ bits, int64_t row_len, int64_t ro
 __global__ void __launch_bounds__(256)
 count_errors_kernel(const uint8_t* __restrict__ cb_ok, int n_ok, const uint8_t* __restrict__ tb_out,
                     const uint8_t* __restrict__ tb_ref, int n_tb, int A, int stride, unsigned long long* counters) {
+  // grid: (x-blocks, n_tb).  Row blockIdx.y of the transport blocks is compared 8 bytes (= 8 bits) at a time.
   unsigned long long be = 0, bits = 0;
+  const int t = blockIdx.y;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = gtid; i < n_ok; i += gsz) be += cb_ok[i] ? 0 : 1;
-  if (tb_out && tb_ref)
-    for (int64_t i = gtid; i < (int64_t)n_tb * A; i += gsz) {
-      const int t = (int)(i / A), k = (int)(i - (int64_t)t * A);
-      bits += ((tb_out[(size_t)t * stride + k] ^ tb_ref[i]) & 1) ? 1 : 0;
+  if (t == 0)
+    for (int64_t i = gtid; i < n_ok; i += gsz) be += cb_ok[i] ? 0 : 1;
+  if (tb_out && tb_ref) {
+    const uint8_t* a = tb_out + (size_t)t * stride;
+    const uint8_t* r = tb_ref + (size_t)t * A;
+    if ((((uintptr_t)a | (uintptr_t)r) & 7u) == 0) {
+      const int n8 = A >> 3;
+      for (int64_t i = gtid; i < n8; i += gsz) {
+        const unsigned long long x = *reinterpret_cast<const unsigned long long*>(a + 8 * i) ^
+                                     *reinterpret_cast<const unsigned long long*>(r + 8 * i);
+        bits += __popcll(x & 0x0101010101010101ull);
+      }
+      for (int64_t k = (int64_t)n8 * 8 + gtid; k < A; k += gsz) bits += ((a[k] ^ r[k]) & 1) ? 1 : 0;
+    } else {
+      for (int64_t k = gtid; k < A; k += gsz) bits += ((a[k] ^ r[k]) & 1) ? 1 : 0;
     }
+  }
   for (int o = 32; o > 0; o >>= 1) {
     be += __shfl_xor(be, o, 64);
     bits += __shfl_xor(bits, o, 64);
   }
+  __shared__ unsigned long long red[2][4];   // one atomic per workgroup (they all hit the same two words)
   if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = be;
+    red[1][threadIdx.x >> 6] = bits;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    be = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    bits = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     if (be) atomicAdd(&counters[0], be);
     if (bits) atomicAdd(&counters[2], bits);
   }
-  if (gtid == 0) {
+  if (gtid == 0 && t == 0) {
     atomicAdd(&counters[1], (unsigned long long)n_ok);
     if (tb_out && tb_ref) atomicAdd(&counters[3], (unsigned long long)n_tb * A);
   }
@@ -519,9 +540,13 @@ extern "C" int32_t nrx_count_errors(const uint8_t* cb_ok, int32_t n_ok, const ui
   NRX_REQUIRE(cb_ok && counters, NRX_E_ARG, "nrx_count_errors: NULL buffer");
   NRX_REQUIRE((tb_out == nullptr) == (tb_ref == nullptr), NRX_E_ARG, "nrx_count_errors: tb_out and tb_ref go together");
   NRX_REQUIRE(!tb_out || tb_out_stride >= A, NRX_E_SHAPE, "nrx_count_errors: stride < A");
-  const long work = (long)n_tb * A > n_ok ? (long)n_tb * A : n_ok;
-  hipLaunchKernelGGL(count_errors_kernel, dim3(nrx::stream_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, cb_ok,
-                     n_ok, tb_out, tb_ref, n_tb, A, tb_out_stride, (unsigned long long*)counters);
+  const int rows = (tb_out && n_tb > 0) ? n_tb : 1;
+  long per_row = tb_out ? ((long)A + 7) / 8 : 0;
+  if (per_row < n_ok) per_row = n_ok;
+  int gx = nrx::stream_grid(per_row, 256);
+  if (gx > 16) gx = 16;
+  hipLaunchKernelGGL(count_errors_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, cb_ok, n_ok, tb_out,
+                     tb_ref, n_tb, A, tb_out_stride, (unsigned long long*)counters);
   NRX_CHECK_LAUNCH("nrx_count_errors");
   return NRX_OK;
 }
