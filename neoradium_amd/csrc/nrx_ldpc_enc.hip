@@ -281,6 +281,65 @@ rate_match_kernel(const uint8_t* __restrict__ coded, int n_tb, RmGeom g, uint8_t
   }
 }
 
+// One (x-strip, code block) per workgroup and the modulation order as a template parameter: no 64-bit divisions,
+// a thread handles the QM bits of one modulation symbol (consecutive output bytes), and for a fixed bit plane the
+// lanes read consecutive coded bits.
+template <int QM>
+__global__ void __launch_bounds__(256)
+rate_match_cb_kernel(const uint8_t* __restrict__ coded, RmGeom g, uint8_t* __restrict__ out) {
+  const int cbi = blockIdx.y;
+  const int t = cbi / g.C, r = cbi - t * g.C;
+  int E, off;
+  if (r < g.n_small) { E = g.e_small; off = r * g.e_small; }
+  else { E = g.e_small + g.f; off = g.n_small * g.e_small + (r - g.n_small) * E; }
+  const int eq = E / QM;
+  const uint8_t* src = coded + (size_t)cbi * g.N;
+  uint8_t* dst = out + (size_t)t * g.G + off;
+  for (int sidx = blockIdx.x * blockDim.x + threadIdx.x; sidx < eq; sidx += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+      const int e = q * eq + sidx;
+      const int ci = (e + g.k0) % g.cs;
+      dst[sidx * QM + q] = src[ci < g.sys_len ? ci : ci + g.F];
+    }
+  }
+}
+
+// Rate recovery without wrap-around repetition (E_r <= circular buffer): every buffer position receives at most one
+// LLR, so the de-interleaver can run as a coalesced scatter; untransmitted positions, fillers and the part of the
+// code block beyond a limited buffer are filled by the same workgroup.  Same sums as rate_recover_kernel.
+template <typename T, int QM>
+__global__ void __launch_bounds__(256)
+rate_recover_cb_kernel(const T* __restrict__ llr, int llr_len, RmGeom g, T* __restrict__ circ, T* __restrict__ out) {
+  const int cbi = blockIdx.y;
+  const int t = cbi / g.C, r = cbi - t * g.C;
+  int E, off;
+  if (r < g.n_small) { E = g.e_small; off = r * g.e_small; }
+  else { E = g.e_small + g.f; off = g.n_small * g.e_small + (r - g.n_small) * E; }
+  const int eq = E / QM;
+  const T* src = llr + (size_t)t * llr_len;
+  T* dst = out + (size_t)cbi * g.N;
+  T* cb = circ ? circ + (size_t)cbi * g.cs : nullptr;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int sidx = tid; sidx < eq; sidx += nth) {
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+      const int e = q * eq + sidx;
+      const int ci = (e + g.k0) % g.cs;
+      const int j = off + sidx * QM + q;
+      T v = j < llr_len ? src[j] : (T)0;   // short input is zero padded (ldpc.py:1401-1402)
+      if (cb) { v = cb[ci] + v; cb[ci] = v; }
+      dst[ci < g.sys_len ? ci : ci + g.F] = v;
+    }
+  }
+  for (int e = E + tid; e < g.cs; e += nth) {             // buffer positions this transmission did not reach
+    const int ci = (e + g.k0) % g.cs;
+    dst[ci < g.sys_len ? ci : ci + g.F] = cb ? cb[ci] : (T)0;
+  }
+  for (int i = tid; i < g.F; i += nth) dst[g.sys_len + i] = (T)1e20;   // LARGE_LLR fillers (ldpc.py:1414-1418)
+  for (int n = g.cs + g.F + tid; n < g.N; n += nth) dst[n] = (T)0;      // beyond a limited (LBRM) buffer
+}
+
 // -------------------------------------------------------------------------------- nrx_ldpc_rate_recover
 // ldpc.py:1330-1418 as a gather: one thread per (code block, coded position).  Accumulation order over the
 // wrap-around repetitions follows the reference (increasing e), so float sums are bit-identical.
@@ -485,6 +544,24 @@ extern "C" int32_t nrx_ldpc_rate_match(const uint8_t* coded, int32_t n_tb, const
   RmGeom g;
   fill_geom(cfg, G, nl, qm, rv, n_ref, &g);
   g.G = ((G + nl * qm - 1) / (nl * qm)) * (nl * qm);  // = sum of E_r (ldpc.py:852-855); equals G for PDSCH
+  {
+    const int eq_max = (g.e_small + g.f) / qm;
+    const dim3 grid2((eq_max + 255) / 256 > 8 ? 8 : (eq_max + 255) / 256, n_tb * cfg->C);
+    bool done = true;
+    switch (qm) {
+      case 1: hipLaunchKernelGGL(rate_match_cb_kernel<1>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
+      case 2: hipLaunchKernelGGL(rate_match_cb_kernel<2>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
+      case 4: hipLaunchKernelGGL(rate_match_cb_kernel<4>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
+      case 6: hipLaunchKernelGGL(rate_match_cb_kernel<6>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
+      case 8: hipLaunchKernelGGL(rate_match_cb_kernel<8>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
+      case 10: hipLaunchKernelGGL(rate_match_cb_kernel<10>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
+      default: done = false;
+    }
+    if (done) {
+      NRX_CHECK_LAUNCH("nrx_ldpc_rate_match");
+      return NRX_OK;
+    }
+  }
   hipLaunchKernelGGL(rate_match_kernel, dim3(nrx::stream_grid((long)n_tb * g.G, 256)), dim3(256), 0, (hipStream_t)stream,
                      coded, n_tb, g, out);
   NRX_CHECK_LAUNCH("nrx_ldpc_rate_match");
@@ -500,6 +577,24 @@ static int32_t rate_recover_entry(const T* llr, int32_t n_tb, int32_t llr_len, c
   if (n_tb == 0) return NRX_OK;
   RmGeom g;
   fill_geom(cfg, llr_len, nl, qm, rv, n_ref, &g);
+  if (g.e_small + g.f <= g.cs) {   // no wrap-around repetition: coalesced scatter form
+    const dim3 grid2(8, n_tb * cfg->C);
+    hipStream_t st = (hipStream_t)stream;
+    bool done = true;
+    switch (qm) {
+      case 1: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 1>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
+      case 2: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 2>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
+      case 4: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 4>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
+      case 6: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 6>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
+      case 8: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 8>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
+      case 10: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 10>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
+      default: done = false;
+    }
+    if (done) {
+      NRX_CHECK_LAUNCH("nrx_ldpc_rate_recover");
+      return NRX_OK;
+    }
+  }
   hipLaunchKernelGGL(rate_recover_kernel<T>, dim3(nrx::stream_grid((long)n_tb * cfg->C * cfg->N, 256)), dim3(256), 0,
                      (hipStream_t)stream, llr, n_tb, llr_len, g, circ, out);
   NRX_CHECK_LAUNCH("nrx_ldpc_rate_recover");

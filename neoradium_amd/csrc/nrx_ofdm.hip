@@ -20,14 +20,21 @@ struct SymGeom {
 template <typename T>
 __global__ void __launch_bounds__(256)
 ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
-                cx<T>* __restrict__ wave, int64_t wave_stride /* samples per (item, port) row */) {
+                cx<T>* __restrict__ wave, int64_t wave_stride /* samples per (item, port) row */,
+                const cx<T>* __restrict__ f, int64_t f_stride, int nl, int ports) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
   cx<T>* tw = buf + nfft;
   cx<T>* tail = tw + nfft / 2;  // [w] windowed tail of the previous symbol
   cx<T>* head0 = tail + w;      // [w] windowed head of symbol 0 (completed by the last symbol's tail)
   const int row = blockIdx.x;   // item * ports + port
-  const cx<T>* src = grid + (size_t)row * g.n_sym * K;
+  // f != null: the grid holds `nl` layers per item and this row is antenna port `row % ports` of the wideband
+  // precoder F (Grid.precode, grid.py:505-516, fused into the load): x_port = sum_n F[port][n] * layer_n
+  const int item = f ? row / ports : 0, port = f ? row % ports : 0;
+  const cx<T>* src = f ? grid + (size_t)item * nl * g.n_sym * K : grid + (size_t)row * g.n_sym * K;
+  cx<double> fw[8];
+  if (f)
+    for (int n = 0; n < nl; ++n) fw[n] = cx<double>(f[(size_t)item * f_stride + (size_t)port * nl + n]);
   cx<T>* dst = wave + (size_t)row * wave_stride;
   nrx::fft_fill_twiddles(tw, nfft);
   const int pad_lo = (nfft - K + 1) / 2;  // grid.py:543
@@ -38,7 +45,17 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
     for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
       const int j = (i + nfft / 2) & (nfft - 1);
       const int k = j - pad_lo;
-      buf[i] = (k >= 0 && k < K) ? src[(size_t)l * K + k] : cx<T>(0, 0);
+      cx<T> v(0, 0);
+      if (k >= 0 && k < K) {
+        if (f) {
+          cx<double> acc(0, 0);
+          for (int n = 0; n < nl; ++n) nrx::cmac(acc, fw[n], cx<double>(src[((size_t)n * g.n_sym + l) * K + k]));
+          v = cx<T>(acc);
+        } else {
+          v = src[(size_t)l * K + k];
+        }
+      }
+      buf[i] = v;
     }
     __syncthreads();
     nrx::fft_dif_lds(buf, tw, nfft, log2n, true);
@@ -136,8 +153,11 @@ int32_t fill_geom(const int32_t* cp_lens, int32_t n_sym, int32_t nfft, SymGeom* 
 
 template <typename T>
 int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
-                  int32_t window_len, void* wave, int64_t wave_stride, void* stream) {
+                  int32_t window_len, void* wave, int64_t wave_stride, void* stream, const void* f = nullptr,
+                  int64_t f_stride = 0, int32_t nl = 0, int32_t ports = 1) {
   NRX_REQUIRE(grid && wave, NRX_E_ARG, "nrx_ofdm_modulate: NULL buffer");
+  NRX_REQUIRE(!f || (nl >= 1 && nl <= 8 && ports >= 1 && n_rows % ports == 0), NRX_E_ARG,
+              "nrx_ofdm_modulate_precoded: bad layer / port counts");
   SymGeom g;
   int slot_len;
   int32_t rc = fill_geom(cp_lens, n_sym, nfft, &g, &slot_len);
@@ -153,7 +173,7 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
   auto kern = ofdm_mod_kernel<T>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(n_rows), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft, ilog2(nfft), g,
-                     window_len, slot_len, (cx<T>*)wave, wave_stride);
+                     window_len, slot_len, (cx<T>*)wave, wave_stride, (const cx<T>*)f, f_stride, nl, ports);
   NRX_CHECK_LAUNCH("nrx_ofdm_modulate");
   return NRX_OK;
 }
@@ -186,5 +206,7 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
 
 extern "C" int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<float>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
 extern "C" int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
+extern "C" int32_t nrx_ofdm_modulate_precoded_f32(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); return mod_entry<float>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports); }
+extern "C" int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); return mod_entry<double>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports); }
 extern "C" int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }
 extern "C" int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }

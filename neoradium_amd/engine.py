@@ -174,20 +174,19 @@ class PdschLink:
         cir1, off = ops.cir(gains1, self.coeff, self.L)
         hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
         F = ops.svd_precoder(hsub, self.nl)                                     # wideband SVD precoder (first PRB)
-        pg = ops.precode(grid, F)
         H = None
         if self.freqDomain or self.chanEst == "Perfect":
             H = ops.channel_matrix(cir1, off, self.L, self.K, self.nfft)
 
         if self.freqDomain:
-            rx = ops.apply_channel_fd(pg, H)
+            rx = ops.apply_channel_fd(ops.precode(grid, F), H)
             _, sigma, nv = ops.noise_level(rx, snr_lin=snr_lin)                 # grid.py:1040-1046
             rxg = ops.add_noise(rx, noise.to(dev), sigma) if noise is not None else \
                 ops.awgn(rx, sigma, seed, stream_id=2, batch_offset=int(slots[0]))
         else:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
-            tx = ops.ofdm_modulate(pg, self.nfft, cps, window_len=w, pad=self.max_delay)
+            tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay, f=F)   # precoder fused
             ry = ops.apply_td_paths(tx, gains1, self.taps, self.tap_off, [int(v) for v in self.sym_lens[sis]])
             width = ry.shape[-1]
             _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=self.nfft / (12.0 * self.bwp.numRbs),

@@ -342,17 +342,36 @@ def awgn(x, sigma, seed, stream_id=0, batch_offset=0):
 
 
 # -------------------------------------------------------------------------------------------------------- OFDM
-def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0):
-    """Grid.ofdmModulate (+windowing): (n,P,L,K) -> (n,P,slotLen+pad) (the pad samples are zeros, Waveform.pad)."""
+def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0, f=None):
+    """Grid.ofdmModulate (+windowing): (n,P,L,K) -> (n,P,slotLen+pad) (the pad samples are zeros, Waveform.pad).
+
+    With ``f`` (Nt,Nl) or (n,Nt,Nl) the grid holds Nl layers and the wideband precoder is applied while loading
+    (Grid.precode fused; output has Nt rows per item)."""
     grid = grid.contiguous()
     sfx, _ = _ct(grid)
     n, P, L, K = grid.shape
     if len(cp_lens) != L:
         raise ValueError("one CP length per OFDM symbol is required")
     S = int(sum(cp_lens)) + L * nfft
-    wave = torch.zeros((n, P, S + pad), dtype=grid.dtype, device=_dev(grid))
-    fn = getattr(lib(), 'nrx_ofdm_modulate_' + sfx)
-    check(fn(ptr(grid), n * P, K, nfft, _host_i32(cp_lens), L, int(window_len), ptr(wave), S + pad, stream()))
+    dev = _dev(grid)
+    if f is not None:
+        f = f.to(grid.dtype).contiguous()
+        shared = f.dim() == 2
+        nt = f.shape[-2]
+        if f.shape[-1] != P or (not shared and f.shape[0] != n):
+            raise ValueError("The last dimension of 'f' (%d) must match the first dimension of the grid (%d)" % (f.shape[-1], P))
+    else:
+        nt = P
+    wave = torch.empty((n, nt, S + pad), dtype=grid.dtype, device=dev)
+    if pad:
+        wave[:, :, S:].zero_()
+    if f is None:
+        fn = getattr(lib(), 'nrx_ofdm_modulate_' + sfx)
+        check(fn(ptr(grid), n * P, K, nfft, _host_i32(cp_lens), L, int(window_len), ptr(wave), S + pad, stream()))
+    else:
+        fn = getattr(lib(), 'nrx_ofdm_modulate_precoded_' + sfx)
+        check(fn(ptr(grid), n, P, nt, ptr(f), 0 if shared else nt * P, K, nfft, _host_i32(cp_lens), L, int(window_len),
+                 ptr(wave), S + pad, stream()))
     return wave
 
 
