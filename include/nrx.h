@@ -223,13 +223,17 @@ int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32
  * offset of item b at t_off[b*t_off_stride]. */
 /* Grid.precode (wideband F, grid.py:505-516) fused into the modulator's load: layers (n_items, n_layers, n_sym, K),
  * f: per item (f_stride = n_ports*n_layers) or shared (f_stride = 0) n_ports x n_layers; wave rows = item*n_ports+port.
- * Same arithmetic as nrx_precode_* followed by nrx_ofdm_modulate_*; the precoded grid is never materialised. */
+ * Same arithmetic as nrx_precode_* followed by nrx_ofdm_modulate_*; the precoded grid is never materialised.
+ * Symbols are transformed in parallel; tails_ws: caller-owned scratch of n_items*n_ports*n_sym*window_len complex
+ * samples (may be NULL when window_len == 0) that carries the windowed symbol tails between the two launches. */
 int32_t nrx_ofdm_modulate_precoded_f32(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports,
                                        const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens,
-                                       int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream);
+                                       int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws,
+                                       void* stream);
 int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports,
                                        const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens,
-                                       int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream);
+                                       int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws,
+                                       void* stream);
 int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
                                 int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
                                 const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream);

@@ -102,11 +102,9 @@ chan_offset_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int nr, in
 // (channelmodel.py:381-399).  One LDS FFT per (b, c, rt); workgroups loop over tasks.
 __global__ void __launch_bounds__(256)
 chan_matrix_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int n_rt, int cl, const int32_t* __restrict__ off,
-                   int K, int nfft, int log2n, cd* __restrict__ H, int n_tasks) {
+                   int K, int nfft, int log2n, cd* __restrict__ H, int n_tasks, const cd* __restrict__ tw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* buf = (cd*)smem;
-  cd* tw = buf + nfft;
-  nrx::fft_fill_twiddles(tw, nfft);
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
     const int rt = task % n_rt;
     const int c = (task / n_rt) % nc;
@@ -396,10 +394,12 @@ extern "C" int32_t nrx_channel_matrix_f64(const void* cir, int32_t n_items, int3
   NRX_REQUIRE(K > 0 && K <= nfft && nc >= 1 && nc <= n_t && cl >= 1, NRX_E_SHAPE, "nrx_channel_matrix: bad sizes");
   const int n_tasks = n_items * nc * n_rx * n_tx;
   if (n_tasks == 0) return NRX_OK;
-  const size_t lds = sizeof(cd) * ((size_t)nfft + nfft / 2);
+  const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
+  NRX_REQUIRE(tw, NRX_E_HIP, "nrx_channel_matrix: FFT twiddle table unavailable");
+  const size_t lds = sizeof(cd) * (size_t)nfft;
   (void)hipFuncSetAttribute((const void*)chan_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(chan_matrix_kernel, dim3(n_tasks < 1024 ? n_tasks : 1024), dim3(256), lds, (hipStream_t)stream,
-                     (const cd*)cir, n_t, nc, n_rx * n_tx, cl, chan_offset, K, nfft, ilog2(nfft), (cd*)H, n_tasks);
+  hipLaunchKernelGGL(chan_matrix_kernel, dim3(n_tasks < 2048 ? n_tasks : 2048), dim3(256), lds, (hipStream_t)stream,
+                     (const cd*)cir, n_t, nc, n_rx * n_tx, cl, chan_offset, K, nfft, ilog2(nfft), (cd*)H, n_tasks, tw);
   NRX_CHECK_LAUNCH("nrx_channel_matrix");
   return NRX_OK;
 }

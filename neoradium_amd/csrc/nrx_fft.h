@@ -2,25 +2,25 @@
 // output) for gfx950.
 // Shared by OFDM modulation/demodulation and the CIR -> channel-matrix transform.
 #pragma once
+#include "nrx_common.h"
 #include "nrx_cplx.h"
 
 namespace nrx {
 
-// tw[k] = exp(-2*pi*i*k/n), k < n/2, evaluated with sincospi in float64 (exact quadrant handling).
-template <typename T>
-__device__ __forceinline__ void fft_fill_twiddles(cx<T>* tw, int n) {
-  for (int k = threadIdx.x; k < n / 2; k += blockDim.x) {
-    double s, c;
-    sincospi(2.0 * (double)k / (double)n, &s, &c);
-    tw[k] = cx<T>((T)c, (T)(-s));
-  }
-}
+// Twiddles: one device-resident table W[k] = exp(-2*pi*i*k/FFT_TW_N), k < FFT_TW_N/2, evaluated once with sincospi
+// in float64 (exact quadrant handling); an n-point transform uses every (FFT_TW_N/n)-th entry (power-of-two scaling
+// of the argument is exact, so the values equal exp(-2*pi*i*k/n) computed directly).  Kept in global memory (64 KB,
+// L1/L2 resident) so that an LDS FFT needs only its data buffer: two 4096-point float64 workgroups per CU.
+constexpr int FFT_TW_N = 8192;
+// Device pointer of the table; the first call fills it on `stream` and waits for that once (nrx_fft_tab.hip).
+const cx<double>* fft_twiddle_table(hipStream_t stream);
 
 // LG consecutive radix-2 DIF stages (starting at stage s) fused in registers: a thread loads the 2^LG points that
 // only interact with each other during those stages, runs the butterflies, stores them back.  Same arithmetic and
 // same (bit-reversed) result order as stage-by-stage radix-2, but one LDS round trip and one barrier per LG stages.
 template <typename T, int LG>
-__device__ __forceinline__ void fft_dif_fused(cx<T>* buf, const cx<T>* tw, int n, int log2n, int s, bool inverse) {
+__device__ __forceinline__ void fft_dif_fused(cx<T>* buf, const cx<double>* __restrict__ tw, int tws, int n, int log2n,
+                                              int s, bool inverse) {
   constexpr int P = 1 << LG;
   const int lq = log2n - s - LG;   // log2 of the point spacing q
   const int q = 1 << lq;
@@ -38,7 +38,8 @@ __device__ __forceinline__ void fft_dif_fused(cx<T>* buf, const cx<T>* tw, int n
       for (int m = 0; m < P; ++m) {
         if (m & half) continue;        // m is the upper element of its pair
         const int j = (lo + ((m & (half - 1)) << lq)) << (s + t + dummy);
-        cx<T> w = tw[j];
+        const cx<double> wd = tw[(size_t)j * tws];
+        cx<T> w((T)wd.re, (T)wd.im);
         if (inverse) w.im = -w.im;
         const cx<T> u = x[m], v = x[m + half];
         x[m] = u + v;
@@ -54,16 +55,18 @@ __device__ __forceinline__ void fft_dif_fused(cx<T>* buf, const cx<T>* tw, int n
 // In-place DIF FFT of buf[0..n): X[k] ends up at buf[bitrev(k)].  inverse: conjugated twiddles, no scaling.
 // All threads of the workgroup must call it; it ends with a barrier.
 template <typename T>
-__device__ __forceinline__ void fft_dif_lds(cx<T>* buf, const cx<T>* tw, int n, int log2n, bool inverse) {
+__device__ __forceinline__ void fft_dif_lds(cx<T>* buf, const cx<double>* __restrict__ tw, int n, int log2n,
+                                            bool inverse) {
+  const int tws = FFT_TW_N / n;
   int s = 0;
   while (log2n - s >= 4) {
-    fft_dif_fused<T, 4>(buf, tw, n, log2n, s, inverse);
+    fft_dif_fused<T, 4>(buf, tw, tws, n, log2n, s, inverse);
     s += 4;
   }
   const int rem = log2n - s;
-  if (rem == 3) fft_dif_fused<T, 3>(buf, tw, n, log2n, s, inverse);
-  else if (rem == 2) fft_dif_fused<T, 2>(buf, tw, n, log2n, s, inverse);
-  else if (rem == 1) fft_dif_fused<T, 1>(buf, tw, n, log2n, s, inverse);
+  if (rem == 3) fft_dif_fused<T, 3>(buf, tw, tws, n, log2n, s, inverse);
+  else if (rem == 2) fft_dif_fused<T, 2>(buf, tw, tws, n, log2n, s, inverse);
+  else if (rem == 1) fft_dif_fused<T, 1>(buf, tw, tws, n, log2n, s, inverse);
 }
 
 __device__ __forceinline__ int fft_bitrev(int k, int log2n) { return (int)(__brev((unsigned)k) >> (32 - log2n)); }

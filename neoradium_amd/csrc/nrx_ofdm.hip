@@ -21,11 +21,10 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
                 cx<T>* __restrict__ wave, int64_t wave_stride /* samples per (item, port) row */,
-                const cx<T>* __restrict__ f, int64_t f_stride, int nl, int ports) {
+                const cx<T>* __restrict__ f, int64_t f_stride, int nl, int ports, const cx<double>* __restrict__ tw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
-  cx<T>* tw = buf + nfft;
-  cx<T>* tail = tw + nfft / 2;  // [w] windowed tail of the previous symbol
+  cx<T>* tail = buf + nfft;     // [w] windowed tail of the previous symbol
   cx<T>* head0 = tail + w;      // [w] windowed head of symbol 0 (completed by the last symbol's tail)
   const int row = blockIdx.x;   // item * ports + port
   // f != null: the grid holds `nl` layers per item and this row is antenna port `row % ports` of the wideband
@@ -36,7 +35,6 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
   if (f)
     for (int n = 0; n < nl; ++n) fw[n] = cx<double>(f[(size_t)item * f_stride + (size_t)port * nl + n]);
   cx<T>* dst = wave + (size_t)row * wave_stride;
-  nrx::fft_fill_twiddles(tw, nfft);
   const int pad_lo = (nfft - K + 1) / 2;  // grid.py:543
   const double inv_n = 1.0 / (double)nfft;
   for (int l = 0; l < g.n_sym; ++l) {
@@ -102,11 +100,9 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t wave_len,
                   const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
-                  cx<T>* __restrict__ grid, int n_tasks) {
+                  cx<T>* __restrict__ grid, int n_tasks, const cx<double>* __restrict__ tw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
-  cx<T>* tw = buf + nfft;
-  nrx::fft_fill_twiddles(tw, nfft);
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
     const int l = task % g.n_sym;
     const int row = task / g.n_sym;  // item * n_ant + antenna
@@ -127,6 +123,79 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
       const int q = (k - K / 2 + nfft) & (nfft - 1);  // fftshift + centre K bins (waveform.py:514-520)
       dst[k] = buf[nrx::fft_bitrev(q, log2n)];
     }
+  }
+}
+
+// Symbol-parallel modulator (used by the precoded entry): one workgroup per (item, port, symbol).  The raised-cosine
+// overlap couples neighbouring symbols only through w samples: a workgroup writes its own windowed head to its final
+// place and parks its windowed tail in `tails`; ofdm_tail_add_kernel then adds tail l onto head l+1 (head + tail, the
+// order of the sequential kernel, so both produce identical samples).
+template <typename T>
+__global__ void __launch_bounds__(256)
+ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
+                    cx<T>* __restrict__ wave, int64_t wave_stride, const cx<T>* __restrict__ f, int64_t f_stride, int nl,
+                    int ports, const cx<double>* __restrict__ tw, cx<T>* __restrict__ tails) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cx<T>* buf = (cx<T>*)smem;
+  const int l = blockIdx.x % g.n_sym;
+  const int row = blockIdx.x / g.n_sym;   // item * ports + port
+  const int item = f ? row / ports : 0, port = f ? row % ports : 0;
+  const cx<T>* src = f ? grid + (size_t)item * nl * g.n_sym * K : grid + (size_t)row * g.n_sym * K;
+  cx<double> fw[8];
+  if (f)
+    for (int n = 0; n < nl; ++n) fw[n] = cx<double>(f[(size_t)item * f_stride + (size_t)port * nl + n]);
+  cx<T>* dst = wave + (size_t)row * wave_stride;
+  const int pad_lo = (nfft - K + 1) / 2;  // grid.py:543
+  const double inv_n = 1.0 / (double)nfft;
+  for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
+    const int j = (i + nfft / 2) & (nfft - 1);
+    const int k = j - pad_lo;
+    cx<T> v(0, 0);
+    if (k >= 0 && k < K) {
+      if (f) {
+        cx<double> acc(0, 0);
+        for (int n = 0; n < nl; ++n) nrx::cmac(acc, fw[n], cx<double>(src[((size_t)n * g.n_sym + l) * K + k]));
+        v = cx<T>(acc);
+      } else {
+        v = src[(size_t)l * K + k];
+      }
+    }
+    buf[i] = v;
+  }
+  __syncthreads();
+  nrx::fft_dif_lds(buf, tw, nfft, log2n, true);
+  const int cp = g.cp[l], n_l = cp + nfft;
+  for (int i = threadIdx.x; i < n_l + w; i += blockDim.x) {
+    const int t = (i - w - cp + 2 * nfft) & (nfft - 1);
+    const cx<T> x = buf[nrx::fft_bitrev(t, log2n)];
+    double win = 1.0;
+    if (i < w) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * i) / (double)(2 * w)));
+    else if (i >= n_l) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * (n_l + w - 1 - i)) / (double)(2 * w)));
+    const cx<T> v((T)((double)x.re * inv_n * win), (T)((double)x.im * inv_n * win));
+    if (i >= n_l) {
+      tails[((size_t)row * g.n_sym + l) * w + (i - n_l)] = v;
+    } else {
+      int pos = g.start[l] + i - w;  // roll(-w) of waveform.py:467
+      if (pos < 0) pos += slot_len;
+      dst[pos] = v;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+ofdm_tail_add_kernel(cx<T>* __restrict__ wave, int64_t wave_stride, SymGeom g, int w, int slot_len,
+                     const cx<T>* __restrict__ tails, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % w);
+    const int64_t rl = i / w;
+    const int l = (int)(rl % g.n_sym);
+    const int64_t row = rl / g.n_sym;
+    const int ln = (l + 1) % g.n_sym;      // the last symbol's tail wraps onto the slot start (waveform.py:462-465)
+    int pos = g.start[ln] + q - w;
+    if (pos < 0) pos += slot_len;
+    cx<T>* d = wave + (size_t)row * wave_stride + pos;
+    *d = *d + tails[i];
   }
 }
 
@@ -154,7 +223,7 @@ int32_t fill_geom(const int32_t* cp_lens, int32_t n_sym, int32_t nfft, SymGeom* 
 template <typename T>
 int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
                   int32_t window_len, void* wave, int64_t wave_stride, void* stream, const void* f = nullptr,
-                  int64_t f_stride = 0, int32_t nl = 0, int32_t ports = 1) {
+                  int64_t f_stride = 0, int32_t nl = 0, int32_t ports = 1, void* tails = nullptr) {
   NRX_REQUIRE(grid && wave, NRX_E_ARG, "nrx_ofdm_modulate: NULL buffer");
   NRX_REQUIRE(!f || (nl >= 1 && nl <= 8 && ports >= 1 && n_rows % ports == 0), NRX_E_ARG,
               "nrx_ofdm_modulate_precoded: bad layer / port counts");
@@ -169,11 +238,28 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
   NRX_REQUIRE(window_len >= 0 && (window_len == 0 || window_len < wmin), NRX_E_ARG,
               "nrx_ofdm_modulate: The windowing size must be smaller than CP size");
   if (n_rows == 0) return NRX_OK;
-  const size_t lds = sizeof(cx<T>) * ((size_t)nfft + nfft / 2 + 2 * (size_t)window_len);
+  const cx<double>* tw = nrx::fft_twiddle_table((hipStream_t)stream);
+  NRX_REQUIRE(tw, NRX_E_HIP, "nrx_ofdm_modulate: FFT twiddle table unavailable");
+  if (tails || window_len == 0) {   // symbol-parallel form
+    const size_t lds = sizeof(cx<T>) * (size_t)nfft;
+    auto kern = ofdm_mod_sym_kernel<T>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(n_rows * n_sym), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
+                       ilog2(nfft), g, window_len, slot_len, (cx<T>*)wave, wave_stride, (const cx<T>*)f, f_stride, nl,
+                       ports, tw, (cx<T>*)tails);
+    if (window_len > 0) {
+      const int64_t total = (int64_t)n_rows * n_sym * window_len;
+      hipLaunchKernelGGL(ofdm_tail_add_kernel<T>, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                         (cx<T>*)wave, wave_stride, g, window_len, slot_len, (const cx<T>*)tails, total);
+    }
+    NRX_CHECK_LAUNCH("nrx_ofdm_modulate");
+    return NRX_OK;
+  }
+  const size_t lds = sizeof(cx<T>) * ((size_t)nfft + 2 * (size_t)window_len);
   auto kern = ofdm_mod_kernel<T>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(n_rows), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft, ilog2(nfft), g,
-                     window_len, slot_len, (cx<T>*)wave, wave_stride, (const cx<T>*)f, f_stride, nl, ports);
+                     window_len, slot_len, (cx<T>*)wave, wave_stride, (const cx<T>*)f, f_stride, nl, ports, tw);
   NRX_CHECK_LAUNCH("nrx_ofdm_modulate");
   return NRX_OK;
 }
@@ -192,12 +278,14 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
               "nrx_ofdm_demodulate: waveform shorter than one slot (%d samples)", slot_len);
   const int n_tasks = n_items * n_ant * n_sym;
   if (n_tasks == 0) return NRX_OK;
-  const size_t lds = sizeof(cx<T>) * ((size_t)nfft + nfft / 2);
+  const cx<double>* tw = nrx::fft_twiddle_table((hipStream_t)stream);
+  NRX_REQUIRE(tw, NRX_E_HIP, "nrx_ofdm_demodulate: FFT twiddle table unavailable");
+  const size_t lds = sizeof(cx<T>) * (size_t)nfft;
   auto kern = ofdm_demod_kernel<T>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int grid_dim = n_tasks < 1024 ? n_tasks : 1024;
+  const int grid_dim = n_tasks < 4096 ? n_tasks : 4096;
   hipLaunchKernelGGL(kern, dim3(grid_dim), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)wave, wave_stride, wave_len,
-                     t_off, t_off_stride, n_ant, K, nfft, ilog2(nfft), g, (cx<T>*)grid, n_tasks);
+                     t_off, t_off_stride, n_ant, K, nfft, ilog2(nfft), g, (cx<T>*)grid, n_tasks, tw);
   NRX_CHECK_LAUNCH("nrx_ofdm_demodulate");
   return NRX_OK;
 }
@@ -206,7 +294,7 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
 
 extern "C" int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<float>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
 extern "C" int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
-extern "C" int32_t nrx_ofdm_modulate_precoded_f32(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); return mod_entry<float>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports); }
-extern "C" int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); return mod_entry<double>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports); }
+extern "C" int32_t nrx_ofdm_modulate_precoded_f32(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); NRX_REQUIRE(tails_ws || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_precoded: windowing needs the tails workspace"); return mod_entry<float>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports, tails_ws); }
+extern "C" int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); NRX_REQUIRE(tails_ws || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_precoded: windowing needs the tails workspace"); return mod_entry<double>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports, tails_ws); }
 extern "C" int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }
 extern "C" int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }

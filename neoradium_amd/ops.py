@@ -370,8 +370,9 @@ def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0, f=None):
         check(fn(ptr(grid), n * P, K, nfft, _host_i32(cp_lens), L, int(window_len), ptr(wave), S + pad, stream()))
     else:
         fn = getattr(lib(), 'nrx_ofdm_modulate_precoded_' + sfx)
+        tails = torch.empty((n, nt, L, int(window_len)), dtype=grid.dtype, device=dev) if window_len else None
         check(fn(ptr(grid), n, P, nt, ptr(f), 0 if shared else nt * P, K, nfft, _host_i32(cp_lens), L, int(window_len),
-                 ptr(wave), S + pad, stream()))
+                 ptr(wave), S + pad, ptr(tails), stream()))
     return wave
 
 

@@ -140,6 +140,13 @@ def test_ofdm_mod_demod(dev, mu, nfft, K, slot):
         ref = np.stack([op.ofdm_modulate(grid[i], nfft, cps, window=win > 0) for i in range(n)])
         assert rel(wave[..., :-7], ref) < 1e-12, win
         assert not wave[..., -7:].any()
+    # precoder fused into the (symbol-parallel) modulator == precode, then the sequential modulator: same samples
+    F = crandn(rng, n, 4, P)
+    for win in (0, w):
+        fused = ops.ofdm_modulate(T(grid, dev), nfft, cps, window_len=win, pad=5, f=T(F, dev))
+        two = ops.ofdm_modulate(ops.precode(T(grid, dev), T(F, dev)), nfft, cps, window_len=win, pad=5)
+        assert fused.shape == two.shape == (n, 4, ref.shape[-1] + 5)
+        assert np.array_equal(fused.cpu().numpy(), two.cpu().numpy()), win
     # demodulate a time-shifted noisy waveform with per-item timing offsets
     S = ref.shape[-1]
     rxw = np.concatenate([crandn(rng, n, P, 20), ref, crandn(rng, n, P, 30)], axis=-1)
