@@ -6,6 +6,7 @@
 // :1040-1046 (getNoiseStd -> np.var), :1049-1187 + waveform.py:145-292 (addNoise), random.py:203 (awgn).
 #include "nrx_common.h"
 #include "nrx_cplx.h"
+#include "nrx_mmse.h"
 
 namespace {
 using nrx::cx;
@@ -71,78 +72,13 @@ mmse_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ hf, int64_t 
 #pragma unroll
       for (int p = 0; p < NL; ++p) H[r][p] = cd(hb[r * NL + p]);
     }
-    // A = H^H H + nv I (lower triangle), z = H^H y
-    cd A[NL][NL], z[NL];
+    cd xh[NL];
+    double sc[NL];
+    nrx::mmse_solve<NR, NL>(H, y, nv, xh, sc);
 #pragma unroll
     for (int p = 0; p < NL; ++p) {
-      cd zz(0, 0);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) nrx::cmacc(zz, H[r][p], y[r]);
-      z[p] = zz;
-#pragma unroll
-      for (int q = 0; q <= p; ++q) {
-        cd a(0, 0);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) nrx::cmacc(a, H[r][q], H[r][p]);  // conj(H[r][q]) * H[r][p] = A[q][p]
-        A[p][q] = nrx::conj(a);                                         // store A[p][q] = conj(A[q][p])
-      }
-      A[p][p].re += nv;
-    }
-    // Cholesky A = L L^H (L lower, real positive diagonal)
-    cd Lm[NL][NL];
-    double dinv[NL];
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      double d = A[j][j].re;
-#pragma unroll
-      for (int k = 0; k < j; ++k) d -= nrx::norm2(Lm[j][k]);
-      const double ljj = sqrt(d);
-      dinv[j] = 1.0 / ljj;
-      Lm[j][j] = cd(ljj, 0);
-#pragma unroll
-      for (int r = j + 1; r < NL; ++r) {
-        cd s = A[r][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) {  // s -= L[r][k] * conj(L[j][k])
-          s.re -= Lm[r][k].re * Lm[j][k].re + Lm[r][k].im * Lm[j][k].im;
-          s.im -= Lm[r][k].im * Lm[j][k].re - Lm[r][k].re * Lm[j][k].im;
-        }
-        Lm[r][j] = s * dinv[j];
-      }
-    }
-    // M = L^-1 (lower)
-    cd M[NL][NL];
-#pragma unroll
-    for (int c = 0; c < NL; ++c) {
-      M[c][c] = cd(dinv[c], 0);
-#pragma unroll
-      for (int r = c + 1; r < NL; ++r) {
-        cd s(0, 0);
-#pragma unroll
-        for (int k = c; k < r; ++k) nrx::cmac(s, Lm[r][k], M[k][c]);
-        M[r][c] = cd(-s.re * dinv[r], -s.im * dinv[r]);
-      }
-    }
-    // xhat = M^H (M z);  diag(Ainv)_p = sum_{k>=p} |M[k][p]|^2
-    cd u[NL];
-#pragma unroll
-    for (int r = 0; r < NL; ++r) {
-      cd s(0, 0);
-#pragma unroll
-      for (int c = 0; c <= r; ++c) nrx::cmac(s, M[r][c], z[c]);
-      u[r] = s;
-    }
-#pragma unroll
-    for (int p = 0; p < NL; ++p) {
-      cd s(0, 0);
-      double dg = 0;
-#pragma unroll
-      for (int k = p; k < NL; ++k) {
-        nrx::cmacc(s, M[k][p], u[k]);
-        dg += nrx::norm2(M[k][p]);
-      }
-      eq[((size_t)b * NL + p) * lk + i] = cx<T>(s);
-      scale[((size_t)b * NL + p) * lk + i] = (T)(1.0 / dg);
+      eq[((size_t)b * NL + p) * lk + i] = cx<T>(xh[p]);
+      scale[((size_t)b * NL + p) * lk + i] = (T)sc[p];
     }
   }
 }

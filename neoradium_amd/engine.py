@@ -70,6 +70,9 @@ class PdschLink:
         self.templates = D(np.stack(templ))                    # (S, Nl, L, K) complex128
         self.pilots = D(np.stack(pil))                         # (S, P, nDs, nK)
         self.l_cdm, self.k_cdm = dmrs.symbols, (4 if dmrs.enhanced else 2)
+        self.port_ks_d = D(np.ascontiguousarray(np.int32(self.port_ks)))
+        assert 0 <= int(np.min(self.port_ks)) and int(np.max(self.port_ks)) < self.K
+        self.n_tg = len(self.dmrs_syms) // self.l_cdm                   # DMRS time groups
         n_re = len(idx0[0])
         self.G = n_re * self.qm
         lm = pdsch.getLayerMapIndexes(idx0, [n_re])[0]
@@ -196,12 +199,17 @@ class PdschLink:
             rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off)
 
         # ---- Rx
+        hest = None
         if self.chanEst == "Perfect":
             hest = ops.effective_channel(H, F)
-        else:
+            eq, sc = ops.mmse_equalize(rxg, hest, nv)
+        elif details or self.n_tg > 2:
             hest = ops.chest_ls(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,
                                 pil_set=sif.to(torch.int32))
-        eq, sc = ops.mmse_equalize(rxg, hest, nv)
+            eq, sc = ops.mmse_equalize(rxg, hest, nv)
+        else:       # estimate + equalise fused: the (L, K, Nr, Nl) estimate is never written out
+            eq, sc = ops.chest_ls_mmse(rxg, self.pilots, self.port_ks_d, self.dmrs_syms, nv, l_cdm=self.l_cdm,
+                                       k_cdm=self.k_cdm, pil_set=sif.to(torch.int32))
         llr = ops.qam_demap(eq, nv, self.qm, scr=self.scr, re_index=self.re_index, scales=sc, nv_floor=1e-10,
                             llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
         rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm)

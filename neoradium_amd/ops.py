@@ -478,6 +478,29 @@ def chest_ls(rx, pilots, port_ks, dmrs_syms, l_cdm=1, k_cdm=2, pil_set=None):
     return hest
 
 
+def chest_ls_mmse(rx, pilots, port_ks, dmrs_syms, noise_var, l_cdm=1, k_cdm=2, pil_set=None):
+    """chest_ls + mmse_equalize fused (complex128, <= 2 DMRS time groups): -> eq (n,P,L,K), llrScales (n,P,L,K).
+
+    Trusted inputs (the engine validates its tables once): no host-side range checks, no device synchronisation."""
+    rx = rx.contiguous()
+    if rx.dtype != torch.complex128:
+        raise ValueError("chest_ls_mmse is built for complex128")
+    n, nr, L, K = rx.shape
+    dev = _dev(rx)
+    if pilots.dim() == 3:
+        pilots = pilots[None]
+    sets, P, nds, nk = pilots.shape
+    n_g = nds // l_cdm
+    nv = torch.as_tensor(noise_var, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+    hk = torch.empty((n, n_g, K, nr, P), dtype=torch.complex128, device=dev)
+    eq = torch.empty((n, P, L, K), dtype=torch.complex128, device=dev)
+    sc = torch.empty((n, P, L, K), dtype=torch.float64, device=dev)
+    check(lib().nrx_chest_ls_mmse_f64(ptr(rx), ptr(pilots), ptr(pil_set), ptr(port_ks), _host_i32(dmrs_syms), nds, l_cdm,
+                                      k_cdm, nk, L, K, nr, P, ptr(nv), 0 if nv.numel() == 1 else 1, ptr(hk), ptr(eq),
+                                      ptr(sc), n, stream()))
+    return eq, sc
+
+
 def channel_matrix_sub(cir_t, off, nc, K, nfft, k0, n_k):
     """H at subcarriers [k0, k0+n_k) only: (n,nc,n_k,Nr,Nt)."""
     cir_t = cir_t.contiguous()

@@ -160,6 +160,26 @@ def test_ofdm_mod_demod(dev, mu, nfft, K, slot):
     assert rel(back, grid) < 1e-12
 
 
+def test_chest_mmse_fused_equals_separate(dev):
+    """nrx_chest_ls_mmse = nrx_chest_ls + nrx_mmse_equalize, bit for bit (1 and 2 DMRS time groups)."""
+    import torch
+    from neoradium_amd import ops
+    rng = np.random.default_rng(21)
+    n, nr, P, L, K = 3, 4, 4, 14, 96
+    for ds in ([2], [2, 11]):
+        nk = K // 2
+        port_ks = np.int32([np.arange(nk) * 2 + (p % 2) for p in range(P)])
+        pilots = np.exp(1j * rng.uniform(0, 6.28, (2, P, len(ds), nk)))
+        rx = crandn(rng, n, nr, L, K)
+        nv = rng.uniform(0.01, 0.1, n)
+        pil_set = T(np.int32([0, 1, 0]), dev)
+        hest = ops.chest_ls(T(rx, dev), T(pilots, dev), port_ks, ds, l_cdm=1, k_cdm=2, pil_set=pil_set)
+        eq0, sc0 = ops.mmse_equalize(T(rx, dev), hest, T(nv, dev))
+        eq1, sc1 = ops.chest_ls_mmse(T(rx, dev), T(pilots, dev), T(port_ks, dev), ds, T(nv, dev), l_cdm=1, k_cdm=2,
+                                     pil_set=pil_set)
+        assert torch.equal(eq0, eq1) and torch.equal(sc0, sc1), ds
+
+
 def test_tdl_chain(dev):
     """gains -> CIR -> channel matrix / time-domain filtering, CDL-like random static tensors."""
     from neoradium_amd import ops
