@@ -88,6 +88,7 @@ class PdschLink:
         self.coeff = D(coeff)
         taps, offs = ops.path_taps(coeff, channel.filterLen)
         self.taps, self.tap_off = D(taps), D(offs)
+        self.td_hist = int(np.max(offs)) + int(np.asarray(taps).shape[1]) - 1
         self.max_delay = channel.getMaxDelay()
         self.fs = bwp.sampleRate
         self.window = windowing
@@ -190,7 +191,8 @@ class PdschLink:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
             tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay, f=F)   # precoder fused
-            ry = ops.apply_td_paths(tx, gains1, self.taps, self.tap_off, [int(v) for v in self.sym_lens[sis]])
+            ry = ops.apply_td_paths(tx, gains1, self.taps, self.tap_off, [int(v) for v in self.sym_lens[sis]],
+                                    hist=self.td_hist)
             width = ry.shape[-1]
             _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=self.nfft / (12.0 * self.bwp.numRbs),
                                            nv_mult=float(self.nfft), gather=self._cp_gather(sis, width))

@@ -562,7 +562,7 @@ def path_taps(coeff, filter_len=16):
     return taps, offs
 
 
-def apply_td_paths(x, gains1, taps, tap_off, set_lens):
+def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None):
     """ChannelModel.applyToSignal, path form: x (n,Nt,ns), gains1 (n,nc+1,Nr,Nt,P), taps (P,flen), tap_off (P) -> (n,Nr,ns)."""
     x = x.to(torch.complex128).contiguous()
     gains1 = gains1.to(torch.complex128).contiguous()
@@ -576,7 +576,8 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens):
     if taps.shape[0] != P or tap_off.numel() != P:
         raise ValueError("tap table / path count mismatch")
     flen = taps.shape[1]
-    hist = int(tap_off.max()) + flen - 1
+    if hist is None:                       # (device -> host read; batched callers pass it)
+        hist = int(tap_off.max()) + flen - 1
     y = torch.empty((n, nr, ns), dtype=torch.complex128, device=dev)
     check(lib().nrx_apply_td_paths_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen,
                                        hist, _host_i32(set_lens), ptr(y), stream()))
