@@ -97,6 +97,19 @@ int32_t nrx_ldpc_rate_recover_f64(const double* llr, int32_t n_tb, int32_t llr_l
                                   int32_t nl, int32_t qm, int32_t rv, int32_t n_ref, double* circ, double* out,
                                   void* stream);
 
+/* HARQ batches (harq.py:145-202 HarqCW.getRateMatchedCodeBlocks / decodeLLRs for many HARQ processes at once): the
+ * same two operations with one redundancy version per transport block, rv_per_tb[n_tb] (device, values 0..3), and,
+ * for rate recovery, reset_per_tb[n_tb] (device, may be NULL): non-zero = this process starts a new transport block,
+ * its soft buffer is restarted from zero instead of being accumulated into.  The soft buffers stay resident in HBM. */
+int32_t nrx_ldpc_rate_match_harq(const uint8_t* coded, int32_t n_tb, const nrx_ldpc_cfg* cfg, int32_t G, int32_t nl,
+                                 int32_t qm, const int32_t* rv_per_tb, int32_t n_ref, uint8_t* out, void* stream);
+int32_t nrx_ldpc_rate_recover_harq_f32(const float* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                       int32_t nl, int32_t qm, const int32_t* rv_per_tb, const uint8_t* reset_per_tb,
+                                       int32_t n_ref, float* circ, float* out, void* stream);
+int32_t nrx_ldpc_rate_recover_harq_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                       int32_t nl, int32_t qm, const int32_t* rv_per_tb, const uint8_t* reset_per_tb,
+                                       int32_t n_ref, double* circ, double* out, void* stream);
+
 /* ldpc.py:1495-1581 decode: layered normalised min-sum, fixed n_iter.
  * llr: n_cb x N.  hard_out (nullable): n_cb x out_cols bits (r<0).  belief_out (nullable): n_cb x out_cols.
  * out_cols = K (onlyInfoBits) or N+2Zc (all columns incl. the two punctured ones).

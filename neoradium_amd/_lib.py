@@ -37,6 +37,9 @@ SIGNATURES = {
     'nrx_ldpc_segment': (i32, [vp, i32, i32, i32, _cfgp, vp, vp]),
     'nrx_ldpc_encode': (i32, [vp, i32, _cfgp, i32, vp, vp]),
     'nrx_ldpc_rate_match': (i32, [vp, i32, _cfgp, i32, i32, i32, i32, i32, vp, vp]),
+    'nrx_ldpc_rate_match_harq': (i32, [vp, i32, _cfgp, i32, i32, i32, vp, i32, vp, vp]),
+    'nrx_ldpc_rate_recover_harq_f32': (i32, [vp, i32, i32, _cfgp, i32, i32, vp, vp, i32, vp, vp, vp]),
+    'nrx_ldpc_rate_recover_harq_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, vp, vp, i32, vp, vp, vp]),
     'nrx_ldpc_rate_recover_f32': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_ldpc_rate_recover_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_ldpc_decode_ws_bytes': (u64, [_cfgp, i32]),

@@ -250,6 +250,7 @@ struct RmGeom {
   int C, N, K, F, zc, ncb, k0, sys_len, cs;  // cs = ncb - F (circular buffer without fillers)
   int e_small, n_small, f;                   // first n_small blocks have e_small bits, the rest e_small+f
   int G, qm;
+  int k0_tab[4];                             // k0 of every redundancy version (per-transport-block rv arrays)
 };
 
 __device__ __forceinline__ void rm_locate(const RmGeom& g, int pos, int& r, int& j, int& E) {
@@ -267,7 +268,8 @@ __device__ __forceinline__ void rm_locate(const RmGeom& g, int pos, int& r, int&
 }
 
 __global__ void __launch_bounds__(256)
-rate_match_kernel(const uint8_t* __restrict__ coded, int n_tb, RmGeom g, uint8_t* __restrict__ out) {
+rate_match_kernel(const uint8_t* __restrict__ coded, int n_tb, RmGeom g, uint8_t* __restrict__ out,
+                  const int32_t* __restrict__ rvs) {
   const int64_t total = (int64_t)n_tb * g.G;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int t = (int)(i / g.G), pos = (int)(i - (int64_t)t * g.G);
@@ -275,7 +277,8 @@ rate_match_kernel(const uint8_t* __restrict__ coded, int n_tb, RmGeom g, uint8_t
     rm_locate(g, pos, r, j, E);
     const int eq = E / g.qm;
     const int e = (j % g.qm) * eq + j / g.qm;        // position in the selected (pre-interleaver) sequence
-    const int ci = (e + g.k0) % g.cs;                // circular buffer without fillers
+    const int k0 = rvs ? g.k0_tab[rvs[t] & 3] : g.k0;
+    const int ci = (e + k0) % g.cs;                  // circular buffer without fillers
     const int src = ci < g.sys_len ? ci : ci + g.F;  // index in the N-bit coded block (fillers skipped)
     out[i] = coded[((size_t)t * g.C + r) * g.N + src];
   }
@@ -286,9 +289,11 @@ rate_match_kernel(const uint8_t* __restrict__ coded, int n_tb, RmGeom g, uint8_t
 // lanes read consecutive coded bits.
 template <int QM>
 __global__ void __launch_bounds__(256)
-rate_match_cb_kernel(const uint8_t* __restrict__ coded, RmGeom g, uint8_t* __restrict__ out) {
+rate_match_cb_kernel(const uint8_t* __restrict__ coded, RmGeom g, uint8_t* __restrict__ out,
+                     const int32_t* __restrict__ rvs) {
   const int cbi = blockIdx.y;
   const int t = cbi / g.C, r = cbi - t * g.C;
+  const int k0 = rvs ? g.k0_tab[rvs[t] & 3] : g.k0;
   int E, off;
   if (r < g.n_small) { E = g.e_small; off = r * g.e_small; }
   else { E = g.e_small + g.f; off = g.n_small * g.e_small + (r - g.n_small) * E; }
@@ -299,7 +304,7 @@ rate_match_cb_kernel(const uint8_t* __restrict__ coded, RmGeom g, uint8_t* __res
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
       const int e = q * eq + sidx;
-      const int ci = (e + g.k0) % g.cs;
+      const int ci = (e + k0) % g.cs;
       dst[sidx * QM + q] = src[ci < g.sys_len ? ci : ci + g.F];
     }
   }
@@ -310,9 +315,12 @@ rate_match_cb_kernel(const uint8_t* __restrict__ coded, RmGeom g, uint8_t* __res
 // code block beyond a limited buffer are filled by the same workgroup.  Same sums as rate_recover_kernel.
 template <typename T, int QM>
 __global__ void __launch_bounds__(256)
-rate_recover_cb_kernel(const T* __restrict__ llr, int llr_len, RmGeom g, T* __restrict__ circ, T* __restrict__ out) {
+rate_recover_cb_kernel(const T* __restrict__ llr, int llr_len, RmGeom g, T* __restrict__ circ, T* __restrict__ out,
+                       const int32_t* __restrict__ rvs, const uint8_t* __restrict__ reset) {
   const int cbi = blockIdx.y;
   const int t = cbi / g.C, r = cbi - t * g.C;
+  const int k0 = rvs ? g.k0_tab[rvs[t] & 3] : g.k0;
+  const bool fresh = reset && reset[t];     // new transport block in this HARQ process: the soft buffer starts from 0
   int E, off;
   if (r < g.n_small) { E = g.e_small; off = r * g.e_small; }
   else { E = g.e_small + g.f; off = g.n_small * g.e_small + (r - g.n_small) * E; }
@@ -325,16 +333,20 @@ rate_recover_cb_kernel(const T* __restrict__ llr, int llr_len, RmGeom g, T* __re
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
       const int e = q * eq + sidx;
-      const int ci = (e + g.k0) % g.cs;
+      const int ci = (e + k0) % g.cs;
       const int j = off + sidx * QM + q;
       T v = j < llr_len ? src[j] : (T)0;   // short input is zero padded (ldpc.py:1401-1402)
-      if (cb) { v = cb[ci] + v; cb[ci] = v; }
+      if (cb) { v = (fresh ? (T)0 : cb[ci]) + v; cb[ci] = v; }
       dst[ci < g.sys_len ? ci : ci + g.F] = v;
     }
   }
   for (int e = E + tid; e < g.cs; e += nth) {             // buffer positions this transmission did not reach
-    const int ci = (e + g.k0) % g.cs;
-    dst[ci < g.sys_len ? ci : ci + g.F] = cb ? cb[ci] : (T)0;
+    const int ci = (e + k0) % g.cs;
+    T v = (T)0;
+    if (cb) {
+      if (fresh) cb[ci] = (T)0; else v = cb[ci];
+    }
+    dst[ci < g.sys_len ? ci : ci + g.F] = v;
   }
   for (int i = tid; i < g.F; i += nth) dst[g.sys_len + i] = (T)1e20;   // LARGE_LLR fillers (ldpc.py:1414-1418)
   for (int n = g.cs + g.F + tid; n < g.N; n += nth) dst[n] = (T)0;      // beyond a limited (LBRM) buffer
@@ -345,7 +357,8 @@ rate_recover_cb_kernel(const T* __restrict__ llr, int llr_len, RmGeom g, T* __re
 // wrap-around repetitions follows the reference (increasing e), so float sums are bit-identical.
 template <typename T>
 __global__ void __launch_bounds__(256)
-rate_recover_kernel(const T* __restrict__ llr, int n_tb, int llr_len, RmGeom g, T* __restrict__ circ, T* __restrict__ out) {
+rate_recover_kernel(const T* __restrict__ llr, int n_tb, int llr_len, RmGeom g, T* __restrict__ circ, T* __restrict__ out,
+                    const int32_t* __restrict__ rvs, const uint8_t* __restrict__ reset) {
   const int64_t total = (int64_t)n_tb * g.C * g.N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % g.N);
@@ -358,13 +371,13 @@ rate_recover_kernel(const T* __restrict__ llr, int n_tb, int llr_len, RmGeom g, 
       const int ci = n < g.sys_len ? n : n - g.F;
       v = (T)0;
       if (ci < g.cs) {  // positions beyond the (LBRM-limited) buffer do not exist; out is N wide only when ncb==N
-        T acc = circ ? circ[cbi * g.cs + ci] : (T)0;
+        T acc = (circ && !(reset && reset[t])) ? circ[cbi * g.cs + ci] : (T)0;
         // E_r and the offset of block r inside the G-long LLR stream
         int E, off;
         if (r < g.n_small) { E = g.e_small; off = r * g.e_small; }
         else { E = g.e_small + g.f; off = g.n_small * g.e_small + (r - g.n_small) * E; }
         const int eq = E / g.qm;
-        int e = ci - g.k0;
+        int e = ci - (rvs ? g.k0_tab[rvs[t] & 3] : g.k0);
         e %= g.cs;
         if (e < 0) e += g.cs;
         for (; e < E; e += g.cs) {
@@ -461,6 +474,7 @@ int fill_geom(const nrx_ldpc_cfg* cfg, int G, int nl, int qm, int rv, int n_ref,
   g->sys_len = cfg->K - 2 * cfg->Zc - cfg->F;                             // systematic bits w/o fillers
   g->cs = g->ncb - cfg->F;
   g->k0 = (int)(((long)k0num[cfg->bg - 1][rv] * g->ncb / cfg->N) * cfg->Zc);  // ldpc.py:1145
+  for (int v = 0; v < 4; ++v) g->k0_tab[v] = (int)(((long)k0num[cfg->bg - 1][v] * g->ncb / cfg->N) * cfg->Zc);
   g->f = nl * qm;
   const int gb = (G + g->f - 1) / g->f;
   g->e_small = (gb / cfg->C) * g->f;
@@ -535,8 +549,8 @@ static int32_t check_rm_args(const char* who, const nrx_ldpc_cfg* cfg, int G, in
   return NRX_OK;
 }
 
-extern "C" int32_t nrx_ldpc_rate_match(const uint8_t* coded, int32_t n_tb, const nrx_ldpc_cfg* cfg, int32_t G,
-                                       int32_t nl, int32_t qm, int32_t rv, int32_t n_ref, uint8_t* out, void* stream) {
+static int32_t rate_match_impl(const uint8_t* coded, int32_t n_tb, const nrx_ldpc_cfg* cfg, int32_t G, int32_t nl,
+                               int32_t qm, int32_t rv, const int32_t* rvs, int32_t n_ref, uint8_t* out, void* stream) {
   NRX_REQUIRE(coded && out, NRX_E_ARG, "nrx_ldpc_rate_match: NULL buffer");
   int32_t rc = check_rm_args("nrx_ldpc_rate_match", cfg, G, nl, qm, rv);
   if (rc) return rc;
@@ -549,12 +563,12 @@ extern "C" int32_t nrx_ldpc_rate_match(const uint8_t* coded, int32_t n_tb, const
     const dim3 grid2((eq_max + 255) / 256 > 8 ? 8 : (eq_max + 255) / 256, n_tb * cfg->C);
     bool done = true;
     switch (qm) {
-      case 1: hipLaunchKernelGGL(rate_match_cb_kernel<1>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
-      case 2: hipLaunchKernelGGL(rate_match_cb_kernel<2>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
-      case 4: hipLaunchKernelGGL(rate_match_cb_kernel<4>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
-      case 6: hipLaunchKernelGGL(rate_match_cb_kernel<6>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
-      case 8: hipLaunchKernelGGL(rate_match_cb_kernel<8>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
-      case 10: hipLaunchKernelGGL(rate_match_cb_kernel<10>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out); break;
+      case 1: hipLaunchKernelGGL(rate_match_cb_kernel<1>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out, rvs); break;
+      case 2: hipLaunchKernelGGL(rate_match_cb_kernel<2>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out, rvs); break;
+      case 4: hipLaunchKernelGGL(rate_match_cb_kernel<4>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out, rvs); break;
+      case 6: hipLaunchKernelGGL(rate_match_cb_kernel<6>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out, rvs); break;
+      case 8: hipLaunchKernelGGL(rate_match_cb_kernel<8>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out, rvs); break;
+      case 10: hipLaunchKernelGGL(rate_match_cb_kernel<10>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out, rvs); break;
       default: done = false;
     }
     if (done) {
@@ -563,14 +577,26 @@ extern "C" int32_t nrx_ldpc_rate_match(const uint8_t* coded, int32_t n_tb, const
     }
   }
   hipLaunchKernelGGL(rate_match_kernel, dim3(nrx::stream_grid((long)n_tb * g.G, 256)), dim3(256), 0, (hipStream_t)stream,
-                     coded, n_tb, g, out);
+                     coded, n_tb, g, out, rvs);
   NRX_CHECK_LAUNCH("nrx_ldpc_rate_match");
   return NRX_OK;
 }
 
+extern "C" int32_t nrx_ldpc_rate_match(const uint8_t* coded, int32_t n_tb, const nrx_ldpc_cfg* cfg, int32_t G,
+                                       int32_t nl, int32_t qm, int32_t rv, int32_t n_ref, uint8_t* out, void* stream) {
+  return rate_match_impl(coded, n_tb, cfg, G, nl, qm, rv, nullptr, n_ref, out, stream);
+}
+extern "C" int32_t nrx_ldpc_rate_match_harq(const uint8_t* coded, int32_t n_tb, const nrx_ldpc_cfg* cfg, int32_t G,
+                                            int32_t nl, int32_t qm, const int32_t* rv_per_tb, int32_t n_ref,
+                                            uint8_t* out, void* stream) {
+  NRX_REQUIRE(rv_per_tb, NRX_E_ARG, "nrx_ldpc_rate_match_harq: NULL rv array");
+  return rate_match_impl(coded, n_tb, cfg, G, nl, qm, 0, rv_per_tb, n_ref, out, stream);
+}
+
 template <typename T>
 static int32_t rate_recover_entry(const T* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
-                                  int32_t qm, int32_t rv, int32_t n_ref, T* circ, T* out, void* stream) {
+                                  int32_t qm, int32_t rv, int32_t n_ref, T* circ, T* out, void* stream,
+                                  const int32_t* rvs = nullptr, const uint8_t* reset = nullptr) {
   NRX_REQUIRE(llr && out, NRX_E_ARG, "nrx_ldpc_rate_recover: NULL buffer");
   int32_t rc = check_rm_args("nrx_ldpc_rate_recover", cfg, llr_len, nl, qm, rv);
   if (rc) return rc;
@@ -582,12 +608,12 @@ static int32_t rate_recover_entry(const T* llr, int32_t n_tb, int32_t llr_len, c
     hipStream_t st = (hipStream_t)stream;
     bool done = true;
     switch (qm) {
-      case 1: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 1>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
-      case 2: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 2>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
-      case 4: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 4>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
-      case 6: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 6>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
-      case 8: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 8>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
-      case 10: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 10>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out); break;
+      case 1: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 1>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out, rvs, reset); break;
+      case 2: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 2>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out, rvs, reset); break;
+      case 4: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 4>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out, rvs, reset); break;
+      case 6: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 6>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out, rvs, reset); break;
+      case 8: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 8>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out, rvs, reset); break;
+      case 10: hipLaunchKernelGGL((rate_recover_cb_kernel<T, 10>), grid2, dim3(256), 0, st, llr, llr_len, g, circ, out, rvs, reset); break;
       default: done = false;
     }
     if (done) {
@@ -596,7 +622,7 @@ static int32_t rate_recover_entry(const T* llr, int32_t n_tb, int32_t llr_len, c
     }
   }
   hipLaunchKernelGGL(rate_recover_kernel<T>, dim3(nrx::stream_grid((long)n_tb * cfg->C * cfg->N, 256)), dim3(256), 0,
-                     (hipStream_t)stream, llr, n_tb, llr_len, g, circ, out);
+                     (hipStream_t)stream, llr, n_tb, llr_len, g, circ, out, rvs, reset);
   NRX_CHECK_LAUNCH("nrx_ldpc_rate_recover");
   return NRX_OK;
 }
@@ -610,6 +636,21 @@ extern "C" int32_t nrx_ldpc_rate_recover_f64(const double* llr, int32_t n_tb, in
                                              int32_t nl, int32_t qm, int32_t rv, int32_t n_ref, double* circ,
                                              double* out, void* stream) {
   return rate_recover_entry<double>(llr, n_tb, llr_len, cfg, nl, qm, rv, n_ref, circ, out, stream);
+}
+
+extern "C" int32_t nrx_ldpc_rate_recover_harq_f32(const float* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                                  int32_t nl, int32_t qm, const int32_t* rv_per_tb,
+                                                  const uint8_t* reset_per_tb, int32_t n_ref, float* circ, float* out,
+                                                  void* stream) {
+  NRX_REQUIRE(rv_per_tb && circ, NRX_E_ARG, "nrx_ldpc_rate_recover_harq: NULL rv array / soft buffer");
+  return rate_recover_entry<float>(llr, n_tb, llr_len, cfg, nl, qm, 0, n_ref, circ, out, stream, rv_per_tb, reset_per_tb);
+}
+extern "C" int32_t nrx_ldpc_rate_recover_harq_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                                  int32_t nl, int32_t qm, const int32_t* rv_per_tb,
+                                                  const uint8_t* reset_per_tb, int32_t n_ref, double* circ, double* out,
+                                                  void* stream) {
+  NRX_REQUIRE(rv_per_tb && circ, NRX_E_ARG, "nrx_ldpc_rate_recover_harq: NULL rv array / soft buffer");
+  return rate_recover_entry<double>(llr, n_tb, llr_len, cfg, nl, qm, 0, n_ref, circ, out, stream, rv_per_tb, reset_per_tb);
 }
 
 extern "C" int32_t nrx_ldpc_crc_merge(const uint8_t* dec, int32_t n_tb, const nrx_ldpc_cfg* cfg, uint8_t* tb_out,

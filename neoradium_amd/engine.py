@@ -156,7 +156,9 @@ class PdschLink:
                 det.append((sel, d))
         return (counters, det) if details else counters
 
-    def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details):
+    def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details, harq=None):
+        """One batch of slots with identical geometry.  ``harq`` = (rv, circ, reset): per-slot redundancy versions
+        (int32 device tensor), the resident soft buffers and the restart flags of a batched HARQ round."""
         dev, cfg = self.dev, self.cfg
         n = len(slots)
         sis = int(slots[0]) % self.bwp.slotsPerSubFrame
@@ -168,7 +170,7 @@ class PdschLink:
         tb = ops.random_bits(n, self.tbs, seed, dev, stream_id=1, batch_offset=int(slots[0])) if tb_bits is None \
             else tb_bits.to(dev).to(torch.uint8).contiguous()
         coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
-        bits = ops.ldpc_rate_match(coded, cfg, self.G, self.nl, self.qm)
+        bits = ops.ldpc_rate_match(coded, cfg, self.G, self.nl, self.qm, rv=0 if harq is None else harq[0])
         grid = self.templates.index_select(0, sif)                              # DMRS-filled (n, Nl, L, K)
         ops.qam_map(bits, self.qm, scr=self.scr, re_index=self.re_index, out=grid)
 
@@ -214,11 +216,71 @@ class PdschLink:
                                        k_cdm=self.k_cdm, pil_set=sif.to(torch.int32))
         llr = ops.qam_demap(eq, nv, self.qm, scr=self.scr, re_index=self.re_index, scales=sc, nv_floor=1e-10,
                             llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
-        rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm)
+        if harq is None:
+            rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm)
+        else:
+            rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm, rv=harq[0], circ=harq[1], reset=harq[2])
         dec = ops.ldpc_decode(rr, cfg, self.numIter)
         tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
-        ops.count_errors(cb_ok, tb_out, tb, counters)
+        if counters is not None:
+            ops.count_errors(cb_ok, tb_out, tb, counters)
         if details:
             return dict(tb=tb, cb_ok=cb_ok, tb_out=tb_out, llr=llr, eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv,
                         sigma=sigma, grid=grid)
-        return None
+        return dict(cb_ok=cb_ok) if harq is not None else None
+
+    # ----------------------------------------------------------------------------------------------- HARQ
+    def run_harq(self, n_proc, n_rounds, snr_db, seed=0, rvSequence=(0, 2, 3, 1), maxTries=4, harqType="IR", slot0=0,
+                 state=None):
+        """Batched HARQ (reference harq.py + Playground/HARQ/Harq.ipynb loop) for ``n_proc`` HARQ processes.
+
+        Round k transmits slots slot0 + k*n_proc + p, p = 0..n_proc-1, one per process -- the reference's round-robin
+        (harq.py:626-631) -- in one batch.  Per process the state is what ``HarqCW`` keeps (harq.py:145-202): the
+        transport block being sent, the try counter, and the soft buffer the decoder accumulates into; all of it stays
+        on the GPU (soft buffers: n_proc*C x (Ncb-F) LLRs resident in HBM), and the retransmission decision is taken
+        on the device, so a round needs no host round trip.  A process whose block decodes (every code-block CRC
+        passes) or times out after ``maxTries`` starts a new block in its next round.
+
+        Returns (stats, state): stats with the fields of ``HarqEntity`` (txBlocks/rxBlocks/txBits/rxBits per try,
+        numTimeouts, throughput and BLER in percent, meanTries); pass ``state`` back in to continue the run."""
+        dev, cfg = self.dev, self.cfg
+        if len({tuple(v) for v in self.sym_lens}) != 1:
+            raise NotImplementedError("run_harq: slots of one round must share their symbol geometry (mu <= 1)")
+        if harqType not in ("IR", "CC"):
+            raise ValueError("harqType must be 'IR' or 'CC'")
+        rvs = torch.tensor(list(rvSequence) if harqType == "IR" else [0], dtype=torch.int32, device=dev)
+        if state is None:
+            ft = torch.float32 if self.decoder == "f32" else torch.float64
+            state = dict(tb=torch.zeros((n_proc, self.tbs), dtype=torch.uint8, device=dev),
+                         tries=torch.zeros(n_proc, dtype=torch.int64, device=dev),
+                         circ=torch.zeros((n_proc * cfg.C, cfg.N - cfg.F), dtype=ft, device=dev),
+                         tx=torch.zeros(maxTries, dtype=torch.int64, device=dev),
+                         rx=torch.zeros(maxTries, dtype=torch.int64, device=dev),
+                         timeouts=torch.zeros(1, dtype=torch.int64, device=dev), next_slot=int(slot0))
+        elif state['tb'].shape[0] != n_proc or state['tx'].numel() != maxTries:
+            raise ValueError("state does not belong to this (n_proc, maxTries) configuration")
+        ones = torch.ones(n_proc, dtype=torch.int64, device=dev)
+        for _ in range(n_rounds):
+            s0 = state['next_slot']
+            slots = np.arange(s0, s0 + n_proc)
+            tries = state['tries']
+            new = tries == 0
+            fresh = ops.random_bits(n_proc, self.tbs, seed, dev, stream_id=1, batch_offset=s0)
+            state['tb'] = torch.where(new[:, None], fresh, state['tb'])
+            rv = rvs[tries % rvs.numel()].contiguous()
+            out = self._run_group(slots, snr_db, seed, state['tb'], None, None, False,
+                                  harq=(rv, state['circ'], new.to(torch.uint8)))
+            ok = out['cb_ok'].reshape(n_proc, cfg.C).to(torch.bool).all(1)
+            state['tx'].index_add_(0, tries, ones)                                  # harq.py:185-186
+            state['rx'].index_add_(0, tries, ok.to(torch.int64))                    # harq.py:187-190
+            nxt = tries + 1
+            timeout = (~ok) & (nxt == maxTries)                                     # harq.py:196-199
+            state['timeouts'] += timeout.sum()
+            state['tries'] = torch.where(ok | timeout, torch.zeros_like(nxt), nxt)
+            state['next_slot'] = s0 + n_proc
+        tx, rx = state['tx'].cpu().numpy(), state['rx'].cpu().numpy()
+        nto = int(state['timeouts'].item())
+        stats = dict(txBlocks=tx, rxBlocks=rx, txBits=tx * self.tbs, rxBits=rx * self.tbs, numTimeouts=nto,
+                     throughput=100.0 * rx.sum() / max(tx.sum(), 1), bler=100.0 * (tx.sum() - rx.sum()) / max(tx.sum(), 1),
+                     meanTries=float(((rx * np.arange(maxTries)).sum() + nto * maxTries) / max(rx.sum() + nto, 1)))
+        return stats, state

@@ -61,21 +61,35 @@ def ldpc_encode(cbs, cfg, puncture=True):
     return out
 
 
+def _rv_array(rv, n_tb, dev):
+    if rv.dtype != torch.int32 or rv.numel() != n_tb or rv.device != dev:
+        raise ValueError("per-transport-block rv must be an int32 device tensor with one entry per transport block")
+    return rv.contiguous()
+
+
 def ldpc_rate_match(coded, cfg, G, nl, qm, rv=0, nref=0):
-    """ldpc.py:1093-1159 rateMatch: (n_tb*C, N) -> (n_tb, sum E_r)."""
+    """ldpc.py:1093-1159 rateMatch: (n_tb*C, N) -> (n_tb, sum E_r).  ``rv``: int, or an int32 device tensor with
+    one redundancy version per transport block (batched HARQ processes)."""
     coded = _u8(coded)
     if coded.dim() != 2 or coded.shape[1] != cfg.N or coded.shape[0] % cfg.C:
         raise ValueError(f"coded blocks must be (n_tb*C, N={cfg.N}), got {tuple(coded.shape)}")
     n_tb = coded.shape[0] // cfg.C
     f = nl * qm
     gout = ((G + f - 1) // f) * f
-    out = torch.empty((n_tb, gout), dtype=torch.uint8, device=_dev(coded))
-    check(lib().nrx_ldpc_rate_match(ptr(coded), n_tb, C.byref(cfg), int(G), nl, qm, rv, nref, ptr(out), stream()))
+    dev = _dev(coded)
+    out = torch.empty((n_tb, gout), dtype=torch.uint8, device=dev)
+    if torch.is_tensor(rv):
+        check(lib().nrx_ldpc_rate_match_harq(ptr(coded), n_tb, C.byref(cfg), int(G), nl, qm, ptr(_rv_array(rv, n_tb, dev)),
+                                             nref, ptr(out), stream()))
+    else:
+        check(lib().nrx_ldpc_rate_match(ptr(coded), n_tb, C.byref(cfg), int(G), nl, qm, rv, nref, ptr(out), stream()))
     return out
 
 
-def ldpc_rate_recover(llr, cfg, nl, qm, rv=0, nref=0, circ=None):
-    """ldpc.py:1330-1418 recoverRate: (n_tb, G) LLRs -> (n_tb*C, N); ``circ`` (n_tb*C, Ncb-F) accumulates in place."""
+def ldpc_rate_recover(llr, cfg, nl, qm, rv=0, nref=0, circ=None, reset=None):
+    """ldpc.py:1330-1418 recoverRate: (n_tb, G) LLRs -> (n_tb*C, N); ``circ`` (n_tb*C, Ncb-F) accumulates in place.
+    Batched HARQ: ``rv`` int32 device tensor (one per transport block), ``reset`` uint8 device tensor (non-zero = the
+    soft buffer of that transport block restarts from zero)."""
     if llr.dtype not in _FT:
         raise ValueError("LLRs must be float32 or float64")
     llr = llr.contiguous()
@@ -84,7 +98,19 @@ def ldpc_rate_recover(llr, cfg, nl, qm, rv=0, nref=0, circ=None):
     if circ is not None:
         if tuple(circ.shape) != (n_tb * cfg.C, ncb - cfg.F) or circ.dtype != llr.dtype:
             raise ValueError(f"HARQ buffer shape mismatch! It must be a {n_tb * cfg.C}x{ncb - cfg.F} {llr.dtype} tensor!")
-    out = torch.empty((n_tb * cfg.C, cfg.N), dtype=llr.dtype, device=_dev(llr))
+    dev = _dev(llr)
+    out = torch.empty((n_tb * cfg.C, cfg.N), dtype=llr.dtype, device=dev)
+    if torch.is_tensor(rv):
+        if circ is None:
+            raise ValueError("per-transport-block rv needs the HARQ soft buffer `circ`")
+        if reset is not None and (reset.dtype != torch.uint8 or reset.numel() != n_tb):
+            raise ValueError("reset must be a uint8 device tensor with one entry per transport block")
+        fn = getattr(lib(), 'nrx_ldpc_rate_recover_harq_' + _FT[llr.dtype])
+        check(fn(ptr(llr), n_tb, G, C.byref(cfg), nl, qm, ptr(_rv_array(rv, n_tb, dev)),
+                 ptr(None if reset is None else reset.contiguous()), nref, ptr(circ), ptr(out), stream()))
+        return out
+    if reset is not None:
+        raise ValueError("reset goes with a per-transport-block rv tensor")
     fn = getattr(lib(), 'nrx_ldpc_rate_recover_' + _FT[llr.dtype])
     check(fn(ptr(llr), n_tb, G, C.byref(cfg), nl, qm, rv, nref, ptr(circ), ptr(out), stream()))
     return out

@@ -222,3 +222,39 @@ def test_engine_throughput_mode_properties(dev):
     mid_all = link.run(4, 8, 17.0, seed=9).cpu().numpy()
     mid_split = (link.run(4, 3, 17.0, seed=9) + link.run(7, 5, 17.0, seed=9)).cpu().numpy()
     assert np.array_equal(mid_all, mid_split)
+
+
+def test_engine_batched_harq(dev):
+    """PdschLink.run_harq (BASELINE cfg5: HARQ-IR, 4 redundancy versions, soft buffers resident on the GPU): the
+    HarqEntity bookkeeping identities hold, combining helps (blocks that fail the first try decode on a later one),
+    and a run can be split in two without changing anything."""
+    import neoradium_amd as nr
+    cfg = dict(seed=5, numRbs=24, spacing=30, mod='16QAM', layers=1, dm=dict(configType=1, additionalPos=1),
+               chan=('cdl', 'C', 100, 5, [1, 1], [1, 1]), slot0=0)
+    car, bwp, p, ch = _slot(nr, cfg)
+    link = nr.PdschLink(p, ch, 490 / 1024, numIter=10, decoder="f32")
+    P, R, MT = 16, 6, 4
+    hi, _ = link.run_harq(P, 3, 40.0, seed=3, maxTries=MT)
+    assert hi['txBlocks'].tolist() == [3 * P, 0, 0, 0] and hi['rxBlocks'].tolist() == [3 * P, 0, 0, 0]
+    assert hi['throughput'] == 100.0 and hi['numTimeouts'] == 0 and hi['meanTries'] == 0.0
+    lo, _ = link.run_harq(P, 2 * MT, -15.0, seed=3, maxTries=MT)
+    assert lo['rxBlocks'].sum() == 0 and lo['numTimeouts'] == 2 * P and lo['txBlocks'].tolist() == [2 * P] * MT
+    assert lo['meanTries'] == MT
+    # around the first-transmission waterfall: retransmissions with new redundancy versions rescue blocks
+    snr = 0.0
+    st, state = link.run_harq(P, R, snr, seed=3, maxTries=MT)
+    tx, rx = st['txBlocks'], st['rxBlocks']
+    assert tx.sum() == P * R and rx[0] < tx[0] and rx[1:].sum() > 0
+    tries = state['tries'].cpu().numpy()
+    for k in range(1, MT):          # a block is sent a k-th time iff its (k-1)-th try failed (or is still pending)
+        assert tx[k] == tx[k - 1] - rx[k - 1] - (tries == k).sum()
+    assert st['numTimeouts'] == tx[MT - 1] - rx[MT - 1]
+    assert abs(st['throughput'] - 100.0 * rx.sum() / tx.sum()) < 1e-12
+    # chase combining (rv always 0) also converges, with the same bookkeeping
+    cc, _ = link.run_harq(P, R, snr, seed=3, maxTries=MT, harqType="CC")
+    assert cc['txBlocks'].sum() == P * R and cc['throughput'] <= st['throughput']   # IR gains coding, CC only energy
+    # split run == one run
+    a, s1 = link.run_harq(P, 2, snr, seed=3, maxTries=MT)
+    b, s2 = link.run_harq(P, R - 2, snr, seed=3, maxTries=MT, state=s1)
+    assert np.array_equal(b['txBlocks'], tx) and np.array_equal(b['rxBlocks'], rx) and b['numTimeouts'] == st['numTimeouts']
+    assert np.array_equal(s2['tries'].cpu().numpy(), tries)

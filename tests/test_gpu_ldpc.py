@@ -141,3 +141,36 @@ def test_errors_are_valueerrors(dev):
         ops.ldpc_rate_match(coded, cfg, 22808, 1, 2, rv=4)      # ldpc.py:1131
     with pytest.raises(ValueError):
         ops.ldpc_decode(torch.zeros((2, 17), device=dev), cfg)
+
+
+@pytest.mark.parametrize("bg,A,G,nl,qm", [(1, 10000, 20900, 1, 4), (2, 3817, 12000, 1, 6), (1, 800, 1400, 2, 2)])
+def test_harq_batch_rv_and_reset(dev, bg, A, G, nl, qm):
+    """Per-transport-block redundancy versions and soft-buffer restarts (batched HARQ processes) give, row by row,
+    what the scalar-rv calls give (bit for bit), including wrap-around repetition (last case: E > circular buffer)."""
+    import torch
+    from neoradium_amd import ops, _lib
+    rng = np.random.default_rng(A)
+    cfg = _lib.ldpc_config(bg, A + 24)
+    n = 5
+    tb = _t(rng.integers(0, 2, (n, A)).astype(np.uint8), dev)
+    coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+    rv = np.int32([0, 2, 3, 1, 2])
+    reset = np.uint8([1, 0, 0, 1, 0])
+    bits = ops.ldpc_rate_match(coded, cfg, G, nl, qm, rv=_t(rv, dev))
+    for i in range(n):
+        one = ops.ldpc_rate_match(coded[i * cfg.C:(i + 1) * cfg.C], cfg, G, nl, qm, rv=int(rv[i]))
+        assert torch.equal(bits[i], one[0]), i
+    for dt in (torch.float32, torch.float64):
+        llr = _t(rng.standard_normal((n, bits.shape[1])), dev, dt)
+        circ0 = _t(rng.standard_normal((n * cfg.C, cfg.N - cfg.F)), dev, dt)
+        circ = circ0.clone()
+        rr = ops.ldpc_rate_recover(llr, cfg, nl, qm, rv=_t(rv, dev), circ=circ, reset=_t(reset, dev))
+        for i in range(n):
+            c1 = circ0[i * cfg.C:(i + 1) * cfg.C].clone()
+            if reset[i]:
+                c1.zero_()
+            r1 = ops.ldpc_rate_recover(llr[i:i + 1], cfg, nl, qm, rv=int(rv[i]), circ=c1)
+            assert torch.equal(rr[i * cfg.C:(i + 1) * cfg.C], r1), (i, dt)
+            assert torch.equal(circ[i * cfg.C:(i + 1) * cfg.C], c1), (i, dt)
+    with pytest.raises(ValueError):
+        ops.ldpc_rate_recover(llr, cfg, nl, qm, rv=_t(rv, dev))            # needs the soft buffer
