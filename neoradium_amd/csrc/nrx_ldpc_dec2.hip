@@ -383,19 +383,20 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             }
           });
           __builtin_amdgcn_sched_barrier(0);
-          // ---- old state.  Sign/argmin word of the layer: sign of edge j at bit j of its field, argmin above.
+          // ---- old state.  Sign/argmin word of the layer: argmin in the low bits of its field (so that the argmin
+          // selects below work with inline constants), sign of edge j at bit IB + j above it.
           const float om1 = m1[L], om2 = m2[L];
           uint32_t oidx;
-          int top;   // left shift that brings bit 0 of the field to bit 31
+          int top;   // left shift that brings the sign of edge 0 to bit 31
           if constexpr (WIDE) {
             word = sgw[Y::wide_idx(L)];
-            oidx = word >> 24;
-            top = 31;
+            oidx = word & 31u;
+            top = 31 - 5;
           } else {
             constexpr int ni = Y::narrow_idx(L);
             word = sgn[ni / 2];
-            oidx = (ni & 1) ? (word >> 28) : ((word >> 12) & 15u);
-            top = (ni & 1) ? 15 : 31;
+            oidx = (ni & 1) ? ((word >> 16) & 15u) : (word & 15u);
+            top = (ni & 1) ? (31 - 20) : (31 - 4);
           }
           // ---- pass 1b: t_j = r_j - msg_old_j.  All "was edge j the minimum" tests first, into SGPR pairs: a VALU
           // write of VCC/SGPR needs two wait states before a v_cndmask may read it, batching avoids the s_nops.
@@ -440,7 +441,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           });
           // QUIRK ldpc.py:1563 (second minimum taken after adding +100000 to the signed argmin entry): it can
           // only bite when every other entry exceeds ~5e4 (filler / saturated LLRs) -- wave-uniform cold path.
-          if (__builtin_amdgcn_ballot_w64(a2 > 5.0e4f) != 0) {
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(a2 > 5.0e4f) != 0, 0)) {
             float v = t[D - 1];
             static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
               constexpr int j = D - 2 - decltype(jc)::value;
@@ -484,10 +485,10 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             }
           });
           if constexpr (WIDE) {
-            sgw[Y::wide_idx(L)] = nsg | (idx << 24);
+            sgw[Y::wide_idx(L)] = idx | (nsg << 5);           // argmin [4:0], signs [5+D-1:5]
           } else {
             constexpr int ni = Y::narrow_idx(L);
-            const uint32_t f = nsg | (idx << 12);             // 16-bit field: signs [D-1:0], argmin [15:12]
+            const uint32_t f = idx | (nsg << 4);              // 16-bit field: argmin [3:0], signs [4+D-1:4]
             if constexpr (ni & 1) sgn[ni / 2] = (word & 0x0000ffffu) | (f << 16);
             else sgn[ni / 2] = (word & 0xffff0000u) | f;
           }
