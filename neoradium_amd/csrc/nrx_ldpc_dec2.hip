@@ -324,7 +324,8 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
       // (scalar base + 32-bit lane offset: no per-column 64-bit pointers to keep in SGPRs)
       const uint32_t zq = (SPEC && ZC % 64 == 0) ? zb : (zb < zc4 ? zb : zc4 - 4u);   // partial last wave: stay inside
       const uint32_t off = zq + (uint32_t)(Y::ext_col(L) - 2) * zc4;
-      return __builtin_amdgcn_fmed3f(*(const float*)((const char*)in + off), -1e10f, 1e10f) + 0.0f;
+      return *(const float*)((const char*)in + off);   // raw: clipped when it is consumed, PFN layers later, so that
+                                                        // nothing waits for the load inside the layer that issues it
     };
     static_for<PFN>([&](auto k) __attribute__((always_inline)) {
       constexpr int Lk = Y::next_ext(Y::first_ext() == 0 ? B::ROWS - 1 : Y::first_ext() - 1, decltype(k)::value + 1);
@@ -424,7 +425,8 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           }
           if constexpr (EXT) {
             constexpr int slot = Y::ext_idx(L) % PFN;
-            t[D - 1] = epf[slot];
+            // clip to +-1e10 (ldpc.py:1536); + 0.0f turns -0.0 into +0.0 (the reference's sign test is (v < 0))
+            t[D - 1] = __builtin_amdgcn_fmed3f(epf[slot], -1e10f, 1e10f) + 0.0f;
             constexpr int Ln = Y::next_ext(L, PFN);
             epf[slot] = ext_load(Ln, z4);
           }
