@@ -174,3 +174,31 @@ def test_harq_batch_rv_and_reset(dev, bg, A, G, nl, qm):
             assert torch.equal(circ[i * cfg.C:(i + 1) * cfg.C], c1), (i, dt)
     with pytest.raises(ValueError):
         ops.ldpc_rate_recover(llr, cfg, nl, qm, rv=_t(rv, dev))            # needs the soft buffer
+
+
+def test_decoder_all_lifting_size_classes(dev):
+    """Fast f32 kernel (generic any-Zc path with 1 or 2 code blocks per workgroup, and the specialised sizes) against
+    the float64 kernel and the transmitted bits, over lifting sizes of every wave count and both base graphs."""
+    import torch
+    from neoradium_amd import ops, _lib
+    rng = np.random.default_rng(99)
+    # (bg, B): chosen to hit Zc = 384 352 320 288 256 208 144 96 64 36 (BG1) and 256 192 120 52 (BG2)
+    cases = [(1, 8448 * 3), (1, 7744 * 2), (1, 7040), (1, 6336), (1, 5632), (1, 4576), (1, 3168), (1, 2112), (1, 1408),
+             (1, 792), (2, 2560), (2, 1920), (2, 1200), (2, 520)]
+    seen = set()
+    for bg, B in cases:
+        cfg = _lib.ldpc_config(bg, B)
+        seen.add((bg, cfg.Zc))
+        n_cb = 5 if cfg.C == 1 else cfg.C * 2 + (1 if cfg.C % 2 == 0 else 0) * 0
+        n_tb = max(1, n_cb // cfg.C)
+        tb = _t(rng.integers(0, 2, (n_tb, B - 24)).astype(np.uint8), dev)
+        cbs = ops.ldpc_segment(tb, cfg)
+        coded = ops.ldpc_encode(cbs, cfg)
+        sig = 0.55 if bg == 1 else 0.7
+        llr = (2.0 / sig ** 2) * (1.0 - 2.0 * coded.double() + sig * _t(rng.standard_normal(tuple(coded.shape)), dev))
+        llr[:, cfg.K - cfg.F - 2 * cfg.Zc:cfg.K - 2 * cfg.Zc] = 1e20          # filler positions
+        d32 = ops.ldpc_decode(llr.float(), cfg, 8)
+        d64 = ops.ldpc_decode(llr, cfg, 8)
+        assert torch.equal(d32, d64), (bg, cfg.Zc)
+        assert torch.equal(d32, cbs), (bg, cfg.Zc)
+    assert len(seen) >= 12, seen
