@@ -100,11 +100,13 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(local)
+    # NRX_BENCH_BACKEND=gloo is a test hook: several ranks on ONE GPU (the collectives then go through the host)
+    backend = os.environ.get('NRX_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(local if backend == 'nccl' else local % torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl')           # RCCL over xGMI
+        dist.init_process_group(backend=backend)          # 'nccl' = RCCL over xGMI
 
     import neoradium_amd as nr
     from neoradium_amd import ops
@@ -131,9 +133,11 @@ def main():
         timer.on = False
         dec_ms = timer.mean_ms()
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        red = (lambda t: t) if backend == 'nccl' else (lambda t: t.cpu())
+        tmax = red(torch.tensor([dt], dtype=torch.float64, device=dev))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        counters = red(counters)
         dist.all_reduce(counters)                         # the path's only collective: 4 int64 error counters
     c = counters.cpu().numpy()
 
