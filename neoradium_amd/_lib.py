@@ -120,11 +120,24 @@ def check(rc):
     raise NrxError(f"libnrx error {rc}: {msg}")
 
 
+_empty_anchor = {}
+
+
 def ptr(t):
-    """Device pointer of a (contiguous) torch tensor, or NULL for None."""
+    """Device pointer of a (contiguous) torch tensor, or NULL for None.
+
+    An empty tensor has no storage (data_ptr() == 0) but is not "no buffer": libnrx rejects NULL for mandatory
+    arguments before it looks at the counts, so an empty tensor is passed as the address of a small per-device anchor
+    (never dereferenced: a zero count returns before any launch)."""
     if t is None:
         return None
     assert t.is_contiguous(), "nrx buffers must be contiguous"
+    if t.numel() == 0:
+        import torch
+        a = _empty_anchor.get(t.device)
+        if a is None:
+            a = _empty_anchor[t.device] = torch.zeros(16, dtype=torch.uint8, device=t.device)
+        return a.data_ptr()
     return t.data_ptr()
 
 

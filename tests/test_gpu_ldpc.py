@@ -202,3 +202,50 @@ def test_decoder_all_lifting_size_classes(dev):
         assert torch.equal(d32, d64), (bg, cfg.Zc)
         assert torch.equal(d32, cbs), (bg, cfg.Zc)
     assert len(seen) >= 12, seen
+
+
+@pytest.mark.parametrize("bg,A", [(2, 24), (2, 3816), (2, 3824), (1, 8424), (1, 8425), (1, 1277992)])
+def test_chain_round_trip_extreme_sizes(dev, bg, A):
+    """Size-independent property at the edges of the size range (smallest block, the one- / two-code-block boundary of
+    each base graph, the largest NR transport block: 152 code blocks): segment -> encode -> rate match -> noiseless
+    LLRs -> rate recover -> decode -> CRC + merge returns the transport block, every CRC passes."""
+    import torch
+    from neoradium_amd import ops, _lib
+    rng = np.random.default_rng(A)
+    cfg = _lib.ldpc_config(bg, A + 24)
+    nl, qm = 1, 2
+    G = int(np.ceil((A + 24) / 0.5 / (nl * qm))) * nl * qm
+    G = max(G, cfg.C * nl * qm)
+    tb = _t(rng.integers(0, 2, (2, A)).astype(np.uint8), dev)
+    coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+    bits = ops.ldpc_rate_match(coded, cfg, G, nl, qm)
+    llr = (8.0 * (1.0 - 2.0 * bits.float())).contiguous()
+    rr = ops.ldpc_rate_recover(llr, cfg, nl, qm)
+    dec = ops.ldpc_decode(rr, cfg, 6)
+    out, cb_ok, tb_ok = ops.ldpc_crc_merge(dec, cfg)
+    assert bool(cb_ok.all()) and bool(tb_ok.all()), (cfg.C, cfg.Zc)
+    assert torch.equal(out[:, :A], tb)
+
+
+def test_empty_batches(dev):
+    """Zero transport blocks / code words are a no-op everywhere (no launch, correctly shaped empty outputs)."""
+    import torch
+    from neoradium_amd import ops, _lib
+    from neoradium_amd.polar import PolarEncoder, PolarDecoder
+    cfg = _lib.ldpc_config(1, 10024)
+    tb = torch.empty((0, 10000), dtype=torch.uint8, device=dev)
+    cbs = ops.ldpc_segment(tb, cfg)
+    assert tuple(cbs.shape) == (0, cfg.K)
+    coded = ops.ldpc_encode(cbs, cfg)
+    assert tuple(coded.shape) == (0, cfg.N)
+    bits = ops.ldpc_rate_match(coded, cfg, 20000, 1, 2)
+    assert tuple(bits.shape) == (0, 20000)
+    rr = ops.ldpc_rate_recover(torch.empty((0, 20000), dtype=torch.float32, device=dev), cfg, 1, 2)
+    dec = ops.ldpc_decode(rr, cfg, 5)
+    assert tuple(dec.shape) == (0, cfg.K)
+    assert tuple(ops.crc(torch.empty((0, 100), dtype=torch.uint8, device=dev), '24A').shape) == (0, 24)
+    enc, pdec = PolarEncoder(30, 120, 'dci'), PolarDecoder(30, 120, 'dci')
+    x = enc.encodeDevice(torch.empty((0, 54), dtype=torch.uint8, device=dev))
+    assert tuple(x.shape) == (0, 128) and tuple(enc.rateMatchDevice(x).shape) == (0, 120)
+    msg, ok = pdec.decodeDevice(torch.empty((0, 128), dtype=torch.float64, device=dev))
+    assert tuple(msg.shape) == (0, 54) and ok.numel() == 0
