@@ -357,9 +357,9 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         // opaque copies keep the (loop-invariant) address arithmetic and the scalar table loads inside the layer
         uint32_t z4 = 4u * (uint32_t)z;
         ctab_t d4 = tab_it;
-        int wo = 0;   // opaque zero: keeps the layer's mask loads inside the layer (readfirstlane: provably uniform)
+        uint32_t wo = 0;   // opaque zero: keeps the layer's mask loads inside the layer (readfirstlane: provably uniform)
         asm volatile("" : "+v"(z4), "+s"(d4), "+s"(wo));
-        const mtab_t wml = wm + __builtin_amdgcn_readfirstlane(wo);
+        const mtab_t wml = (mtab_t)((const char __attribute__((address_space(4)))*)wm + __builtin_amdgcn_readfirstlane(wo));
         // byte addresses of element z of column 0 / buffer 0 of this slot: plain, wrapped (- Zc), and both + HI
         // (four live registers; everything else of an address is a DS immediate)
         const uint32_t zb = zb0, zbw = zb0 - zc4, zbh = zb0 + HI, zbwh = zb0 - zc4 + HI;
@@ -491,8 +491,10 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           } else {
             constexpr int ni = Y::narrow_idx(L);
             const uint32_t f = idx | (nsg << 4);              // 16-bit field: argmin [3:0], signs [4+D-1:4]
-            if constexpr (ni & 1) sgn[ni / 2] = (word & 0x0000ffffu) | (f << 16);
-            else sgn[ni / 2] = (word & 0xffff0000u) | f;
+            // one v_perm_b32 puts the field into its half of the word (and keeps the optimiser from folding the
+            // shift into the argmin constants): bytes 7..4 = f, bytes 3..0 = word
+            if constexpr (ni & 1) sgn[ni / 2] = __builtin_amdgcn_perm(f, word, 0x05040100u);   // f.lo16 : word.lo16
+            else sgn[ni / 2] = __builtin_amdgcn_perm(f, word, 0x03020504u);                    // word.hi16 : f.lo16
           }
         }
         if constexpr (Y::barrier_before(L + 1)) __syncthreads();
