@@ -243,6 +243,101 @@ encode_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __
     }
 }
 
+// Bit-packed encoder for lifting sizes that are multiples of 32: one wavefront per code block, a Zc-column is
+// NW = Zc/32 words, a circulant product is a word rotation + funnel shift (v_alignbit) instead of Zc byte reads.
+// Same equations as encode_kernel (ldpc.py:1033-1090); packing / unpacking the one-byte-per-bit interface is the
+// only part that touches memory: bytes -> words with wave ballots, words -> bytes with a 4-bits-per-store expansion.
+template <int BG>
+__global__ void __launch_bounds__(64)
+encode_packed_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __restrict__ coded, const EncTab tab) {
+  constexpr int ROWS = BG == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
+  constexpr int KB = BG == 1 ? 22 : 10;
+  constexpr int NWMAX = ZMAX / 32;
+  const int16_t* rs = BG == 1 ? kBg1RowStart : kBg2RowStart;
+  const int16_t* cl = BG == 1 ? kBg1Col : kBg2Col;
+  __shared__ uint32_t W[(KB + 4 + ROWS - 4) * NWMAX];   // info + core parity + extension parity columns
+  __shared__ uint32_t acc[4 * NWMAX];                   // information part of the four core rows
+  const int lane = threadIdx.x;
+  const int nw = zc >> 5;
+  const int K = KB * zc;
+  const int ncols = BG == 1 ? 68 : 52;
+  const int skip = puncture ? 2 : 0;
+  const uint8_t* in = cbs + (size_t)blockIdx.x * K;
+  uint8_t* out = coded + (size_t)blockIdx.x * (ncols - skip) * zc;
+  // word j of the column rotated by s:  out[z] = in[(z + s) mod Zc]
+  auto rotw = [&](int col, int s, int j) -> uint32_t {
+    const int q = s >> 5, r = s & 31;
+    int a = j + q;
+    if (a >= nw) a -= nw;
+    int b = a + 1;
+    if (b >= nw) b -= nw;
+    return __builtin_amdgcn_alignbit(W[col * NWMAX + b], W[col * NWMAX + a], r);
+  };
+
+  // ---- pack the information columns: 64 bits per ballot
+  for (int c = 0; c < KB; ++c)
+    for (int k = 0; k < zc; k += 64) {
+      const int z = k + lane;
+      const unsigned long long m = __ballot(z < zc && (in[c * zc + (z < zc ? z : 0)] & 1));
+      if (lane == 0) {
+        W[c * NWMAX + (k >> 5)] = (uint32_t)m;
+        if (k + 32 < zc) W[c * NWMAX + (k >> 5) + 1] = (uint32_t)(m >> 32);
+      }
+    }
+  __syncthreads();
+  // ---- information part of core rows 0..3 (lane = (row, word))
+  int sh_p[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < 4; ++q) sh_p[i][q] = -1;
+  for (int i = 0; i < 4; ++i)
+    for (int e = rs[i]; e < rs[i + 1]; ++e) {
+      const int c = cl[e];
+      if (c >= KB && c < KB + 4) sh_p[i][c - KB] = tab.s[e];
+    }
+  if (lane < 4 * nw) {
+    const int i = lane / nw, j = lane - i * nw;
+    uint32_t v = 0;
+    for (int e = rs[i]; e < rs[i + 1]; ++e)
+      if (cl[e] < KB) v ^= rotw(cl[e], tab.s[e], j);
+    acc[i * NWMAX + j] = v;
+  }
+  __syncthreads();
+  // p0 = rot(sum of the four rows, Zc - shift): ldpc.py:1068-1074
+  const int s0 = sh_p[1][0] >= 0 ? sh_p[1][0] : sh_p[2][0];
+  if (lane < nw) W[(KB + 4) * NWMAX + lane] = acc[lane] ^ acc[NWMAX + lane] ^ acc[2 * NWMAX + lane] ^ acc[3 * NWMAX + lane];
+  __syncthreads();
+  if (lane < nw) W[KB * NWMAX + lane] = rotw(KB + 4, (zc - s0) % zc, lane);   // column KB+4 is scratch here
+  __syncthreads();
+  // p1..p3: ldpc.py:1077-1080
+  for (int i = 0; i < 3; ++i) {
+    if (lane < nw) {
+      uint32_t v = acc[i * NWMAX + lane];
+      for (int q = 0; q <= i; ++q)
+        if (sh_p[i][q] >= 0) v ^= rotw(KB + q, sh_p[i][q], lane);
+      W[(KB + i + 1) * NWMAX + lane] = v;
+    }
+    __syncthreads();
+  }
+  // ---- extension parities (ldpc.py:1083-1084): items (row, word) over the wave
+  for (int it = lane; it < (ROWS - 4) * nw; it += 64) {
+    const int r = 4 + it / nw, j = it - (r - 4) * nw;
+    uint32_t v = 0;
+    for (int e = rs[r]; e < rs[r + 1]; ++e) {
+      const int c = cl[e];
+      if (c < KB + 4) v ^= rotw(c, tab.s[e], j);
+    }
+    W[(KB + r) * NWMAX + j] = v;
+  }
+  __syncthreads();
+  // ---- unpack: 4 bits -> 4 bytes per store (nibble * 0x00204081 puts bit k at bit 8k)
+  const int quads = zc >> 2;                                // 4-byte stores per column
+  for (int it = lane; it < (ncols - skip) * quads; it += 64) {
+    const int c = it / quads + skip, qd = it - (c - skip) * quads;
+    const uint32_t nib = (W[c * NWMAX + (qd >> 3)] >> ((qd & 7) * 4)) & 15u;
+    *reinterpret_cast<uint32_t*>(out + (size_t)(c - skip) * zc + 4 * qd) = (nib * 0x00204081u) & 0x01010101u;
+  }
+}
+
 // ---------------------------------------------------------------------------------- nrx_ldpc_rate_match
 // ldpc.py:1093-1159.  One thread per output bit: locate the code block r and position within E_r, undo the
 // bit interleaver (out[i*qm+q] = sel[q*(E/qm)+i]), map through the filler-free circular buffer at k0.
@@ -531,6 +626,15 @@ extern "C" int32_t nrx_ldpc_encode(const uint8_t* cbs, int32_t n_cb, const nrx_l
   for (int e = 0; e < E; ++e)
     tab.s[e] = (int16_t)((cfg->bg == 1 ? kBg1Shift[cfg->iLS][e] : kBg2Shift[cfg->iLS][e]) % cfg->Zc);
   const int threads = ((cfg->Zc + 63) / 64) * 64;
+  // output rows are (N or N+2Zc) bytes apart: 4-byte stores need that, and the buffer itself, 4-byte aligned
+  if (cfg->Zc % 32 == 0 && ((uintptr_t)coded & 3u) == 0) {
+    if (cfg->bg == 1)
+      hipLaunchKernelGGL(encode_packed_kernel<1>, dim3(n_cb), dim3(64), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+    else
+      hipLaunchKernelGGL(encode_packed_kernel<2>, dim3(n_cb), dim3(64), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+    NRX_CHECK_LAUNCH("nrx_ldpc_encode");
+    return NRX_OK;
+  }
   if (cfg->bg == 1)
     hipLaunchKernelGGL(encode_kernel<1>, dim3(n_cb), dim3(threads), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
   else
