@@ -195,7 +195,8 @@ int32_t nrx_mmse_equalize_f64(const void* rx, const void* hf, int64_t h_stride, 
 /* Noise level of addNoise(snrDb, useRxPower=True): grid.py:1040-1046 (np.var of the grid) and
  * waveform.py:107-142 (np.var of the CP-stripped samples, gathered through `gather`, / (12*numRbs) * nFFT).
  * x: n_batch items (x_stride elements apart) of n_per complex values; gather (nullable): n_gather element
- * offsets to reduce over instead of [0,n_per).  acc_ws: 3*n_batch doubles of scratch.
+ * offsets to reduce over instead of [0,n_per).  acc_ws: 192*n_batch doubles of scratch (per-workgroup partial sums,
+ * reduced in a fixed order: reproducible bit for bit).
  * var_out (nullable): complex variance per item.  If snr_lin != NULL (linear SNR, element b*snr_stride):
  *   sigma_out[b] = sqrt(var*mult/snr)  and  nv_out[b] = sigma^2 * nv_mult   (either may be NULL). */
 int32_t nrx_noise_level_f32(const void* x, int64_t n_per, int64_t x_stride, const int32_t* gather, int64_t n_gather,

@@ -85,11 +85,12 @@ mmse_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ hf, int64_t 
 
 // ---------------------------------------------------------------------------------------- complex variance
 // np.var of a complex array = mean |x - mean(x)|^2 (grid.py:1046, waveform.py:117): per batch item, float64,
-// two-level reduction (sum x, sum |x|^2 per workgroup -> atomics on 3 doubles), finalised by var_finish_kernel.
+// two-level reduction: (sum x, sum |x|^2) per workgroup into acc[b][workgroup][3], summed in workgroup order by
+// var_finish_kernel -- no atomics, so the result (and with it the noise scaling of a slot) is reproducible bit for bit.
 template <typename T>
 __global__ void __launch_bounds__(256)
 var_partial_kernel(const cx<T>* __restrict__ x, int64_t n_per, int64_t x_stride, const int32_t* __restrict__ gather,
-                   int64_t n_gather, double* __restrict__ acc /* n_batch x 3 */) {
+                   int64_t n_gather, double* __restrict__ acc /* n_batch x gridDim.x x 3 */) {
   const int b = blockIdx.y;
   const int64_t n = gather ? n_gather : n_per;
   double sr = 0, si = 0, s2 = 0;
@@ -112,21 +113,29 @@ var_partial_kernel(const cx<T>* __restrict__ x, int64_t n_per, int64_t x_stride,
   if (threadIdx.x == 0) {
     double a = 0, c = 0, d = 0;
     for (int k = 0; k < 4; ++k) { a += red[0][k]; c += red[1][k]; d += red[2][k]; }
-    atomicAdd(&acc[b * 3 + 0], a);
-    atomicAdd(&acc[b * 3 + 1], c);
-    atomicAdd(&acc[b * 3 + 2], d);
+    double* o = acc + ((size_t)b * gridDim.x + blockIdx.x) * 3;
+    o[0] = a;
+    o[1] = c;
+    o[2] = d;
   }
 }
 
 // sigma[b] = sqrt(var * mult / snr_lin[b])  and  noise_var_out[b] = sigma^2 * nv_mult (both optional outputs)
 template <typename T>
-__global__ void var_finish_kernel(const double* __restrict__ acc, double n, int n_batch, T* __restrict__ var_out,
-                                  const double* __restrict__ snr_lin, int snr_stride, double mult,
+__global__ void var_finish_kernel(const double* __restrict__ acc, int n_part, double n, int n_batch,
+                                  T* __restrict__ var_out, const double* __restrict__ snr_lin, int snr_stride, double mult,
                                   T* __restrict__ sigma_out, T* __restrict__ nv_out, double nv_mult) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_batch) return;
-  const double mr = acc[b * 3] / n, mi = acc[b * 3 + 1] / n;
-  double var = acc[b * 3 + 2] / n - (mr * mr + mi * mi);
+  double sr = 0, si = 0, s2 = 0;
+  for (int k = 0; k < n_part; ++k) {
+    const double* p = acc + ((size_t)b * n_part + k) * 3;
+    sr += p[0];
+    si += p[1];
+    s2 += p[2];
+  }
+  const double mr = sr / n, mi = si / n;
+  double var = s2 / n - (mr * mr + mi * mi);
   if (var < 0) var = 0;
   if (var_out) var_out[b] = (T)var;
   if (snr_lin) {
@@ -303,18 +312,17 @@ template <typename T>
 static int32_t noise_level_entry(const void* x, int64_t n_per, int64_t x_stride, const int32_t* gather, int64_t n_gather,
                                  int32_t n_batch, double* acc_ws, void* var_out, const double* snr_lin, int32_t snr_stride,
                                  double mult, void* sigma_out, void* nv_out, double nv_mult, void* stream) {
-  NRX_REQUIRE(x && acc_ws, NRX_E_ARG, "nrx_noise_level: NULL buffer (acc_ws = 3 doubles per batch item)");
+  NRX_REQUIRE(x && acc_ws, NRX_E_ARG, "nrx_noise_level: NULL buffer (acc_ws = 192 doubles per batch item)");
   NRX_REQUIRE(n_per > 0 && n_batch >= 0, NRX_E_ARG, "nrx_noise_level: bad sizes");
   if (n_batch == 0) return NRX_OK;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(acc_ws, 0, sizeof(double) * 3 * n_batch, st);
   const int64_t n = gather ? n_gather : n_per;
   int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(var_partial_kernel<T>, dim3(gx, n_batch), dim3(256), 0, st, (const cx<T>*)x, n_per, x_stride, gather,
                      n_gather, acc_ws);
-  hipLaunchKernelGGL(var_finish_kernel<T>, dim3((n_batch + 63) / 64), dim3(64), 0, st, acc_ws, (double)n, n_batch,
+  hipLaunchKernelGGL(var_finish_kernel<T>, dim3((n_batch + 63) / 64), dim3(64), 0, st, acc_ws, gx, (double)n, n_batch,
                      (T*)var_out, snr_lin, snr_stride, mult, (T*)sigma_out, (T*)nv_out, nv_mult);
   NRX_CHECK_LAUNCH("nrx_noise_level");
   return NRX_OK;

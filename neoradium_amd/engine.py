@@ -26,7 +26,7 @@ from .waveform import Waveform
 
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
-                 decoder="f32", windowing="STD", dev=None):
+                 decoder="f32", windowing="STD", dev=None, firstPassIter=None):
         if pdsch.numCW != 1:
             raise NotImplementedError("PdschLink: two-codeword PDSCH (more than 4 layers) is not built")
         if pdsch.prgSize != 0:
@@ -43,6 +43,13 @@ class PdschLink:
         self.carrier = bwp.carrier
         self.freqDomain, self.chanEst, self.decoder = freqDomain, chanEst, decoder
         self.numIter = int(numIter)
+        # Opt-in two-pass decoding (NOT the reference's schedule, off by default): every code block is first decoded
+        # with `firstPassIter` iterations; the blocks whose CRC fails are then decoded again FROM SCRATCH with the full
+        # `numIter` iterations, so a failing block gets exactly the reference's result and a passing block is the
+        # code word the full run converges to as well.  Costs one host read (the number of failing blocks) per batch.
+        self.firstPassIter = None if firstPassIter is None else int(firstPassIter)
+        if self.firstPassIter is not None and not 0 < self.firstPassIter < self.numIter:
+            raise ValueError("firstPassIter must be between 1 and numIter-1")
         self.codeRate = codeRate
         self.nl = pdsch.numLayers
         self.qm = pdsch.modems[0].qm
@@ -220,8 +227,16 @@ class PdschLink:
             rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm)
         else:
             rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm, rv=harq[0], circ=harq[1], reset=harq[2])
-        dec = ops.ldpc_decode(rr, cfg, self.numIter)
-        tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
+        if self.firstPassIter is None:
+            dec = ops.ldpc_decode(rr, cfg, self.numIter)
+            tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
+        else:
+            dec = ops.ldpc_decode(rr, cfg, self.firstPassIter)
+            _, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb=False)
+            fail = (cb_ok.reshape(-1) == 0).nonzero().reshape(-1)              # host read: how many blocks go on
+            if fail.numel():
+                dec.index_copy_(0, fail, ops.ldpc_decode(rr.index_select(0, fail), cfg, self.numIter))
+            tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
         if counters is not None:
             ops.count_errors(cb_ok, tb_out, tb, counters)
         if details:

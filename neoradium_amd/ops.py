@@ -325,7 +325,7 @@ def noise_level(x, snr_lin=None, mult=1.0, nv_mult=1.0, gather=None):
     sfx, rt = _ct(flat)
     n, m = flat.shape
     dev = _dev(flat)
-    acc = torch.empty(3 * n, dtype=torch.float64, device=dev)
+    acc = torch.empty(192 * n, dtype=torch.float64, device=dev)       # <= 64 workgroup partials x 3 per item
     var = torch.empty(n, dtype=rt, device=dev)
     g = _i32(gather, dev)
     snr = sigma = nv = None

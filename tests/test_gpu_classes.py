@@ -258,3 +258,29 @@ def test_engine_batched_harq(dev):
     b, s2 = link.run_harq(P, R - 2, snr, seed=3, maxTries=MT, state=s1)
     assert np.array_equal(b['txBlocks'], tx) and np.array_equal(b['rxBlocks'], rx) and b['numTimeouts'] == st['numTimeouts']
     assert np.array_equal(s2['tries'].cpu().numpy(), tries)
+
+
+def test_engine_two_pass_decoding_is_equivalent(dev):
+    """Opt-in firstPassIter: a short first pass + a full re-decode of the failing blocks gives the same CRC verdicts and
+    the same decoded bits as the reference schedule (fixed numIter for every block) around the waterfall."""
+    import neoradium_amd as nr
+    cfg = dict(seed=5, numRbs=51, spacing=30, mod='16QAM', layers=2, dm=dict(configType=1, additionalPos=1),
+               chan=('cdl', 'C', 300, 5, [1, 1], [1, 1]), slot0=0)
+    car, bwp, p, ch = _slot(nr, cfg)
+    full = nr.PdschLink(p, ch, 490 / 1024, numIter=30, decoder="f32")
+    two = nr.PdschLink(p, ch, 490 / 1024, numIter=30, decoder="f32", firstPassIter=8)
+    n_fail = 0
+    for snr in (10.0, 10.5, 11.0):
+        _, da = full.run(0, 16, snr, seed=11, details=True)
+        _, db = two.run(0, 16, snr, seed=11, details=True)
+        a, b = da[0][1], db[0][1]
+        assert torch_equal(a['cb_ok'], b['cb_ok']) and torch_equal(a['tb_out'], b['tb_out']), snr
+        n_fail += int((a['cb_ok'] == 0).sum())
+    assert n_fail > 0                                       # the second pass did run
+    with pytest.raises(ValueError):
+        nr.PdschLink(p, ch, 490 / 1024, numIter=30, firstPassIter=30)
+
+
+def torch_equal(x, y):
+    import torch
+    return torch.equal(x, y)
