@@ -235,6 +235,17 @@ int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32
 /* waveform.py:317-341 sync + :473-527 ofdmDemodulate (f0=0, cpOffsetRatio=0.5): waveform rows (n_items*n_ant rows
  * of wave_stride samples, wave_len valid) -> grid (n_items,n_ant,n_sym,K).  t_off (nullable, device): timing
  * offset of item b at t_off[b*t_off_stride]. */
+/* nrx_awgn_* followed by nrx_ofdm_demodulate_* in one pass (throughput mode: the noisy waveform is never written):
+ * wave is the NOISELESS received waveform, rows contiguous (wave_stride == wave_len); sigma[item*sigma_stride] and
+ * (seed, stream_id, batch_offset) as for nrx_awgn_* over the item's n_ant*wave_len elements.  Identical output. */
+int32_t nrx_ofdm_demodulate_awgn_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
+                                     int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
+                                     const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride,
+                                     uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* grid, void* stream);
+int32_t nrx_ofdm_demodulate_awgn_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
+                                     int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
+                                     const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride,
+                                     uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* grid, void* stream);
 /* Grid.precode (wideband F, grid.py:505-516) fused into the modulator's load: layers (n_items, n_layers, n_sym, K),
  * f: per item (f_stride = n_ports*n_layers) or shared (f_stride = 0) n_ports x n_layers; wave rows = item*n_ports+port.
  * Same arithmetic as nrx_precode_* followed by nrx_ofdm_modulate_*; the precoded grid is never materialised.

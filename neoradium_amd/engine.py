@@ -205,9 +205,10 @@ class PdschLink:
             width = ry.shape[-1]
             _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=self.nfft / (12.0 * self.bwp.numRbs),
                                            nv_mult=float(self.nfft), gather=self._cp_gather(sis, width))
-            ry = ops.add_noise(ry, noise.to(dev), sigma) if noise is not None else \
-                ops.awgn(ry, sigma, seed, stream_id=2, batch_offset=int(slots[0]))
-            rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off)
+            if noise is not None:
+                rxg = ops.ofdm_demodulate(ops.add_noise(ry, noise.to(dev), sigma), self.nfft, cps, self.K, t_off=off)
+            else:       # the noise is generated while the demodulator loads its samples (= ops.awgn, then demodulate)
+                rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off, awgn=(sigma, seed, 2, int(slots[0])))
 
         # ---- Rx
         hest = None

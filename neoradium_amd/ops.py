@@ -402,8 +402,10 @@ def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0, f=None):
     return wave
 
 
-def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None):
-    """Waveform.sync(t_off).ofdmDemodulate: (n,Nr,S_in) -> (n,Nr,L,K)."""
+def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None):
+    """Waveform.sync(t_off).ofdmDemodulate: (n,Nr,S_in) -> (n,Nr,L,K).
+
+    ``awgn`` = (sigma, seed, stream_id, batch_offset): add the noise of :func:`awgn` while loading (same values)."""
     wave = wave.contiguous()
     sfx, _ = _ct(wave)
     n, nr, S_in = wave.shape
@@ -415,6 +417,15 @@ def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None):
         if to.numel() not in (1, n):
             raise ValueError("one timing offset per batch item expected")
     grid = torch.empty((n, nr, L, K), dtype=wave.dtype, device=dev)
+    if awgn is not None:
+        sigma, seed, stream_id, batch_offset = awgn
+        _, rt = _ct(wave)
+        sg = torch.as_tensor(sigma, dtype=rt, device=dev).reshape(-1).contiguous()
+        fn = getattr(lib(), 'nrx_ofdm_demodulate_awgn_' + sfx)
+        check(fn(ptr(wave), S_in, S_in, ptr(to), 0 if to is None or to.numel() == 1 else 1, n, nr, K, nfft,
+                 _host_i32(cp_lens), L, ptr(sg), 0 if sg.numel() == 1 else 1, int(seed), int(stream_id), int(batch_offset),
+                 ptr(grid), stream()))
+        return grid
     fn = getattr(lib(), 'nrx_ofdm_demodulate_' + sfx)
     check(fn(ptr(wave), S_in, S_in, ptr(to), 0 if to is None or to.numel() == 1 else 1, n, nr, K, nfft,
              _host_i32(cp_lens), L, ptr(grid), stream()))

@@ -154,6 +154,12 @@ def test_ofdm_mod_demod(dev, mu, nfft, K, slot):
     g = ops.ofdm_demodulate(T(rxw, dev), nfft, cps, K, t_off=T(toff, dev)).cpu().numpy()
     for i in range(n):
         assert rel(g[i], op.ofdm_demodulate(rxw[i][:, toff[i]:], nfft, cps, K)) < 1e-12
+    # noise generated inside the demodulator's load == awgn, then demodulate (same Philox stream, same samples)
+    sig = T(np.float64([0.3, 0.7]), dev)
+    noisy = ops.awgn(T(rxw, dev), sig, 77, stream_id=2, batch_offset=5)
+    a = ops.ofdm_demodulate(noisy, nfft, cps, K, t_off=T(toff, dev))
+    b = ops.ofdm_demodulate(T(rxw, dev), nfft, cps, K, t_off=T(toff, dev), awgn=(sig, 77, 2, 5))
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
     # round trip without windowing recovers the grid (cdlTiming.ipynb cell 3: NMSE ~ 1e-32)
     nw = ops.ofdm_modulate(T(grid, dev), nfft, cps, window_len=0)
     back = ops.ofdm_demodulate(nw, nfft, cps, K).cpu().numpy()
