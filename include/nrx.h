@@ -342,8 +342,10 @@ int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, const int32_t*
  *   NULL, inv_subblock = inverse sub-block interleaver (N).  E >= N adds the repeated LLRs (TS 38.212 5.4.1.2; the
  *   reference raises there, polar.py:914-915).
  * nrx_polar_scl_decode_f64 -- polar.py:606-720 SclDecoder + :931-982 PolarDecoder.decode: clip to +-20, min-sum
- *   SCL with list_size <= 8, CRC-aided pick.  info_mask: N bytes, 1 = non-frozen leaf (message or parity-check
- *   bit), n_info of them; msg_src[m]: which non-frozen leaf (in leaf order) carries message bit m after input
+ *   SCL with list_size <= 8, CRC-aided pick.  info_mask: N bytes, bit 0 = non-frozen leaf (message or parity-check
+ *   bit), n_info of them; optionally, on a frozen leaf i, bits 1..4 = s0 > 0 announce that leaves [i, i + 2^s0) are
+ *   all frozen and i is a multiple of 2^s0 (a rate-0 node): the kernel then expands that subtree level by level and
+ *   adds its 2^s0 penalties in leaf order -- same values, same path costs, far fewer sequential steps; msg_src[m]: which non-frozen leaf (in leaf order) carries message bit m after input
  *   de-interleaving (K entries).  msg_out: n_cw x K (first CRC-passing candidate, else the cheapest), crc_ok: n_cw;
  *   optional cand_out: n_cw x list_size x K and cost_out: n_cw x list_size (all candidates, cheapest first).
  *   crc_poly_id -1 = no CRC (cheapest candidate). */

@@ -18,6 +18,7 @@
 // order and the path costs are bit-identical to the reference's.
 #include "nrx_common.h"
 #include "nrx_crc.h"
+#include <utility>
 
 namespace {
 
@@ -105,6 +106,7 @@ struct SclLayout {
   int xl_off;    // bytes
   int hist_off;  // bytes
   int scr_off;   // bytes
+  int kind_off;  // bytes: per-leaf kind byte (copy of info_mask)
   int total;     // bytes
 };
 __host__ __device__ inline int xl_words(int s) { return s <= 5 ? 1 : (1 << (s - 5)); }
@@ -124,11 +126,27 @@ __host__ __device__ inline SclLayout scl_layout(int n, int k_info) {
   l.hist_off = l.xl_off + xl_bytes;
   const int hist_bytes = ((LMAX * k_info) + 7) & ~7;
   l.scr_off = l.hist_off + hist_bytes;
-  l.total = l.scr_off + 16 * 8 + 16 * 4;
+  l.kind_off = l.scr_off + 16 * 8 + 16 * 4;
+  l.total = l.kind_off + N;
   return l;
 }
 
 __device__ __forceinline__ double clip20(double v) { return fmin(fmax(v, -20.0), 20.0); }  // polar.py:958
+
+// value of lane r (compile-time r) as a wave-uniform scalar: two v_readlane instead of two LDS-crossbar permutes
+template <int R>
+__device__ __forceinline__ double lane_value(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, R);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), R);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int N, class F>
+__device__ __forceinline__ void unrolled(F&& f) {
+  [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+    (f(std::integral_constant<int, I>{}), ...);
+  }(std::make_integer_sequence<int, N>{});
+}
 
 // One wavefront per codeword.  info_mask[i] = 1 for every non-frozen leaf (message and parity-check bits).
 __global__ __launch_bounds__(64) void polar_scl_kernel(
@@ -147,6 +165,11 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
   const int lane = threadIdx.x;
   const int64_t cw = blockIdx.x;
   const double* chan = llr_in + cw * N;
+  // leaf kinds: bit 0 = non-frozen leaf; bits 1..4 = s0 > 0 when leaves [i, i + 2^s0) form an aligned all-frozen
+  // block (rate-0 node) starting here
+  uint8_t* const kind = smem + lay.kind_off;
+  for (int i = lane; i < N; i += 64) kind[i] = info_mask[i];
+  __syncthreads();
 
   // per-candidate state, owned by lane c (< LMAX)
   double cost = 0.0;
@@ -156,8 +179,12 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
 
   auto stage_ptr = [&](int s) { return lds_llr + LMAX * ((1 << s) - 2); };  // stage s >= 1
 
-  for (int i = 0; i < N; ++i) {
+  for (int i = 0; i < N;) {
     const int t = (i == 0) ? n : __builtin_ctz(i);
+    const int kd = kind[i];
+    int s0 = (kd & 1) ? 0 : (kd >> 1) & 15;   // rate-0 node of 2^s0 frozen leaves starts here (0: plain leaf)
+    if (s0 > t) s0 = t;                        // (cannot happen for a well-formed table; keeps the descent sane)
+    if (s0 > n - 1) s0 = n - 1;
     double leaf = 0.0;  // leaf LLR of candidate `lane`
     // ---- g step at stage t (right child entered): polar.py:659-663
     if (i != 0) {
@@ -165,7 +192,7 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
       const int half = 1 << t;
       const int items = count << t;
       const double* src = (t + 1 < n) ? stage_ptr(t + 1) : nullptr;
-      double* dst = (t > 0) ? stage_ptr(t) : nullptr;
+      double* dst = (t > 0) ? stage_ptr(t) : nullptr;   // (t >= s0 >= 1 on the rate-0 path)
       const uint32_t* xs = xl + xl_stage_off(t);
       const int xw = xl_words(t);
       for (int it0 = 0; it0 < items; it0 += 64) {
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
       __syncthreads();
     }
     // ---- f steps down to the leaf: polar.py:697-705
-    for (int s = ((i == 0) ? n : t) - 1; s >= 0; --s) {
+    for (int s = ((i == 0) ? n : t) - 1; s >= s0; --s) {
       const int half = 1 << s;
       const int items = count << s;
       const double* src = (s + 1 < n) ? stage_ptr(s + 1) : nullptr;
@@ -231,9 +258,44 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
       lrow = (lrow & ~mask) | ((0x1111111111111111ull * (uint64_t)(lane & 15)) & mask);
     }
 
+    // ---- rate-0 node: every leaf below is frozen, so no decision depends on another one's.  The whole subtree is
+    // expanded level by level, in place in the stage-s0 rows (left child <- f(a,b), right child <- g(a,b,u=0) = b + a:
+    // the values the leaf-by-leaf recursion computes, polar.py:697-713), then the 2^s0 frozen-leaf penalties are
+    // added to each path cost in leaf order (polar.py:623-628: same additions, same order).
+    if (s0 > 0) {
+      double* A = stage_ptr(s0);
+      const int rowlen = 1 << s0;
+      for (int lev = s0; lev >= 1; --lev) {
+        const int h = 1 << (lev - 1);
+        const int items = count << (s0 - 1);
+        for (int it0 = 0; it0 < items; it0 += 64) {
+          const int it = it0 + lane;
+          if (it < items) {
+            const int c = it >> (s0 - 1);
+            const int pidx = it & ((1 << (s0 - 1)) - 1);          // pair index inside the row
+            const int idx = ((pidx >> (lev - 1)) << lev) | (pidx & (h - 1));
+            double* r = A + c * rowlen + idx;
+            const double a = r[0], b = r[h];
+            const double m = fmin(fabs(a), fabs(b));
+            double v = ((a < 0.0) != (b < 0.0)) ? -m : m;
+            if (a == 0.0 || b == 0.0) v = 0.0;
+            r[0] = v;
+            r[h] = b + a;
+          }
+        }
+        __syncthreads();
+      }
+      if (lane < count) {
+        const double* r = A + lane * rowlen;
+        for (int k = 0; k < rowlen; ++k) cost = cost - fmin(0.0, r[k]);
+      }
+    }
+
     // ---- leaf
     int ubit = 0;
-    if (!info_mask[i]) {
+    if (s0 > 0) {
+      // (handled above)
+    } else if (!(kd & 1)) {
       if (lane < count) cost = cost - fmin(0.0, leaf);  // polar.py:623-628
     } else {
       // polar.py:631-656: 2*count forked costs [all 0-branches, all 1-branches], keep the L cheapest, stable.
@@ -243,11 +305,12 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
       const double nc = qb ? (cq + fmax(0.0, lq)) : (cq - fmin(0.0, lq));
       const bool valid = qc < count;
       int rank = 0;
-      for (int r = 0; r < 16; ++r) {
-        const double cr = __shfl(nc, r, 64);
+      unrolled<16>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        const double cr = lane_value<r>(nc);
         const bool vr = (r & 7) < count;
         rank += (vr && (cr < nc || (cr == nc && r < q))) ? 1 : 0;
-      }
+      });
       if (lane < 16) {
         sc_cost[lane] = nc;
         if (valid && rank < L) sel[rank] = q;
@@ -272,8 +335,9 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
 
     // ---- partial sums: the finished leaf closes `S` right children in a row (polar.py:666-668); the
     // combined word becomes the left-child result of stage S.
-    if (i != N - 1) {
-      const int S = __builtin_ctz(~(unsigned)i);
+    const int il = i + (1 << s0) - 1;          // last leaf of this step
+    if (il != N - 1) {
+      const int S = __builtin_ctz(~(unsigned)il);
       const int W = xl_words(S);
       const int items = count * W;
       for (int it0 = 0; it0 < items; it0 += 64) {
@@ -284,14 +348,14 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
         const uint32_t x_lo = __shfl((uint32_t)xrow, c, 64), x_hi = __shfl((uint32_t)(xrow >> 32), c, 64);
         const uint64_t xr = ((uint64_t)x_hi << 32) | x_lo;
         if (it < items) {
-          uint32_t cur = ub;
+          uint32_t cur = ub;                   // the step's own partial-sum vector (all zero for a rate-0 node)
           const int low = S < 5 ? S : 5;
-          for (int j = 0; j < low; ++j) {
+          for (int j = s0; j < low; ++j) {
             const uint32_t xv = xl[xl_stage_off(j) + (int)((xr >> (4 * j)) & 15u)];
             const int sh = 1 << j;
             cur = ((xv ^ cur) & ((1u << sh) - 1u)) | (cur << sh);
           }
-          for (int j = 5; j < S; ++j) {
+          for (int j = (s0 > 5 ? s0 : 5); j < S; ++j) {
             if (!((w >> (j - 5)) & 1)) {
               const int wj = xl_words(j);
               cur ^= xl[xl_stage_off(j) + (int)((xr >> (4 * j)) & 15u) * wj + (w & (wj - 1))];
@@ -303,15 +367,17 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
       xrow = (xrow & ~(15ull << (4 * S))) | ((uint64_t)(lane & 15) << (4 * S));
       __syncthreads();
     }
+    i = il + 1;
   }
 
   // ---- final ranking by path cost (polar.py:671-678), stable
   {
     int rank = 0;
-    for (int r = 0; r < LMAX; ++r) {
-      const double cr = __shfl(cost, r, 64);
+    unrolled<LMAX>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      const double cr = lane_value<r>(cost);
       rank += (r < count && (cr < cost || (cr == cost && r < lane))) ? 1 : 0;
-    }
+    });
     if (lane < count) sel[rank] = lane;
     __syncthreads();
   }

@@ -670,7 +670,7 @@ def polar_scl_decode(llr, info_mask, n_info, msg_src, list_size=8, crc_poly=None
     llr = llr.contiguous()
     n_cw, N = llr.shape
     if info_mask.dtype != torch.uint8 or info_mask.numel() != N:
-        raise ValueError(f"info_mask must be uint8 with N={N} entries")
+        raise ValueError(f"info_mask must be uint8 with N={N} entries (bit 0: non-frozen; bits 1..4: rate-0 node size)")
     K = msg_src.numel()
     dev = _dev(llr)
     msg = torch.empty((n_cw, K), dtype=torch.uint8, device=dev)

@@ -313,10 +313,24 @@ class PolarDecoder(PolarBase):
         mask = np.ones(NN, dtype=np.uint8)
         mask[self.frozenBits] = 0
         leafRank = np.cumsum(mask) - 1                      # position of a non-frozen leaf among the non-frozen
+        nInfo = int(mask.sum())
+        # rate-0 nodes: bits 1..4 of a frozen leaf's byte = log2 of the largest aligned all-frozen block starting there
+        # (the kernel expands such a block in one go instead of leaf by leaf; see include/nrx.h)
+        kinds = mask.copy()
+        i = 0
+        while i < NN:
+            if mask[i]:
+                i += 1
+                continue
+            s = 0
+            while s + 1 < int(np.log2(NN)) and i % (2 << s) == 0 and i + (2 << s) <= NN and not mask[i:i + (2 << s)].any():
+                s += 1
+            kinds[i] = s << 1
+            i += 1 << s
         msg = np.int64(self.msgBits)
         if self.inInterleaveIndexes is not None:
             msg = msg[self.inInterleaveIndexes]
-        return (self._d('mask', lambda: mask), int(mask.sum()), self._d('msrc', lambda: np.int32(leafRank[msg])))
+        return (self._d('mask', lambda: kinds), nInfo, self._d('msrc', lambda: np.int32(leafRank[msg])))
 
     def decodeDevice(self, llr, wantCandidates=False):
         """(n, N) float64 device LLRs -> message bits incl. CRC (n, K), CRC flags (n,) [, candidates, path costs]."""
