@@ -458,7 +458,8 @@ extern "C" int32_t nrx_apply_td_f64(const void* x, int32_t n_items, int32_t n_tx
 namespace {
 __global__ void __launch_bounds__(256)
 chan_matrix_sub_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int n_rt, int cl, const int32_t* __restrict__ off,
-                       int K, int nfft, int k0, int n_k, cd* __restrict__ H, int64_t total) {
+                       int K, int nfft, int k0, int n_k, cd* __restrict__ H, int64_t total, const cd* __restrict__ tw) {
+  const int tws = nrx::FFT_TW_N / nfft;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int rt = (int)(g % n_rt);
     const int k = (int)((g / n_rt) % n_k);
@@ -472,9 +473,11 @@ chan_matrix_sub_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int n_
     for (int l = 0; l < use; ++l) {
       const int pos = (l - o + nfft) & (nfft - 1);
       const int ph = (int)(((int64_t)bin * pos) & (nfft - 1));
-      double s, c2;
-      sincospi(-2.0 * (double)ph / (double)nfft, &s, &c2);
-      nrx::cmac(acc, src[l], cd(c2, s));
+      // exp(-2 pi i ph / nfft) from the shared twiddle table (entries k < N/2; the other half by W[k + N/2] = -W[k])
+      const int ti = ph * tws;
+      cd w = tw[ti & (nrx::FFT_TW_N / 2 - 1)];
+      if (ti >= nrx::FFT_TW_N / 2) w = cd(-w.re, -w.im);
+      nrx::cmac(acc, src[l], w);
     }
     H[g] = acc;
   }
@@ -711,8 +714,11 @@ extern "C" int32_t nrx_channel_matrix_sub_f64(const void* cir, int32_t n_items, 
   NRX_REQUIRE(k0 >= 0 && n_k >= 1 && k0 + n_k <= K && nc >= 1 && nc <= n_t, NRX_E_SHAPE, "nrx_channel_matrix_sub: bad range");
   const int64_t total = (int64_t)n_items * nc * n_k * n_rx * n_tx;
   if (total == 0) return NRX_OK;
+  NRX_REQUIRE(nfft <= nrx::FFT_TW_N, NRX_E_UNSUPPORTED, "nrx_channel_matrix_sub: nfft > %d", nrx::FFT_TW_N);
+  const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
+  NRX_REQUIRE(tw, NRX_E_HIP, "nrx_channel_matrix_sub: FFT twiddle table unavailable");
   hipLaunchKernelGGL(chan_matrix_sub_kernel, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const cd*)cir, n_t, nc, n_rx * n_tx, cl, chan_offset, K, nfft, k0, n_k, (cd*)H, total);
+                     (const cd*)cir, n_t, nc, n_rx * n_tx, cl, chan_offset, K, nfft, k0, n_k, (cd*)H, total, tw);
   NRX_CHECK_LAUNCH("nrx_channel_matrix_sub");
   return NRX_OK;
 }
