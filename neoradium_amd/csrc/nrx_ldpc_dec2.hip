@@ -135,6 +135,11 @@ __device__ __forceinline__ float clip10(float x) { return fminf(fmaxf(x, -1e10f)
 __device__ __forceinline__ float sign_from(uint32_t signsrc, float mag) {  // mag >= 0
   return __uint_as_float((signsrc & 0x80000000u) | __float_as_uint(mag));
 }
+__device__ __forceinline__ uint32_t dbl(uint32_t w) {   // w + w as an add the optimiser cannot turn into a shift
+  uint32_t r;
+  asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(w));
+  return r;
+}
 __device__ __forceinline__ uint32_t wrap4(uint32_t a4, uint32_t zc4) {  // a4 in [0, 2*zc4)
   const uint32_t b = a4 - zc4;
   return a4 < b ? a4 : b;
@@ -367,9 +372,9 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         float a1 = 0.0f, a2 = 0.0f;
         uint32_t px = 0, word = 0;
         if (live) {   // (wave-uniform; the per-layer branch also keeps each layer its own scheduling region)
-          // ---- pass 1a: issue every LDS read of the layer
+          // ---- pass 1a: issue every LDS read of the layer (last edge first: the order pass 1b consumes them in)
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
+            constexpr int j = DC - 1 - decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
             constexpr uint32_t cof = (uint32_t)((Y::touch_par(L, col) * B::CORE + col) * ZS * 4);   // read buffer
             if constexpr (SPEC) {
@@ -407,10 +412,16 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             was_min[j] = oidx == (uint32_t)j;
           });
           __builtin_amdgcn_sched_barrier(0);
+          // sign of edge j at bit 31 of a running word (last edge first, doubled per edge: an add issues at almost
+          // twice the rate of a shift on this chip, profiles/r1_valu_issue_rates.txt)
+          uint32_t wrun = word << (top - (DC > 0 ? DC - 1 : 0));
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
+            constexpr int j = DC - 1 - decltype(jc)::value;
+            uint32_t wnext = 0;
+            if constexpr (j > 0) wnext = dbl(wrun);   // (issued ahead of its use: the word after an asm needs a wait state)
             const float mag = was_min[j] ? om2 : om1;
-            t[j] = t[j] - sign_from(word << (top - j), mag);
+            t[j] = t[j] - sign_from(wrun, mag);
+            wrun = wnext;
           });
           if constexpr (SPEC) {
             // every LDS read of this layer has been consumed: fetch the next layer's wrap masks (scalar loads share
