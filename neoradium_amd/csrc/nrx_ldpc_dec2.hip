@@ -438,8 +438,6 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             constexpr int slot = Y::ext_idx(L) % PFN;
             // clip to +-1e10 (ldpc.py:1536); + 0.0f turns -0.0 into +0.0 (the reference's sign test is (v < 0))
             t[D - 1] = __builtin_amdgcn_fmed3f(epf[slot], -1e10f, 1e10f) + 0.0f;
-            constexpr int Ln = Y::next_ext(L, PFN);
-            epf[slot] = ext_load(Ln, z4);
           }
           // ---- min-sum: two smallest magnitudes and the sign parity; no compares, no argmin here
           a1 = __builtin_fabsf(t[0]);
@@ -463,6 +461,14 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             const float q = __builtin_fabsf(v + 100000.0f);
             a2 = (a2 > 5.0e4f && q < a2) ? q : a2;
           }
+        }
+        if constexpr (EXT) {
+          // Refill the ring slot just consumed.  Issued OUTSIDE the `live` branches: with the load on one side of a
+          // branch only, the compiler's wait-count bookkeeping merges "one younger load" with "none" at the join and
+          // falls back to s_waitcnt vmcnt(0) at every use, i.e. it waits for the load issued one layer ago and the
+          // ring is one deep instead of PFN.  Unconditional, every path has the same load sequence and the use waits
+          // with vmcnt(PFN - 1).  (`in` is clamped to an existing code block when the wave is not live.)
+          epf[Y::ext_idx(L) % PFN] = ext_load(Y::next_ext(L, PFN), z4);
         }
         if (live) {   // (second region: measured slightly faster than one region per layer)
           const float nm1 = a1 * 0.75f, nm2 = a2 * 0.75f;
