@@ -284,27 +284,92 @@ def _lin_interp(x, y, xn):
     return sl * (xn - x0).reshape((-1,) + (1,) * (y.ndim - 1)) + y[j - 1]
 
 
-def estimate_channel_ls(rx, pilots, dmrs_syms, port_ks, l_cdm=1, k_cdm=2):
-    """grid.py:874-975 estimateChannelLS(polarInt=False, kernel='linear') -> (L,K,Nr,P) (channel part only).
+def _polar_interp(x, y, xn):
+    """utils.py:38-42 polarInterpolate(..., 'linear'): unwrapped angle and magnitude interpolated separately."""
+    theta, r = np.unwrap(np.angle(y), axis=0), np.abs(y)
+    tn, rn = _lin_interp(x, theta, xn), _lin_interp(x, r, xn)
+    return rn * (np.cos(tn) + 1j * np.sin(tn))
+
+
+def estimate_channel_ls(rx, pilots, dmrs_syms, port_ks, l_cdm=1, k_cdm=2, polar=False, parts=False):
+    """grid.py:874-975 estimateChannelLS(polarInt, kernel='linear') -> (L,K,Nr,P) (channel part).
 
     rx (Nr,L,K); pilots (P, nDmrsSym, nK) pilot values of each port at its own subcarriers port_ks[p] (nK,);
     dmrs_syms (nDmrsSym,).  CDM averaging over k_cdm adjacent pilots (x l_cdm symbols), linear inter/extrapolation
-    over subcarriers then over symbols (repeat when a single estimate remains)."""
+    over subcarriers (of the complex values, or with ``polar`` of unwrapped angle and magnitude, utils.py:38-42) then
+    over symbols (always on the complex values, grid.py:866; repeat when a single estimate remains).
+    ``parts``: also return the raw LS values at the pilots and the estimates at the DMRS time groups per port
+    (hEstAtPilots / hEstAtPilotSyms of grid.py:767-806), which the noise estimate works on."""
     nr, L, K = rx.shape
     P = pilots.shape[0]
     out = np.zeros((L, K, nr, P), dtype=np.complex128)
     ls = np.asarray(dmrs_syms)
+    at_pilots, at_syms = [], []
     for p in range(P):
         ks = np.asarray(port_ks[p])
         h = np.transpose(rx[:, ls][:, :, ks] / pilots[p][None], (1, 2, 0))          # (nL, nK, Nr)
+        at_pilots.append(h)
         nL, nK = h.shape[:2]
         h = np.transpose(h.reshape(nL, -1, k_cdm, nr), (0, 2, 1, 3)).reshape(nL // l_cdm, l_cdm * k_cdm, -1, nr).mean(1)
         kc = ks.reshape(-1, k_cdm).mean(1)
-        hk = np.transpose(_lin_interp(kc, np.transpose(h, (1, 0, 2)), np.arange(K)), (1, 0, 2))   # (nL', K, Nr)
+        interp = _polar_interp if polar else _lin_interp
+        hk = np.transpose(interp(kc, np.transpose(h, (1, 0, 2)), np.arange(K)), (1, 0, 2))   # (nL', K, Nr)
+        at_syms.append(hk)
         if hk.shape[0] == 1:
             full = np.repeat(hk, L, axis=0)
         else:
             lc = ls.reshape(-1, l_cdm).mean(1)
             full = _lin_interp(lc, hk, np.arange(L))
         out[..., p] = full
-    return out
+    return (out, at_pilots, at_syms) if parts else out
+
+
+# the small 8-8-4-1 ReLU network of grid.py:697-737 (scaleNoiseVar): raw pilot-residual variance -> noise variance
+_NV_W1 = np.float64([[6.25861, -0.22737, -8.51406, -0.25593, 0.08617, 0.54746, -10.5016, -0.0075],
+                     [0.05773, -0.08806, 0.03222, 0.65573, -1.05669, -0.00781, 0.01074, -0.02898],
+                     [-11.48739, -18.84534, 9.54569, -0.02089, 9.92439, 0.07408, 11.41916, -34.07344],
+                     [0.71498, 4.52607, -0.35023, 0.05907, 2.24553, 0.06049, 0.47961, 0.44182],
+                     [0.84015, 0.14097, 0.20389, -0.45147, 0.12305, -0.51977, 0.37225, 0.12104],
+                     [0.41917, 10.52318, 3.35156, 0.58207, -24.37617, 0.33745, -1.11957, 1.07133],
+                     [-0.12522, -1.82239, 0.90271, -0.06134, 10.43859, 0.37885, 1.36096, -0.70045],
+                     [0.00109, -0.00328, -0.00657, -0.16279, -0.00351, -0.28476, 0.00053, -0.00117]])
+_NV_B1 = np.float64([0.60641, 0.06111, 0.24848, 0., 0.32098, 0., -0.21224, 0.007])
+_NV_W2 = np.float64([[0.10102, 0.22608, 0.32803, -0.11752], [-0.01549, 0.39246, -0.30703, 0.12527],
+                     [-0.02698, 0.09462, -0.31409, 0.03994], [-0.08645, -0.00781, 0.52137, 0.45963],
+                     [0.07151, -0.27656, 0.23206, -0.06437], [-0.0154, 0.07408, -0.15198, -0.4007],
+                     [-0.17055, -0.06038, -0.8417, 0.43372], [-3.12708, 2.03716, -3.90529, 1.21203]])
+_NV_B2 = np.float64([0.54406, 0.36443, -0.21105, 0.35659])
+_NV_W3 = np.float64([[0.04271], [0.07268], [0.0702], [-0.16217]])
+_NV_B3 = np.float64([0.72121])
+
+
+def scale_noise_var(raw, spacing_khz, n_tx, nr, K, l_cdm, k_cdm, n_var):
+    """grid.py:697-737: raw variance kept when the raw SNR exceeds 20 dB, otherwise mapped by the network."""
+    raw_snr_db = 10.0 * np.log10(1 / (raw * nr))
+    if raw_snr_db > 20:
+        return raw
+    x = np.float64([raw_snr_db, spacing_khz, n_tx, nr, K, l_cdm, k_cdm, n_var])
+    snr_db = (np.maximum(np.maximum(x.dot(_NV_W1) + _NV_B1, 0).dot(_NV_W2) + _NV_B2, 0).dot(_NV_W3) + _NV_B3)[0]
+    return 1 / (10.0 ** (snr_db / 10.0) * nr)
+
+
+def estimate_noise_var(at_pilots, at_syms, port_ks, l_cdm, k_cdm, K, nfft, cp_min, spacing_khz):
+    """Noise side output of estimateChannelLsEx (grid.py:808-837): each port's frequency-interpolated estimate goes
+    to the delay domain (IFFT over the K subcarriers), everything outside a raised-cosine window of (cp_min*K//nfft)
+    taps at either end is dropped, back to frequency, and the variance of (raw LS at the pilots - denoised) is
+    rescaled by `scale_noise_var`.  QUIRK kept (grid.py:823): the pilot subcarriers used for EVERY port are those of
+    the LAST port (`portKs` survives from the previous loop), wrong when the ports span two CDM groups."""
+    P = len(at_pilots)
+    nr = at_pilots[0].shape[2]
+    rise = cp_min * K // nfft
+    rc = .5 * (1 - np.sin(np.pi * np.arange(rise - 1, -rise, -2) / (2 * rise)))
+    win = np.concatenate([rc[::-1], np.float64((K - 2 * rise) * [0]), rc])
+    ks = np.asarray(port_ks[P - 1])
+    deltas = []
+    for p in range(P):
+        den = np.fft.fft(np.fft.ifft(at_syms[p], axis=1) * win[None, :, None], axis=1)
+        if l_cdm > 1:
+            den = np.repeat(den, l_cdm, axis=0)
+        deltas.append((at_pilots[p] - den[:, ks, :]).flatten())
+    deltas = np.concatenate(deltas)
+    return scale_noise_var(deltas.var(), spacing_khz, P, nr, K, l_cdm, k_cdm, len(deltas)), deltas.var()

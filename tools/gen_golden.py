@@ -10,6 +10,7 @@ Outputs (all data: inputs + the reference's outputs, nothing of its source):
   tests/golden/phy.npz           gold sequence, constellations, LLRs, equaliser, OFDM, FIR bank, LS estimate
   tests/golden/host.npz          Carrier / PDSCH / DMRS index + pilot tables, TBS values, SnrScheduler walks
   tests/golden/channels.npz      CDL / TDL per-slot gains + coefficient matrices for seeded channels
+  tests/golden/chest.npz         DMRS LS estimates (linear / polar subcarrier interpolation) + noise estimates
   tests/golden/polar.npz         polar DCI/PBCH/UCI chains: bits, LLRs, SCL candidate lists and path costs
   tests/golden/e2e_*.npz         whole PDSCH slots (inputs: seed-derived bits/noise; outputs: LLRs, bits, CRC)
 """
@@ -186,6 +187,61 @@ def channels():
     np.savez_compressed(os.path.join(GOLD, 'channels.npz'), **out)
 
 
+def chest():
+    """Grid.estimateChannelLS with both subcarrier interpolators (complex-linear and polar-linear) and its noise
+    side output, on noisy received grids of three small links (inputs: the received grid and the DMRS tables)."""
+    out = {}
+    cases = [  # name, seed, numRbs, spacing, layers, rx panel, tx panel, dmrs kwargs, snr dB
+        ('a', 11, 25, 15, 2, [1, 1], [1, 1], dict(configType=1, additionalPos=1), 10.0),
+        ('b', 12, 24, 30, 4, [1, 2], [1, 2], dict(configType=1, additionalPos=1), 32.0),
+        ('c', 13, 25, 15, 1, [1, 1], [1, 1], dict(configType=1, additionalPos=0), 4.0),
+        ('d', 14, 24, 30, 3, [1, 2], [1, 2], dict(configType=1, additionalPos=2, symbols=1), 14.0),
+    ]
+    out['names'] = np.array([c[0] for c in cases])
+    for name, seed, numRbs, spacing, layers, rxp, txp, dm, snr in cases:
+        nr.random.setSeed(seed)
+        car = nr.Carrier(numRbs=numRbs, spacing=spacing)
+        bwp = car.curBwp
+        p = nr.PDSCH(bwp, numLayers=layers, nID=car.cellId, modulation='16QAM')
+        p.setDMRS(**dm)
+        ch = nr.CdlChannel(bwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                           txAntenna=nr.AntennaPanel(txp, polarization='x'), rxAntenna=nr.AntennaPanel(rxp, polarization='x'))
+        g = p.getGrid()
+        nb = p.getBitSizes(g)
+        p.populateGrid(g, nr.random.bits(nb[0]))
+        H = ch.getChannelMatrix()
+        F = p.getPrecodingMatrix(H)
+        rx = g.precode(F).applyChannel(H).addNoise(snrDb=snr, useRxPower=True)
+        h_lin, nv_lin = rx.estimateChannelLS(p.dmrs, polarInt=False, kernel='linear')
+        h_pol, nv_pol = rx.estimateChannelLS(p.dmrs, polarInt=True, kernel='linear')
+        # the DMRS tables in the layout of the oracle / kernels: pilots (P, nDmrsSym, nK), subcarriers (P, nK), symbols
+        rs = bwp.createGrid(len(p.portSet))
+        p.dmrs.populateGrid(rs)
+        idx = rs.getReIndexes("DMRS")
+        pil, pks, ds = [], [], None
+        for port in range(len(p.portSet)):
+            pl, pk = idx[1][idx[0] == port], idx[2][idx[0] == port]
+            ls = np.unique(pl)
+            ks = pk[pl == ls[0]]
+            pil.append(rs.grid[port, ls, :][:, ks])
+            pks.append(ks)
+            ds = ls
+        out[name + '_cfg'] = np.array(repr(dict(seed=seed, numRbs=numRbs, spacing=spacing, layers=layers, rx=rxp, tx=txp,
+                                                dmrs=dm, snr=snr)))
+        out[name + '_rx'] = rx.grid
+        out[name + '_true_noise_var'] = np.float64(rx.noiseVar)
+        out[name + '_pilots'] = np.stack(pil)
+        out[name + '_port_ks'] = np.int32(np.stack(pks))
+        out[name + '_dmrs_syms'] = np.int32(ds)
+        out[name + '_geom'] = np.int64([p.dmrs.symbols, 4 if p.dmrs.enhanced else 2, bwp.nFFT,
+                                        min(bwp.symbolLens) - bwp.nFFT, spacing])
+        out[name + '_h_lin'] = h_lin[::3]
+        out[name + '_h_pol'] = h_pol[::3]
+        out[name + '_nv'] = np.float64([nv_lin, nv_pol])
+        print('chest', name, 'true nv', rx.noiseVar, 'est', nv_lin, nv_pol)
+    np.savez_compressed(os.path.join(GOLD, 'chest.npz'), **out)
+
+
 def e2e():
     """Whole slots.  The random stream (bits -> channel construction -> noise) is reproducible from the seed with
     NumPy's PCG64, so only outputs are stored."""
@@ -335,6 +391,10 @@ def polar():
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1:                                 # regenerate selected fixture files only
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     copy_matlab()
     coding()
     phy()
@@ -343,5 +403,6 @@ if __name__ == '__main__':
     snr_walks()
     harq_loop()
     polar()
+    chest()
     e2e()
     print('fixtures written to', GOLD)
