@@ -321,6 +321,29 @@ int32_t nrx_chest_ls_f64(const void* rx, const void* pilots, const int32_t* pil_
                          const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
                          int32_t K, int32_t nr, int32_t P, void* hest, int32_t n_batch, void* stream);
 
+/* estimateChannelLS with the interpolator choice of the notebooks (grid.py:874-975 -> estimateChannelLsEx grid.py:740-806,
+ * int2d=False, kernel='linear'): polar != 0 selects utils.py:38-42 polarInterpolate along the subcarriers (np.unwrap of
+ * the angle in NumPy's operation order, angle and magnitude inter/extrapolated separately; symbols stay complex-linear,
+ * grid.py:866).  pol_ws (polar only): scratch of n_batch*(n_ds/l_cdm)*nr*P*(n_k/k_cdm)*2 doubles.  hk_out (nullable):
+ * the estimates at the DMRS time groups after subcarrier interpolation, (n_batch, n_ds/l_cdm, K, nr, P) complex128
+ * (hEstAtPilotSyms of grid.py:806) -- the input of nrx_chest_noise_f64.  hest out: (n_batch,L,K,nr,P). */
+int32_t nrx_chest_ls_ex_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                            const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
+                            int32_t K, int32_t nr, int32_t P, int32_t polar, void* pol_ws, void* hk_out, void* hest,
+                            int32_t n_batch, void* stream);
+
+/* Noise side output of estimateChannelLsEx, grid.py:808-837 (before scaleNoiseVar): per port the estimate hk goes to the
+ * delay domain (K-point inverse DFT, any K), is cut by the raised-cosine window (2*rise non-zero taps, `win` = their
+ * weights: taps 0..rise-1 then K-rise..K-1), comes back to the pilot subcarriers, and the residuals against the raw LS
+ * values are written to deltas (n_batch, P*n_ds*n_k*nr) complex128; their np.var is the raw noise variance
+ * (nrx_noise_level_f64 computes it).  tw: e^{2 pi i q/K}, q = 0..K-1 (complex128, caller table); cir_ws: scratch of
+ * n_batch*(n_ds/l_cdm)*nr*P*2*rise complex128.  QUIRK kept (grid.py:823): the denoised estimate of EVERY port is sampled
+ * at the pilot subcarriers of the LAST port. */
+int32_t nrx_chest_noise_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                            const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
+                            int32_t K, int32_t nr, int32_t P, const void* hk, const void* tw, const double* win,
+                            int32_t rise, void* cir_ws, void* deltas, int32_t n_batch, void* stream);
+
 /* nrx_chest_ls_f64 + nrx_mmse_equalize_f64 in one call without materialising the (L, K, Nr, P) estimate (at most two
  * DMRS time groups): hk_ws is caller-owned scratch of n_batch * (n_ds/l_cdm) * K * nr * P complex128; eq (n,P,L,K)
  * complex128, scale (n,P,L,K) float64.  Results are identical to the two separate calls. */

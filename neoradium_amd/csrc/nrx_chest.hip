@@ -20,10 +20,14 @@ struct ChestGeom {
   int32_t L, K, nr, P;
 };
 
-template <typename T>
+// POLAR: the CDM-group estimates come as (unwrapped angle, magnitude) pairs from chest_polar_prep_kernel +
+// chest_unwrap_kernel (`pol`, [row = ((b*n_g + tg)*nr + r)*P + p][j][2]); angle and magnitude are inter/extrapolated
+// separately along the subcarriers (utils.py:38-42 polarInterpolate), the symbol axis stays complex-linear.
+template <typename T, bool POLAR>
 __global__ void __launch_bounds__(256)
 chest_ls_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ pilots, const int32_t* __restrict__ pil_set,
-                const int32_t* __restrict__ port_ks, ChestGeom g, cx<T>* __restrict__ hest, int n_batch, int hk_only) {
+                const int32_t* __restrict__ port_ks, ChestGeom g, cx<T>* __restrict__ hest, int n_batch, int hk_only,
+                cx<T>* __restrict__ hk_out, const double* __restrict__ pol) {
   const int rp = g.nr * g.P;
   const int64_t per = (int64_t)g.K * rp;
   const int64_t total = (int64_t)n_batch * per;
@@ -67,11 +71,23 @@ chest_ls_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ pilots, 
         return cd(s.re / (double)cdm, s.im / (double)cdm);
       };
       if (n_j == 1) { hk[tg] = group_mean(0); continue; }
-      const cd y0 = group_mean(j - 1), y1 = group_mean(j);
       const double x0 = centre(j - 1), x1 = centre(j);
-      const cd sl((y1.re - y0.re) / (x1 - x0), (y1.im - y0.im) / (x1 - x0));
-      hk[tg] = cd(sl.re * ((double)k - x0) + y0.re, sl.im * ((double)k - x0) + y0.im);
+      if constexpr (POLAR) {
+        const double* q = pol + ((((size_t)b * n_g + tg) * g.nr + r) * g.P + p) * (size_t)n_j * 2;
+        const double t0 = q[2 * (j - 1)], a0 = q[2 * (j - 1) + 1], t1 = q[2 * j], a1 = q[2 * j + 1];
+        const double tn = (t1 - t0) / (x1 - x0) * ((double)k - x0) + t0;
+        const double an = (a1 - a0) / (x1 - x0) * ((double)k - x0) + a0;
+        double sn, cs;
+        sincos(tn, &sn, &cs);
+        hk[tg] = cd(an * cs, an * sn);
+      } else {
+        const cd y0 = group_mean(j - 1), y1 = group_mean(j);
+        const cd sl((y1.re - y0.re) / (x1 - x0), (y1.im - y0.im) / (x1 - x0));
+        hk[tg] = cd(sl.re * ((double)k - x0) + y0.re, sl.im * ((double)k - x0) + y0.im);
+      }
     }
+    if (hk_out)      // estimates at the DMRS time groups, (n, n_g, K, nr, P): input of the noise estimate
+      for (int tg = 0; tg < n_g; ++tg) hk_out[((size_t)b * n_g + tg) * per + e] = cx<T>(hk[tg]);
     if (hk_only) {   // fused path: keep the per-time-group estimates, the equaliser interpolates along symbols
       for (int tg = 0; tg < n_g; ++tg) hest[((size_t)b * n_g + tg) * per + e] = cx<T>(hk[tg]);
       continue;
@@ -100,6 +116,119 @@ chest_ls_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ pilots, 
   }
 }
 
+
+// ---- polar interpolation, step 1 (utils.py:39): angle and magnitude of every CDM-group estimate.
+// pol[row][j] = (atan2(im, re), hypot(re, im)), row = ((b*n_g + tg)*nr + r)*P + p.
+__global__ void __launch_bounds__(256)
+chest_polar_prep_kernel(const cd* __restrict__ rx, const cd* __restrict__ pilots, const int32_t* __restrict__ pil_set,
+                        const int32_t* __restrict__ port_ks, ChestGeom g, double* __restrict__ pol, int n_batch) {
+  const int n_j = g.n_k / g.k_cdm, n_g = g.n_ds / g.l_cdm, cdm = g.l_cdm * g.k_cdm;
+  const int64_t total = (int64_t)n_batch * n_g * g.nr * g.P * n_j;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(gi % n_j);
+    const int64_t row = gi / n_j;
+    const int p = (int)(row % g.P), r = (int)((row / g.P) % g.nr), tg = (int)((row / ((int64_t)g.P * g.nr)) % n_g);
+    const int b = (int)(row / ((int64_t)g.P * g.nr * n_g));
+    const int32_t* ks = port_ks + (size_t)p * g.n_k;
+    const cd* pil = pilots + ((size_t)(pil_set ? pil_set[b] : 0) * g.P + p) * g.n_ds * g.n_k;
+    const cd* rxb = rx + ((size_t)b * g.nr + r) * g.L * g.K;
+    cd s(0, 0);
+    for (int ll = 0; ll < g.l_cdm; ++ll) {
+      const int di = tg * g.l_cdm + ll;
+      for (int q = 0; q < g.k_cdm; ++q)
+        s = s + nrx::cdiv(rxb[(size_t)g.ds[di] * g.K + ks[j * g.k_cdm + q]], pil[(size_t)di * g.n_k + j * g.k_cdm + q]);
+    }
+    s = cd(s.re / (double)cdm, s.im / (double)cdm);
+    pol[2 * gi] = atan2(s.im, s.re);
+    pol[2 * gi + 1] = hypot(s.re, s.im);
+  }
+}
+
+// ---- step 2: np.unwrap along the subcarrier axis, one thread per row, in NumPy's operation order (the phase
+// corrections are accumulated sequentially like np.cumsum, so the result is the same double).
+__global__ void __launch_bounds__(64) chest_unwrap_kernel(double* __restrict__ pol, int n_j, int64_t n_rows) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  double* q = pol + (size_t)row * n_j * 2;
+  const double pi = 3.141592653589793, two_pi = 6.283185307179586;
+  double prev = q[0], corr = 0.0;
+  for (int j = 1; j < n_j; ++j) {
+    const double cur = q[2 * j];
+    const double dd = cur - prev;
+    double m = fmod(dd + pi, two_pi);          // np.mod: result takes the sign of the divisor
+    if (m != 0.0) { if (m < 0.0) m += two_pi; } else m = 0.0;
+    double ddmod = m - pi;
+    if (ddmod == -pi && dd > 0.0) ddmod = pi;
+    double ph = ddmod - dd;
+    if (fabs(dd) < pi) ph = 0.0;
+    corr += ph;
+    q[2 * j] = cur + corr;
+    prev = cur;
+  }
+}
+
+// ---- noise side output of estimateChannelLsEx (grid.py:808-837).
+// (a) windowed channel impulse response: only the 2*rise taps under the raised-cosine window are non-zero,
+//     cirw[row][t] = win[t] * (1/K) sum_k hk[row][k] e^{+2 pi i k m_t / K},  m_t = t (t < rise) or K - 2*rise + t.
+//     tw[q] = e^{2 pi i q / K} (caller table); the index k*m mod K is advanced incrementally.
+__global__ void __launch_bounds__(128)
+chest_cir_kernel(const cd* __restrict__ hk, const cd* __restrict__ tw, const double* __restrict__ win, int rise, int K,
+                 int rp, cd* __restrict__ cirw) {
+  const int64_t row = blockIdx.x;                    // (b*n_g + tg)*rp + (r*P + p)
+  const int t = blockIdx.y * blockDim.x + threadIdx.x;
+  if (t >= 2 * rise) return;
+  const int m = t < rise ? t : K - 2 * rise + t;
+  const cd* h = hk + (size_t)(row / rp) * K * rp + (row % rp);
+  cd acc(0, 0);
+  int idx = 0;
+  for (int k = 0; k < K; ++k) {
+    nrx::cmac(acc, h[(size_t)k * rp], tw[idx]);
+    idx += m;
+    if (idx >= K) idx -= K;
+  }
+  const double w = win[t];
+  cirw[(size_t)row * 2 * rise + t] = cd(acc.re / (double)K * w, acc.im / (double)K * w);
+}
+
+// (b) residuals at the pilots: delta = (rx/pilot at the port's own pilot q) - denoised estimate sampled at subcarrier
+//     ks_last[q] -- the pilot subcarriers of the LAST port for every port (QUIRK grid.py:823, kept).
+//     deltas[b][((p*n_ds + di)*n_k + q)*nr + r]
+__global__ void __launch_bounds__(256)
+chest_delta_kernel(const cd* __restrict__ rx, const cd* __restrict__ pilots, const int32_t* __restrict__ pil_set,
+                   const int32_t* __restrict__ port_ks, ChestGeom g, const cd* __restrict__ cirw,
+                   const cd* __restrict__ tw, int rise, cd* __restrict__ deltas, int n_batch) {
+  const int n_g = g.n_ds / g.l_cdm;
+  const int64_t per = (int64_t)g.P * g.n_ds * g.n_k * g.nr;
+  const int64_t total = (int64_t)n_batch * per;
+  const int32_t* ks_last = port_ks + (size_t)(g.P - 1) * g.n_k;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(gi / per);
+    int64_t e = gi - (int64_t)b * per;
+    const int r = (int)(e % g.nr); e /= g.nr;
+    const int q = (int)(e % g.n_k); e /= g.n_k;
+    const int di = (int)(e % g.n_ds);
+    const int p = (int)(e / g.n_ds);
+    const int tg = di / g.l_cdm;
+    const cd* pil = pilots + ((size_t)(pil_set ? pil_set[b] : 0) * g.P + p) * g.n_ds * g.n_k;
+    const cd raw = nrx::cdiv(rx[(((size_t)b * g.nr + r) * g.L + g.ds[di]) * g.K + port_ks[(size_t)p * g.n_k + q]],
+                             pil[(size_t)di * g.n_k + q]);
+    const cd* c = cirw + ((((size_t)b * n_g + tg) * g.nr + r) * g.P + p) * 2 * rise;
+    const int kq = ks_last[q];
+    cd den(0, 0);
+    for (int half = 0; half < 2; ++half) {
+      const int m0 = half ? g.K - rise : 0;
+      int idx = (int)(((int64_t)kq * m0) % g.K);
+      for (int t = 0; t < rise; ++t) {
+        const cd w = tw[idx];
+        nrx::cmac(den, c[half * rise + t], cd(w.re, -w.im));   // e^{-2 pi i kq m / K}
+        idx += kq;
+        if (idx >= g.K) idx -= g.K;
+      }
+    }
+    deltas[gi] = cd(raw.re - den.re, raw.im - den.im);
+  }
+}
+
 template <typename T>
 int32_t chest_entry(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
                     const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
@@ -117,8 +246,9 @@ int32_t chest_entry(const void* rx, const void* pilots, const int32_t* pil_set, 
     g.ds[i] = dmrs_syms[i];
   }
   g.l_cdm = l_cdm; g.k_cdm = k_cdm; g.n_k = n_k; g.L = L; g.K = K; g.nr = nr; g.P = P;
-  hipLaunchKernelGGL(chest_ls_kernel<T>, dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const cx<T>*)rx, (const cx<T>*)pilots, pil_set, port_ks, g, (cx<T>*)hest, n_batch, 0);
+  hipLaunchKernelGGL((chest_ls_kernel<T, false>), dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const cx<T>*)rx, (const cx<T>*)pilots, pil_set, port_ks, g, (cx<T>*)hest, n_batch, 0,
+                     (cx<T>*)nullptr, (const double*)nullptr);
   NRX_CHECK_LAUNCH("nrx_chest_ls");
   return NRX_OK;
 }
@@ -210,8 +340,9 @@ extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, con
   const dim3 grid2(nrx::stream_grid((long)n_batch * K, 128));
 #define NRX_CM_CASE(NR, NL)                                                                                              \
   if (nr == NR && P == NL) {                                                                                             \
-    hipLaunchKernelGGL(chest_ls_kernel<double>, dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)), dim3(256), 0, st, \
-                       (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (cd*)hk_ws, n_batch, 1);                   \
+    hipLaunchKernelGGL((chest_ls_kernel<double, false>), dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)),        \
+                       dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (cd*)hk_ws, n_batch, 1,  \
+                       (cd*)nullptr, (const double*)nullptr);                                                           \
     hipLaunchKernelGGL((mmse_interp_kernel<NR, NL>), grid2, dim3(128), 0, st, (const cd*)rx, (const cd*)hk_ws, g,        \
                        noise_var, nv_stride, (cd*)eq, scale, n_batch);                                                   \
     NRX_CHECK_LAUNCH("nrx_chest_ls_mmse");                                                                               \
@@ -226,3 +357,74 @@ extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, con
 
 extern "C" int32_t nrx_chest_ls_f32(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks, const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L, int32_t K, int32_t nr, int32_t P, void* hest, int32_t n_batch, void* stream) { return chest_entry<float>(rx, pilots, pil_set, port_ks, dmrs_syms, n_ds, l_cdm, k_cdm, n_k, L, K, nr, P, hest, n_batch, stream); }
 extern "C" int32_t nrx_chest_ls_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks, const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L, int32_t K, int32_t nr, int32_t P, void* hest, int32_t n_batch, void* stream) { return chest_entry<double>(rx, pilots, pil_set, port_ks, dmrs_syms, n_ds, l_cdm, k_cdm, n_k, L, K, nr, P, hest, n_batch, stream); }
+
+
+static int32_t chest_fill_geom(ChestGeom& g, const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm,
+                               int32_t n_k, int32_t L, int32_t K, int32_t nr, int32_t P, const char* who) {
+  NRX_REQUIRE(dmrs_syms, NRX_E_ARG, "%s: NULL dmrs_syms", who);
+  NRX_REQUIRE(n_ds >= 1 && n_ds <= 8 && l_cdm >= 1 && k_cdm >= 1 && n_k >= 1, NRX_E_ARG, "%s: bad DMRS geometry", who);
+  NRX_REQUIRE(n_k % k_cdm == 0 && n_ds % l_cdm == 0, NRX_E_UNSUPPORTED, "%s: Partial CDMs are not supported in this version.", who);
+  NRX_REQUIRE(n_ds / l_cdm <= 4, NRX_E_UNSUPPORTED, "%s: more than 4 DMRS time groups", who);
+  NRX_REQUIRE(L >= 1 && K >= 1 && nr >= 1 && P >= 1, NRX_E_ARG, "%s: bad sizes", who);
+  g.n_ds = n_ds;
+  for (int i = 0; i < n_ds; ++i) {
+    NRX_REQUIRE(dmrs_syms[i] >= 0 && dmrs_syms[i] < L, NRX_E_ARG, "%s: DMRS symbol index out of range", who);
+    g.ds[i] = dmrs_syms[i];
+  }
+  g.l_cdm = l_cdm; g.k_cdm = k_cdm; g.n_k = n_k; g.L = L; g.K = K; g.nr = nr; g.P = P;
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_chest_ls_ex_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                       const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                       int32_t L, int32_t K, int32_t nr, int32_t P, int32_t polar, void* pol_ws,
+                                       void* hk_out, void* hest, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(rx && pilots && port_ks && hest, NRX_E_ARG, "nrx_chest_ls_ex: NULL buffer");
+  NRX_REQUIRE(!polar || pol_ws, NRX_E_ARG, "nrx_chest_ls_ex: polar interpolation needs pol_ws");
+  NRX_REQUIRE(n_batch >= 0, NRX_E_ARG, "nrx_chest_ls_ex: negative batch");
+  ChestGeom g;
+  const int32_t rc = chest_fill_geom(g, dmrs_syms, n_ds, l_cdm, k_cdm, n_k, L, K, nr, P, "nrx_chest_ls_ex");
+  if (rc != NRX_OK) return rc;
+  NRX_REQUIRE(!polar || n_k / k_cdm >= 2, NRX_E_ARG, "nrx_chest_ls_ex: polar interpolation needs two or more CDM groups");
+  if (n_batch == 0) return NRX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(nrx::stream_grid((long)n_batch * K * nr * P, 256));
+  if (polar) {
+    const int n_j = n_k / k_cdm;
+    const int64_t rows = (int64_t)n_batch * (n_ds / l_cdm) * nr * P;
+    hipLaunchKernelGGL(chest_polar_prep_kernel, dim3(nrx::stream_grid(rows * n_j, 256)), dim3(256), 0, st, (const cd*)rx,
+                       (const cd*)pilots, pil_set, port_ks, g, (double*)pol_ws, n_batch);
+    hipLaunchKernelGGL(chest_unwrap_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, (double*)pol_ws, n_j, rows);
+    hipLaunchKernelGGL((chest_ls_kernel<double, true>), grid, dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set,
+                       port_ks, g, (cd*)hest, n_batch, 0, (cd*)hk_out, (const double*)pol_ws);
+  } else {
+    hipLaunchKernelGGL((chest_ls_kernel<double, false>), grid, dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set,
+                       port_ks, g, (cd*)hest, n_batch, 0, (cd*)hk_out, (const double*)nullptr);
+  }
+  NRX_CHECK_LAUNCH("nrx_chest_ls_ex");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_chest_noise_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                       const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                       int32_t L, int32_t K, int32_t nr, int32_t P, const void* hk, const void* tw,
+                                       const double* win, int32_t rise, void* cir_ws, void* deltas, int32_t n_batch,
+                                       void* stream) {
+  NRX_REQUIRE(rx && pilots && port_ks && hk && tw && win && cir_ws && deltas, NRX_E_ARG, "nrx_chest_noise: NULL buffer");
+  NRX_REQUIRE(rise >= 1 && 2 * rise <= K, NRX_E_ARG, "nrx_chest_noise: window of 2*%d taps does not fit %d subcarriers", rise, K);
+  NRX_REQUIRE(n_batch >= 0, NRX_E_ARG, "nrx_chest_noise: negative batch");
+  ChestGeom g;
+  const int32_t rc = chest_fill_geom(g, dmrs_syms, n_ds, l_cdm, k_cdm, n_k, L, K, nr, P, "nrx_chest_noise");
+  if (rc != NRX_OK) return rc;
+  if (n_batch == 0) return NRX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)n_batch * (n_ds / l_cdm) * nr * P;
+  NRX_REQUIRE(rows < 0x7fffffff, NRX_E_UNSUPPORTED, "nrx_chest_noise: batch too large");
+  hipLaunchKernelGGL(chest_cir_kernel, dim3((unsigned)rows, (unsigned)((2 * rise + 127) / 128)), dim3(128), 0, st,
+                     (const cd*)hk, (const cd*)tw, win, rise, K, nr * P, (cd*)cir_ws);
+  hipLaunchKernelGGL(chest_delta_kernel, dim3(nrx::stream_grid((long)n_batch * P * n_ds * n_k * nr, 256)), dim3(256), 0, st,
+                     (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (const cd*)cir_ws, (const cd*)tw, rise,
+                     (cd*)deltas, n_batch);
+  NRX_CHECK_LAUNCH("nrx_chest_noise");
+  return NRX_OK;
+}

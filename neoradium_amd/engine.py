@@ -26,7 +26,7 @@ from .waveform import Waveform
 
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
-                 decoder="f32", windowing="STD", dev=None, firstPassIter=None):
+                 decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False):
         if pdsch.numCW != 1:
             raise NotImplementedError("PdschLink: two-codeword PDSCH (more than 4 layers) is not built")
         if pdsch.prgSize != 0:
@@ -43,6 +43,7 @@ class PdschLink:
         self.carrier = bwp.carrier
         self.freqDomain, self.chanEst, self.decoder = freqDomain, chanEst, decoder
         self.numIter = int(numIter)
+        self.polarInt = bool(polarInt)        # estimateChannelLS(polarInt=True, kernel='linear') of PDSCH-endToEnd.ipynb
         # Opt-in two-pass decoding (NOT the reference's schedule, off by default): every code block is first decoded
         # with `firstPassIter` iterations; the blocks whose CRC fails are then decoded again FROM SCRATCH with the full
         # `numIter` iterations, so a failing block gets exactly the reference's result and a passing block is the
@@ -214,6 +215,10 @@ class PdschLink:
         hest = None
         if self.chanEst == "Perfect":
             hest = ops.effective_channel(H, F)
+            eq, sc = ops.mmse_equalize(rxg, hest, nv)
+        elif self.polarInt:
+            hest = ops.chest_ls_ex(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,
+                                   pil_set=sif.to(torch.int32), polar=True)
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
         elif details or self.n_tg > 2:
             hest = ops.chest_ls(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,

@@ -208,25 +208,59 @@ class Grid:
         g = self._like(N(eq)[0], noiseVar=nv)
         return g, N(sc)[0]
 
+    # the 8-8-4-1 ReLU network of grid.py:697-737 that maps the raw pilot-residual variance to a noise variance
+    _NV = (np.float64([[6.25861, -0.22737, -8.51406, -0.25593, 0.08617, 0.54746, -10.5016, -0.0075],
+                       [0.05773, -0.08806, 0.03222, 0.65573, -1.05669, -0.00781, 0.01074, -0.02898],
+                       [-11.48739, -18.84534, 9.54569, -0.02089, 9.92439, 0.07408, 11.41916, -34.07344],
+                       [0.71498, 4.52607, -0.35023, 0.05907, 2.24553, 0.06049, 0.47961, 0.44182],
+                       [0.84015, 0.14097, 0.20389, -0.45147, 0.12305, -0.51977, 0.37225, 0.12104],
+                       [0.41917, 10.52318, 3.35156, 0.58207, -24.37617, 0.33745, -1.11957, 1.07133],
+                       [-0.12522, -1.82239, 0.90271, -0.06134, 10.43859, 0.37885, 1.36096, -0.70045],
+                       [0.00109, -0.00328, -0.00657, -0.16279, -0.00351, -0.28476, 0.00053, -0.00117]]),
+           np.float64([0.60641, 0.06111, 0.24848, 0., 0.32098, 0., -0.21224, 0.007]),
+           np.float64([[0.10102, 0.22608, 0.32803, -0.11752], [-0.01549, 0.39246, -0.30703, 0.12527],
+                       [-0.02698, 0.09462, -0.31409, 0.03994], [-0.08645, -0.00781, 0.52137, 0.45963],
+                       [0.07151, -0.27656, 0.23206, -0.06437], [-0.0154, 0.07408, -0.15198, -0.4007],
+                       [-0.17055, -0.06038, -0.8417, 0.43372], [-3.12708, 2.03716, -3.90529, 1.21203]]),
+           np.float64([0.54406, 0.36443, -0.21105, 0.35659]),
+           np.float64([[0.04271], [0.07268], [0.0702], [-0.16217]]), np.float64([0.72121]))
+
+    def scaleNoiseVar(self, rawNoiseVar, numTx, lCdm, kCdm, numVar):
+        """grid.py:697-737 (host scalar arithmetic): the raw variance is returned above 20 dB raw SNR, otherwise the
+        small network maps (raw SNR, spacing, ports, Nr, K, lCdm, kCdm, number of residuals) to an SNR."""
+        rr, kk = self.shape[0], self.shape[2]
+        rawSnrDb = 10.0 * np.log10(1 / (rawNoiseVar * rr))
+        if rawSnrDb > 20:
+            return rawNoiseVar
+        w1, b1, w2, b2, w3, b3 = self._NV
+        x = np.float64([rawSnrDb, self.bwp.spacing, numTx, rr, kk, lCdm, kCdm, numVar])
+        snrDb = (np.maximum(np.maximum(x.dot(w1) + b1, 0).dot(w2) + b2, 0).dot(w3) + b3)[0]
+        return 1 / (10.0 ** (snrDb / 10.0) * rr)
+
     def estimateChannelLS(self, rsInfo, meanCdm=True, polarInt=False, kernel='linear'):
         """grid.py:874-975 with DMRS pilots, CDM averaging and linear interpolation -> (H (L,K,Nr,P), noiseVar est.).
 
-        Only the default path is built (meanCdm=True, polarInt=False, kernel='linear'); the reference's
-        noise-variance side output (IFFT/window/FFT + MLP rescale, grid.py:808-851) is not on the link path the
-        notebooks use, so ``None`` is returned in its place."""
+        Built: meanCdm=True, kernel='linear', polarInt False (complex-linear along the subcarriers) or True (unwrapped
+        angle and magnitude interpolated separately, utils.py:38-42 -- what PDSCH-endToEnd.ipynb asks for).  The second
+        return value is the reference's noise estimate (grid.py:808-837 + scaleNoiseVar), including its habit of
+        sampling every port at the last port's pilot subcarriers."""
         from .dmrs import DMRS
         if not isinstance(rsInfo, DMRS):
             raise NotImplementedError("estimateChannelLS: only DMRS-based estimation is built (CSI-RS is out of scope)")
-        if not meanCdm or polarInt or kernel != 'linear':
-            raise NotImplementedError("estimateChannelLS: only meanCdm=True, polarInt=False, kernel='linear' is built")
+        if not meanCdm or kernel != 'linear':
+            raise NotImplementedError("estimateChannelLS: only meanCdm=True, kernel='linear' is built")
         dmrs = rsInfo
         pil, ks, ds = dmrs.getPilots()
         if self.shape[1:] != (self.bwp.symbolsPerSlot, 12 * self.bwp.numRbs):
             raise ValueError("The Grid size (%dx%d) does not match Reference Signals (%dx%d)." %
                              (self.shape[1], self.shape[2], self.bwp.symbolsPerSlot, 12 * self.bwp.numRbs))
-        h = ops.chest_ls(D(self.grid[None]), D(pil[None]), ks, list(ds), l_cdm=dmrs.symbols,
-                         k_cdm=4 if dmrs.enhanced else 2)
-        return N(h)[0], None
+        l_cdm, k_cdm = dmrs.symbols, (4 if dmrs.enhanced else 2)
+        rx, pd = D(self.grid[None]), D(pil[None])
+        h, hk = ops.chest_ls_ex(rx, pd, ks, list(ds), l_cdm=l_cdm, k_cdm=k_cdm, polar=bool(polarInt), want_hk=True)
+        cp_min = int(min(self.bwp.symbolLens)) - self.bwp.nFFT
+        raw, num = ops.chest_noise_var(rx, pd, ks, list(ds), hk, self.bwp.nFFT, cp_min, l_cdm=l_cdm, k_cdm=k_cdm)
+        est = self.scaleNoiseVar(float(N(raw)[0]), pil.shape[0], l_cdm, k_cdm, num)
+        return N(h)[0], est
 
     def ofdmModulate(self, f0=0, windowing="STD"):
         """grid.py:521-582 + waveform.py:380-470."""

@@ -5,6 +5,7 @@ can take the whole node down), allocates outputs with torch, and enqueues one li
 stream.  Leading batch dimension = Monte-Carlo slots / transport blocks.
 """
 import ctypes as C
+import numpy as np
 import torch
 
 from . import _lib
@@ -513,6 +514,71 @@ def chest_ls(rx, pilots, port_ks, dmrs_syms, l_cdm=1, k_cdm=2, pil_set=None):
     check(fn(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), _host_i32(dmrs_syms), nds, l_cdm, k_cdm, nk, L, K, nr, P, ptr(hest),
              n, stream()))
     return hest
+
+
+def _chest_tables(rx, pilots, port_ks, dmrs_syms, pil_set):
+    rx = rx.contiguous()
+    if rx.dtype != torch.complex128:
+        raise ValueError("the extended estimator is built for complex128")
+    n, nr, L, K = rx.shape
+    dev = _dev(rx)
+    pilots = pilots.to(device=dev, dtype=rx.dtype).contiguous()
+    if pilots.dim() == 3:
+        pilots = pilots[None]
+    sets, P, nds, nk = pilots.shape
+    if nds != len(dmrs_syms):
+        raise ValueError("pilot / DMRS symbol count mismatch")
+    pk = _i32(port_ks, dev)
+    if tuple(pk.shape) != (P, nk):
+        raise ValueError("port_ks must be (P, nK)")
+    if int(pk.max()) >= K or int(pk.min()) < 0:
+        raise ValueError("pilot subcarrier index out of range")
+    ps = _i32(pil_set, dev)
+    if ps is not None and (ps.numel() != n or int(ps.max()) >= sets):
+        raise ValueError("pil_set must hold one valid pilot-set index per batch item")
+    return rx, pilots, pk, ps, (n, nr, L, K, P, nds, nk)
+
+
+def chest_ls_ex(rx, pilots, port_ks, dmrs_syms, l_cdm=1, k_cdm=2, pil_set=None, polar=False, want_hk=False):
+    """Grid.estimateChannelLS(polarInt=polar, kernel='linear'): -> hest (n,L,K,Nr,P) [, hk (n,nTg,K,Nr,P)]."""
+    rx, pilots, pk, ps, (n, nr, L, K, P, nds, nk) = _chest_tables(rx, pilots, port_ks, dmrs_syms, pil_set)
+    dev = _dev(rx)
+    n_g, n_j = nds // max(l_cdm, 1), nk // max(k_cdm, 1)
+    hest = torch.empty((n, L, K, nr, P), dtype=rx.dtype, device=dev)
+    hk = torch.empty((n, n_g, K, nr, P), dtype=rx.dtype, device=dev) if want_hk else None
+    pol = torch.empty((n * n_g * nr * P * n_j * 2,), dtype=torch.float64, device=dev) if polar else None
+    check(lib().nrx_chest_ls_ex_f64(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), _host_i32(dmrs_syms), nds, l_cdm, k_cdm, nk, L, K,
+                                    nr, P, 1 if polar else 0, ptr(pol), ptr(hk), ptr(hest), n, stream()))
+    return (hest, hk) if want_hk else hest
+
+
+_noise_tabs = {}
+
+
+def chest_noise_var(rx, pilots, port_ks, dmrs_syms, hk, nfft, cp_min, l_cdm=1, k_cdm=2, pil_set=None):
+    """Raw noise variance of estimateChannelLsEx (grid.py:808-837): np.var of the pilot residuals against the
+    delay-domain-windowed estimate, per batch item (float64 tensor (n,)) + the number of residuals."""
+    rx, pilots, pk, ps, (n, nr, L, K, P, nds, nk) = _chest_tables(rx, pilots, port_ks, dmrs_syms, pil_set)
+    dev = _dev(rx)
+    rise = int(cp_min) * K // int(nfft)
+    key = (K, rise, dev)
+    if key not in _noise_tabs:                      # window weights exactly as grid.py:812-815, DFT twiddles e^{2 pi i q/K}
+        rc = .5 * (1 - np.sin(np.pi * np.arange(rise - 1, -rise, -2) / (2 * rise)))
+        win = np.concatenate([rc[::-1], rc])
+        q = np.arange(K)
+        tw = np.cos(2 * np.pi * q / K) + 1j * np.sin(2 * np.pi * q / K)
+        _noise_tabs[key] = (torch.from_numpy(np.float64(win)).to(dev), torch.from_numpy(np.complex128(tw)).to(dev))
+    win, tw = _noise_tabs[key]
+    n_g = nds // l_cdm
+    hk = hk.to(torch.complex128).contiguous()
+    if tuple(hk.shape) != (n, n_g, K, nr, P):
+        raise ValueError("hk must be (n, nTg, K, Nr, P)")
+    cir = torch.empty((n, n_g * nr * P * 2 * rise), dtype=torch.complex128, device=dev)
+    deltas = torch.empty((n, P * nds * nk * nr), dtype=torch.complex128, device=dev)
+    check(lib().nrx_chest_noise_f64(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), _host_i32(dmrs_syms), nds, l_cdm, k_cdm, nk, L, K,
+                                    nr, P, ptr(hk), ptr(tw), ptr(win), rise, ptr(cir), ptr(deltas), n, stream()))
+    var, _, _ = noise_level(deltas)
+    return var, deltas.shape[1]
 
 
 def chest_ls_mmse(rx, pilots, port_ks, dmrs_syms, noise_var, l_cdm=1, k_cdm=2, pil_set=None):
