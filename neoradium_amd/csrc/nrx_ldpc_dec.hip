@@ -113,22 +113,19 @@ __device__ __forceinline__ int wrap(int z, int s, int zc) {
 }
 
 // Per-workgroup workspace of the f64 variant, [row][ZMAX] each.
+// Addressed as (uniform base) + (compile-time offset of the array and layer) + (32-bit lane offset): one SGPR pair and
+// one VGPR serve every access of a layer.  (With per-array lane pointers the compiler hoisted ~180 loop-invariant
+// 64-bit addresses out of the iteration loop and spilled 324 VGPRs to scratch.)
 template <typename T> struct ExactWs {
-  T* m1;
-  T* m2;
-  uint32_t* sg;
-  T* rext;
   static constexpr size_t bytes(int rows) { return (size_t)rows * ZMAX * (3 * sizeof(T) + sizeof(uint32_t)); }
-  __device__ void bind(char* base, int rows) {
-    m1 = (T*)base;
-    m2 = m1 + (size_t)rows * ZMAX;
-    rext = m2 + (size_t)rows * ZMAX;
-    sg = (uint32_t*)(rext + (size_t)rows * ZMAX);
-  }
+  static constexpr size_t off_m1(int rows, int L) { return (size_t)L * ZMAX * sizeof(T); }
+  static constexpr size_t off_m2(int rows, int L) { return ((size_t)rows + L) * ZMAX * sizeof(T); }
+  static constexpr size_t off_rext(int rows, int L) { return ((size_t)2 * rows + L) * ZMAX * sizeof(T); }
+  static constexpr size_t off_sg(int rows, int L) { return (size_t)3 * rows * ZMAX * sizeof(T) + (size_t)L * ZMAX * sizeof(uint32_t); }
 };
 
 template <typename T, int BG, bool EXACT>
-__global__ void __launch_bounds__(ZMAX)
+__global__ void __launch_bounds__(ZMAX, EXACT ? 3 : 1)   // f64: state in the workspace, two code blocks per CU (LDS 2 x 80 KB)
 ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out_cols, int n_cols_in,
                 uint8_t* __restrict__ hard, T* __restrict__ belief, char* __restrict__ ws, int tab_off) {
   using G = BgT<BG>;
@@ -143,8 +140,15 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
   T m2[EXACT ? 1 : G::ROWS];
   uint32_t sg[EXACT ? 1 : G::ROWS];
   T ech[EXACT ? 1 : G::ROWS];  // channel LLR of the layer's degree-1 extension column, at (z+shift) mod Zc
-  ExactWs<T> W;
-  if (EXACT) W.bind(ws + (size_t)blockIdx.x * ExactWs<T>::bytes(G::ROWS), G::ROWS);
+  using W = ExactWs<T>;
+  char* const wsb = EXACT ? ws + (size_t)blockIdx.x * W::bytes(G::ROWS) : nullptr;   // this workgroup's workspace
+  constexpr int R = G::ROWS;
+  auto wsT = [](char* base, size_t off, uint32_t z) __attribute__((always_inline)) -> T& {
+    return *(T*)(base + off + (size_t)(z * (uint32_t)sizeof(T)));
+  };
+  auto wsU = [](char* base, size_t off, uint32_t z) __attribute__((always_inline)) -> uint32_t& {
+    return *(uint32_t*)(base + off + (size_t)(z * 4u));
+  };
 
   for (int cb = blockIdx.x; cb < n_cb; cb += gridDim.x) {
     const T* in = llr + (size_t)cb * N;
@@ -157,13 +161,13 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
       static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
         if constexpr (EXACT) {
-          W.m1[L * ZMAX + z] = (T)0;
-          W.m2[L * ZMAX + z] = (T)0;
-          W.sg[L * ZMAX + z] = 0u;
+          wsT(wsb, W::off_m1(R, L), z) = (T)0;
+          wsT(wsb, W::off_m2(R, L), z) = (T)0;
+          wsU(wsb, W::off_sg(R, L), z) = 0u;
           constexpr int e_last = G::row_start(L + 1) - 1;
           constexpr int col = G::col(e_last);
           if constexpr (col >= G::CORE) {
-            W.rext[L * ZMAX + z] = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
+            wsT(wsb, W::off_rext(R, L), z) = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
           }
         } else {
           m1[L] = (T)0;
@@ -187,14 +191,15 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
         // iteration loop; without this the compiler hoists all ~300 of them and spills.
         int zz = z;
         int so = tab_off;
-        asm volatile("" : "+v"(zz), "+s"(so));
+        char* wb = wsb;
+        asm volatile("" : "+v"(zz), "+s"(so), "+s"(wb));
         if (active) {
           T om1, om2;
           uint32_t osg;
           if constexpr (EXACT) {
-            om1 = W.m1[L * ZMAX + z];
-            om2 = W.m2[L * ZMAX + z];
-            osg = W.sg[L * ZMAX + z];
+            om1 = wsT(wb, W::off_m1(R, L), zz);
+            om2 = wsT(wb, W::off_m2(R, L), zz);
+            osg = wsU(wb, W::off_sg(R, L), zz);
           } else {
             om1 = m1[L];
             om2 = m2[L];
@@ -213,7 +218,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
               p = P[ad[j]];
             } else if constexpr (EXACT) {
               ad[j] = 0;
-              p = W.rext[L * ZMAX + z];
+              p = wsT(wb, W::off_rext(R, L), zz);
             } else {
               // degree-1 extension column: r - msg_old is the channel LLR itself (up to fp32 rounding)
               ad[j] = 0;
@@ -252,9 +257,9 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
           const uint32_t par = __popc(negm) & 1u;
           const uint32_t nsg = (negm ^ (par ? ((1u << D) - 1u) : 0u)) | (idx << 24);
           if constexpr (EXACT) {
-            W.m1[L * ZMAX + z] = nm1;
-            W.m2[L * ZMAX + z] = nm2;
-            W.sg[L * ZMAX + z] = nsg;
+            wsT(wb, W::off_m1(R, L), zz) = nm1;
+            wsT(wb, W::off_m2(R, L), zz) = nm2;
+            wsU(wb, W::off_sg(R, L), zz) = nsg;
           } else {
             m1[L] = nm1;
             m2[L] = nm2;
@@ -269,7 +274,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
               const T nw = FpBits<T>::with_sign(mag, (nsg >> j) & 1u);
               const T r = t[j] + nw;
               if constexpr (col < G::CORE) P[ad[j]] = r;
-              else W.rext[L * ZMAX + z] = r;
+              else wsT(wb, W::off_rext(R, L), zz) = r;
             }
           });
         }
@@ -297,7 +302,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
             const int pos = wrap(z, G::shift(tab_off + e), zc);
             T r;
             if constexpr (EXACT) {
-              r = W.rext[L * ZMAX + z];
+              r = wsT(wsb, W::off_rext(R, L), z);
             } else {
               constexpr int j = e - G::row_start(L);
               const uint32_t s = sg[L];
