@@ -138,16 +138,17 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
   // register-resident check-node state (f32 variant)
   T m1[EXACT ? 1 : G::ROWS];
   T m2[EXACT ? 1 : G::ROWS];
-  uint32_t sg[EXACT ? 1 : G::ROWS];
+  uint32_t sg[G::ROWS];   // (f64 too: 46 registers fit beside the 3-waves-per-SIMD budget and save 8 B per lane-layer)
   T ech[EXACT ? 1 : G::ROWS];  // channel LLR of the layer's degree-1 extension column, at (z+shift) mod Zc
   using W = ExactWs<T>;
   char* const wsb = EXACT ? ws + (size_t)blockIdx.x * W::bytes(G::ROWS) : nullptr;   // this workgroup's workspace
   constexpr int R = G::ROWS;
-  auto wsT = [](char* base, size_t off, uint32_t z) __attribute__((always_inline)) -> T& {
-    return *(T*)(base + off + (size_t)(z * (uint32_t)sizeof(T)));
-  };
-  auto wsU = [](char* base, size_t off, uint32_t z) __attribute__((always_inline)) -> uint32_t& {
-    return *(uint32_t*)(base + off + (size_t)(z * 4u));
+  // explicit global address space: after the opaque copy of the base the compiler no longer infers it and would emit
+  // FLAT accesses (both counters, waits of zero)
+  typedef T __attribute__((address_space(1))) * gT;
+  typedef uint32_t __attribute__((address_space(1))) * gU;
+  auto wsT = [](char* base, size_t off, uint32_t z) __attribute__((always_inline)) -> gT {
+    return (gT)(base + off + (size_t)(z * (uint32_t)sizeof(T)));
   };
 
   for (int cb = blockIdx.x; cb < n_cb; cb += gridDim.x) {
@@ -161,13 +162,13 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
       static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
         if constexpr (EXACT) {
-          wsT(wsb, W::off_m1(R, L), z) = (T)0;
-          wsT(wsb, W::off_m2(R, L), z) = (T)0;
-          wsU(wsb, W::off_sg(R, L), z) = 0u;
+          *wsT(wsb, W::off_m1(R, L), z) = (T)0;
+          *wsT(wsb, W::off_m2(R, L), z) = (T)0;
+          sg[L] = 0u;
           constexpr int e_last = G::row_start(L + 1) - 1;
           constexpr int col = G::col(e_last);
           if constexpr (col >= G::CORE) {
-            wsT(wsb, W::off_rext(R, L), z) = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
+            *wsT(wsb, W::off_rext(R, L), z) = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
           }
         } else {
           m1[L] = (T)0;
@@ -182,11 +183,23 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
     }
     __syncthreads();
 
+    // f64: the state of the NEXT layer (0.75*min1, 0.75*min2, extension posterior) is fetched from the workspace
+    // while the current layer computes; every layer used to start by waiting ~1-2 us for its own three loads.
+    T pf_m1 = (T)0, pf_m2 = (T)0, pf_rx = (T)0;
+    if constexpr (EXACT) {
+      if (active) {
+        pf_m1 = *wsT(wsb, W::off_m1(R, 0), z);
+        pf_m2 = *wsT(wsb, W::off_m2(R, 0), z);
+        if constexpr (G::col(G::row_start(1) - 1) >= G::CORE) pf_rx = *wsT(wsb, W::off_rext(R, 0), z);
+      }
+    }
     for (int it = 0; it < n_iter; ++it) {
       static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
         constexpr int E0 = G::row_start(L);
         constexpr int D = G::row_start(L + 1) - E0;
+        constexpr int Ln = (L + 1) % G::ROWS;
+        constexpr bool NEXT_EXT = G::col(G::row_start(Ln + 1) - 1) >= G::CORE;
         // Opaque copies: the (z+shift) mod Zc addresses and the kernarg shift loads are invariant over the
         // iteration loop; without this the compiler hoists all ~300 of them and spills.
         int zz = z;
@@ -196,10 +209,15 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
         if (active) {
           T om1, om2;
           uint32_t osg;
+          T cur_rx = (T)0;
           if constexpr (EXACT) {
-            om1 = wsT(wb, W::off_m1(R, L), zz);
-            om2 = wsT(wb, W::off_m2(R, L), zz);
-            osg = wsU(wb, W::off_sg(R, L), zz);
+            om1 = pf_m1;
+            om2 = pf_m2;
+            cur_rx = pf_rx;
+            osg = sg[L];
+            pf_m1 = *wsT(wb, W::off_m1(R, Ln), zz);
+            pf_m2 = *wsT(wb, W::off_m2(R, Ln), zz);
+            if constexpr (NEXT_EXT) pf_rx = *wsT(wb, W::off_rext(R, Ln), zz);
           } else {
             om1 = m1[L];
             om2 = m2[L];
@@ -218,7 +236,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
               p = P[ad[j]];
             } else if constexpr (EXACT) {
               ad[j] = 0;
-              p = wsT(wb, W::off_rext(R, L), zz);
+              p = cur_rx;
             } else {
               // degree-1 extension column: r - msg_old is the channel LLR itself (up to fp32 rounding)
               ad[j] = 0;
@@ -257,9 +275,9 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
           const uint32_t par = __popc(negm) & 1u;
           const uint32_t nsg = (negm ^ (par ? ((1u << D) - 1u) : 0u)) | (idx << 24);
           if constexpr (EXACT) {
-            wsT(wb, W::off_m1(R, L), zz) = nm1;
-            wsT(wb, W::off_m2(R, L), zz) = nm2;
-            wsU(wb, W::off_sg(R, L), zz) = nsg;
+            *wsT(wb, W::off_m1(R, L), zz) = nm1;
+            *wsT(wb, W::off_m2(R, L), zz) = nm2;
+            sg[L] = nsg;
           } else {
             m1[L] = nm1;
             m2[L] = nm2;
@@ -274,7 +292,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
               const T nw = FpBits<T>::with_sign(mag, (nsg >> j) & 1u);
               const T r = t[j] + nw;
               if constexpr (col < G::CORE) P[ad[j]] = r;
-              else wsT(wb, W::off_rext(R, L), zz) = r;
+              else *wsT(wb, W::off_rext(R, L), zz) = r;
             }
           });
         }
@@ -302,7 +320,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
             const int pos = wrap(z, G::shift(tab_off + e), zc);
             T r;
             if constexpr (EXACT) {
-              r = wsT(wsb, W::off_rext(R, L), z);
+              r = *wsT(wsb, W::off_rext(R, L), z);
             } else {
               constexpr int j = e - G::row_start(L);
               const uint32_t s = sg[L];
