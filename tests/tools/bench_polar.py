@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Polar control path (BASELINE cfg4) throughput: batched DCI blind-decode candidates, SCL list 8.
 
-    python tools/bench_polar.py [--A 64] [--E 864] [--n 32768] [--reps 5]
+    python tests/tools/bench_polar.py [--A 64] [--E 864] [--n 32768] [--reps 5]
 
 Prints decoded candidates/s for the SCL kernel alone and for rate-recover + decode, plus the oracle's (NumPy port of
 the reference's recursive decoder) time per candidate on a few rows as the CPU baseline."""
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

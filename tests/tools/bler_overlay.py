@@ -2,7 +2,7 @@
 """BLER-vs-SNR overlay: the GPU engine against the CPU oracle (NumPy float64 restatement of the reference) on the SAME
 transport blocks and noise draws, slot by slot.  Writes profiles/r1_bler_overlay.json.
 
-    python tools/bler_overlay.py [--slots 24] [--out profiles/r1_bler_overlay.json]
+    python tests/tools/bler_overlay.py [--slots 24] [--out profiles/r1_bler_overlay.json]
 
 Configurations: BASELINE cfg1 (25 PRB, QPSK, BG2, SISO TDL-A 30 ns) and a 2x2 CDL-C 16-QAM case; both time-domain
 channel + DMRS-LS + MMSE, 20 iterations.  Per SNR point: block errors of both paths and whether every per-slot CRC
@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

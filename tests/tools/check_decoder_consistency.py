@@ -1,7 +1,7 @@
 """Dev tool: the fast decoder must be deterministic and agree bit for bit with the in-place (v1) kernel and, on a
 sample, with the NumPy oracle in float32 -- on inputs where many blocks do NOT converge (values keep moving)."""
 import os, sys, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from neoradium_amd import ops, _lib
