@@ -105,6 +105,12 @@ template <typename T> __device__ __forceinline__ T clip10(T x) {
 
 __device__ __forceinline__ float absT(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double absT(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float minT(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double minT(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float maxT(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double maxT(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ uint32_t hiword(float x) { return __float_as_uint(x); }        // the word holding the sign
+__device__ __forceinline__ uint32_t hiword(double x) { return (uint32_t)__double2hiint(x); }
 
 __device__ __forceinline__ int wrap(int z, int s, int zc) {
   unsigned a = (unsigned)(z + s);
@@ -150,6 +156,14 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
   auto wsT = [](char* base, size_t off, uint32_t z) __attribute__((always_inline)) -> gT {
     return (gT)(base + off + (size_t)(z * (uint32_t)sizeof(T)));
   };
+  // hot-loop form: (uniform base + compile-time offset) is made an opaque SGPR pair first, so that the access is
+  // `global_load/store v, v_lane_offset, s[base]` (without this the compiler adds the lane offset first and then
+  // needs two 64-bit VALU additions per access for the large constant)
+  auto wsL = [](char* base, size_t off, uint32_t lane_off) __attribute__((always_inline)) -> gT {
+    char* b = base + off;
+    asm volatile("" : "+s"(b));
+    return (gT)(b + (size_t)lane_off);
+  };
 
   for (int cb = blockIdx.x; cb < n_cb; cb += gridDim.x) {
     const T* in = llr + (size_t)cb * N;
@@ -157,7 +171,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
     if (active) {
       static_for<G::CORE>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        P[c * ZMAX + z] = (c < 2) ? (T)0 : clip10<T>(in[(c - 2) * zc + z]);
+        P[c * ZMAX + z] = (c < 2) ? (T)0 : clip10<T>(in[(c - 2) * zc + z]) + (T)0;   // + 0: -0.0 -> +0.0 (sign test is v < 0)
       });
       static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -168,7 +182,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
           constexpr int e_last = G::row_start(L + 1) - 1;
           constexpr int col = G::col(e_last);
           if constexpr (col >= G::CORE) {
-            *wsT(wsb, W::off_rext(R, L), z) = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
+            *wsT(wsb, W::off_rext(R, L), z) = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]) + (T)0;
           }
         } else {
           m1[L] = (T)0;
@@ -176,7 +190,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
           sg[L] = 0u;
           constexpr int e_last = G::row_start(L + 1) - 1;
           constexpr int col = G::col(e_last);
-          if constexpr (col >= G::CORE) ech[L] = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]);
+          if constexpr (col >= G::CORE) ech[L] = clip10<T>(in[(col - 2) * zc + wrap(z, G::shift(tab_off + e_last), zc)]) + (T)0;
           else ech[L] = (T)0;
         }
       });
@@ -187,11 +201,9 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
     // while the current layer computes; every layer used to start by waiting ~1-2 us for its own three loads.
     T pf_m1 = (T)0, pf_m2 = (T)0, pf_rx = (T)0;
     if constexpr (EXACT) {
-      if (active) {
-        pf_m1 = *wsT(wsb, W::off_m1(R, 0), z);
-        pf_m2 = *wsT(wsb, W::off_m2(R, 0), z);
-        if constexpr (G::col(G::row_start(1) - 1) >= G::CORE) pf_rx = *wsT(wsb, W::off_rext(R, 0), z);
-      }
+      pf_m1 = *wsT(wsb, W::off_m1(R, 0), z);
+      pf_m2 = *wsT(wsb, W::off_m2(R, 0), z);
+      if constexpr (G::col(G::row_start(1) - 1) >= G::CORE) pf_rx = *wsT(wsb, W::off_rext(R, 0), z);
     }
     for (int it = 0; it < n_iter; ++it) {
       static_for<G::ROWS>([&](auto lc) __attribute__((always_inline)) {
@@ -206,18 +218,24 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
         int so = tab_off;
         char* wb = wsb;
         asm volatile("" : "+v"(zz), "+s"(so), "+s"(wb));
+        // state of this layer (fetched while the previous one ran) and the fetch for the next one: OUTSIDE the
+        // `active` branch -- inside it the values become phis at the join and the register allocator copies them at
+        // the end of the layer, which waits for the loads in the layer that issued them.  (Lanes z >= Zc read their own
+        // unused workspace entries: ZMAX entries per row are allocated.)
+        const uint32_t zo = (uint32_t)zz * (uint32_t)sizeof(T);
+        const T cm1 = pf_m1, cm2 = pf_m2, cur_rx = pf_rx;
+        if constexpr (EXACT) {
+          pf_m1 = *wsL(wb, W::off_m1(R, Ln), zo);
+          pf_m2 = *wsL(wb, W::off_m2(R, Ln), zo);
+          if constexpr (NEXT_EXT) pf_rx = *wsL(wb, W::off_rext(R, Ln), zo);
+        }
         if (active) {
           T om1, om2;
           uint32_t osg;
-          T cur_rx = (T)0;
           if constexpr (EXACT) {
-            om1 = pf_m1;
-            om2 = pf_m2;
-            cur_rx = pf_rx;
+            om1 = cm1;
+            om2 = cm2;
             osg = sg[L];
-            pf_m1 = *wsT(wb, W::off_m1(R, Ln), zz);
-            pf_m2 = *wsT(wb, W::off_m2(R, Ln), zz);
-            if constexpr (NEXT_EXT) pf_rx = *wsT(wb, W::off_rext(R, Ln), zz);
           } else {
             om1 = m1[L];
             om2 = m2[L];
@@ -250,33 +268,46 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
               t[j] = p;
             }
           });
-          // ---- min-sum (ldpc.py:1556-1564)
+          // ---- min-sum (ldpc.py:1556-1564).  The two smallest magnitudes by min/max (no compare + select chains), the
+          // sign parity by XOR of the sign words; the argmin falls out of an equality test: first index holding min1.
           T a1 = absT(t[0]);
           T a2 = (T)3.0e38;
-          uint32_t idx = 0;
-          uint32_t negm = t[0] < (T)0 ? 1u : 0u;
+          uint32_t px = hiword(t[0]);
           static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value + 1;
-            const bool ng = t[j] < (T)0;
             const T a = absT(t[j]);
-            negm |= (ng ? 1u : 0u) << j;
-            const bool lt = a < a1;                      // strict: ties keep the first index
-            a2 = lt ? a1 : (a < a2 ? a : a2);
-            idx = lt ? (uint32_t)j : idx;
-            a1 = lt ? a : a1;
+            a2 = minT(a2, maxT(a1, a));
+            a1 = minT(a1, a);
+            px ^= hiword(t[j]);
           });
-          // QUIRK ldpc.py:1563: the argmin entry is bumped by +100000 (signed) before the 2nd min is taken
-          {
-            const T v = ((negm >> idx) & 1u) ? -a1 : a1;
+          uint32_t idx = 0;
+          static_for<D>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = D - 1 - decltype(jc)::value;
+            idx = absT(t[j]) == a1 ? (uint32_t)j : idx;
+          });
+          // QUIRK ldpc.py:1563: the argmin entry is bumped by +100000 (signed) before the 2nd min is taken, i.e.
+          // min2 = min(min2, |v_argmin + 1e5|).  |v_argmin + 1e5| >= 1e5 - min1 >= 1e5 - min2, so the bump can only win
+          // where min2 > 5e4 (filler / saturated LLRs): wave-uniform cold path, same expression for every lane in it.
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(a2 > (T)5.0e4) != 0, 0)) {
+            T v = t[D - 1];
+            static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = D - 2 - decltype(jc)::value;
+              v = idx == (uint32_t)j ? t[j] : v;
+            });
             const T q = absT(v + (T)100000);
             a2 = q < a2 ? q : a2;
           }
           const T nm1 = a1 * (T)0.75, nm2 = a2 * (T)0.75;  // ldpc.py:1573 (scale commutes with the sign)
-          const uint32_t par = __popc(negm) & 1u;
-          const uint32_t nsg = (negm ^ (par ? ((1u << D) - 1u) : 0u)) | (idx << 24);
+          // sign of the new message on edge j = parity ^ sign(t_j)   (no -0.0 can occur: inputs are loaded with + 0.0)
+          uint32_t nsg = 0;
+          static_for<D>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = D - 1 - decltype(jc)::value;
+            nsg = __builtin_amdgcn_alignbit(nsg, px ^ hiword(t[j]), 31);   // (nsg << 1) | sign bit
+          });
+          nsg |= idx << 24;
           if constexpr (EXACT) {
-            *wsT(wb, W::off_m1(R, L), zz) = nm1;
-            *wsT(wb, W::off_m2(R, L), zz) = nm2;
+            *wsL(wb, W::off_m1(R, L), zo) = nm1;
+            *wsL(wb, W::off_m2(R, L), zo) = nm2;
             sg[L] = nsg;
           } else {
             m1[L] = nm1;
@@ -292,7 +323,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
               const T nw = FpBits<T>::with_sign(mag, (nsg >> j) & 1u);
               const T r = t[j] + nw;
               if constexpr (col < G::CORE) P[ad[j]] = r;
-              else *wsT(wb, W::off_rext(R, L), zz) = r;
+              else *wsL(wb, W::off_rext(R, L), zo) = r;
             }
           });
         }
