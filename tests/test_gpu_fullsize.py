@@ -1,0 +1,102 @@
+"""GPU parity at BASELINE.json's FULL sizes (273 PRB / nFFT 4096 / 72-113 code blocks of Zc = 384) through properties
+that need no oracle run (the reference cannot build a 273-PRB carrier; the CPU oracle needs 7 s per slot and is compared
+at this size inside bench.py): encode -> erase -> decode round trips, CRC of CRC, OFDM round trip, linearity of the
+channel filter, batch-split invariance of the counters, float32 vs float64 decoder verdicts."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope='module')
+def link(dev):
+    import bench
+    import neoradium_amd as nr
+    return bench.build_link(nr, decoder="f32", num_iter=20)
+
+
+def test_metric_sizes(link):
+    c = link.cfg
+    assert (link.tbs, c.C, c.Zc, c.K, c.N, link.G, link.nfft, link.K) == (606504, 72, 384, 8448, 25344, 943488, 4096, 3276)
+
+
+@pytest.mark.parametrize("qm,nl", [(6, 4), (8, 4)])
+def test_coding_round_trip_with_erasures(link, dev, qm, nl):
+    """segment -> encode -> rate match -> (LLRs, 12 % of them erased) -> rate recover -> decode -> CRC/merge returns the
+    transport block exactly, in float32 and float64; a code block that received only noise fails alone."""
+    import torch
+    from neoradium_amd import ops, _lib
+    tbs = 606504 if qm == 6 else 950984                   # metric configuration / BASELINE cfg3 (256-QAM, 113 blocks)
+    cfg = _lib.ldpc_config(1, tbs + 24)
+    G = 39312 * nl * qm
+    g = torch.Generator(device=dev)
+    g.manual_seed(qm)
+    tb = torch.randint(0, 2, (2, tbs), device=dev, generator=g, dtype=torch.uint8)
+    coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+    rm = ops.ldpc_rate_match(coded, cfg, G, nl, qm)
+    assert tuple(rm.shape) == (2, G)
+    lens = _lib.ldpc_cb_lens(G, cfg.C, nl, qm)
+    assert sum(lens) == G and all(v % (nl * qm) == 0 for v in lens)
+    llr = (1.0 - 2.0 * rm.to(torch.float64)) * 8.0
+    erase = torch.rand((2, G), device=dev, generator=g) < 0.12
+    llr[erase] = 0.0
+    # code block 5 of transport block 1 receives noise only (random signs at full confidence).  (Erasing it would not
+    # do: all-zero LLRs decode to the all-zero word, which passes the zero-initialised CRC24B -- as in the reference.)
+    dead = sum(lens[:5])
+    llr[1, dead:dead + lens[5]] = 8.0 - 16.0 * torch.randint(0, 2, (lens[5],), device=dev, generator=g).to(torch.float64)
+    for ft in (torch.float32, torch.float64):
+        rr = ops.ldpc_rate_recover(llr.to(ft), cfg, nl, qm)
+        dec = ops.ldpc_decode(rr, cfg, 12)
+        tb_out, cb_ok, tb_ok = ops.ldpc_crc_merge(dec, cfg)
+        ok = cb_ok.cpu().numpy().astype(bool)
+        assert ok[0].all() and ok[1].sum() == cfg.C - 1 and not ok[1, 5]
+        assert torch.equal(tb_out[0, :tbs], tb[0]) and bool(tb_ok.cpu().numpy()[0]) and not bool(tb_ok.cpu().numpy()[1])
+        # the other 71/112 blocks of the damaged transport block are exact too
+        seg = ops.ldpc_segment(tb[1:2], cfg)
+        good = [i for i in range(cfg.C) if i != 5]
+        assert torch.equal(dec[cfg.C:][good], seg[good])
+
+
+def test_ofdm_round_trip_and_filter_linearity(link, dev):
+    """273 PRB, nFFT 4096: demodulate(modulate(X)) = X to 1e-12; the tapped-delay-line filter is linear."""
+    import torch
+    from neoradium_amd import ops
+    rng = np.random.default_rng(3)
+    cps = [int(v) for v in (link.sym_lens[0][:-1] - link.nfft)]
+    x = torch.from_numpy(rng.standard_normal((2, 4, 14, 3276)) + 1j * rng.standard_normal((2, 4, 14, 3276))).to(dev)
+    w = ops.ofdm_modulate(x, 4096, cps, window_len=0)
+    assert w.shape[-1] == link.slot_len[0] == 61440
+    y = ops.ofdm_demodulate(w, 4096, cps, 3276)
+    assert float((y - x).abs().max()) <= 1e-12 * float(x.abs().max())
+    times = torch.from_numpy(link.gain_times(np.arange(2))).to(dev)
+    gains = ops.cdl_gains(link.A, link.nu, times, A_los=link.Alos, nu_los=link.nulos)
+    sl = [int(v) for v in link.sym_lens[0]]
+    a = 0.3 - 1.1j
+    w2 = torch.flip(w, dims=[0])
+    f = lambda s: ops.apply_td_paths(s, gains, link.taps, link.tap_off, sl, hist=link.td_hist)
+    lhs, rhs = f(a * w + w2), a * f(w) + f(w2)
+    assert float((lhs - rhs).abs().max()) <= 1e-12 * float(rhs.abs().max())
+
+
+def test_engine_counters_at_metric_size(link, dev):
+    """Whole slots at the metric configuration: counters do not depend on how a slot range is batched (the basis of the
+    multi-GPU sharding), clean at very high SNR, and the float64 decoder reaches the same CRC verdicts there."""
+    import bench
+    import neoradium_amd as nr
+    whole = link.run(10, 4, 33.0, seed=7).cpu().numpy()
+    split = (link.run(10, 1, 33.0, seed=7) + link.run(11, 3, 33.0, seed=7)).cpu().numpy()
+    assert np.array_equal(whole, split) and whole[1] == 4 * 72 and whole[3] == 4 * 606504
+    hi = link.run(0, 2, 60.0, seed=7).cpu().numpy()
+    assert hi[0] == 0 and hi[2] == 0
+    l64 = bench.build_link(nr, decoder="f64", num_iter=20)
+    _, d32 = link.run(3, 2, 36.0, seed=11, details=True)
+    _, d64 = l64.run(3, 2, 36.0, seed=11, details=True)
+    a, b = d32[0][1]['cb_ok'].cpu().numpy(), d64[0][1]['cb_ok'].cpu().numpy()
+    assert (a != b).mean() <= 0.02           # verdicts may differ on a block sitting exactly on the decoding threshold
+    rel = float((d32[0][1]['llr'].double() - d64[0][1]['llr']).abs().max() / d64[0][1]['llr'].abs().max())
+    assert rel <= 1e-5                        # north-star tolerance on float LLRs
