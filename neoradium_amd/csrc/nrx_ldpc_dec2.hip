@@ -371,7 +371,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         float t[D];
         float a1 = 0.0f, a2 = 0.0f;
         uint32_t px = 0, word = 0;
-        if (live) {   // (wave-uniform; the per-layer branch also keeps each layer its own scheduling region)
+        if (__builtin_expect(live, 1)) {   // (wave-uniform; the per-layer branch also keeps each layer its own scheduling region)
           // ---- pass 1a: issue every LDS read of the layer (last edge first: the order pass 1b consumes them in)
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = DC - 1 - decltype(jc)::value;
@@ -470,7 +470,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           // with vmcnt(PFN - 1).  (`in` is clamped to an existing code block when the wave is not live.)
           epf[Y::ext_idx(L) % PFN] = ext_load(Y::next_ext(L, PFN), z4);
         }
-        if (live) {   // (second region: measured slightly faster than one region per layer)
+        if (__builtin_expect(live, 1)) {   // (second region: measured slightly faster than one region per layer)
           const float nm1 = a1 * 0.75f, nm2 = a2 * 0.75f;
           m1[L] = nm1;
           m2[L] = nm2;
