@@ -177,7 +177,7 @@ def main():
                                  "HBM only at entry/exit (SURVEY 8d)",
                          "edge_visits_per_s": edge_visits / (dec_ms * 1e-3)},
         }
-        if args.decoder == 'f32' and not args.no_exact:
+        if args.decoder == 'f32' and not args.no_exact and world == 1:
             # the same step with the float64 decoder (the reference's arithmetic, hard bits identical to the NumPy path)
             xl = build_link(nr, decoder='f64')
             xb = min(B, 32)
@@ -192,7 +192,7 @@ def main():
             xc = xc.cpu().numpy()
             out["bit_exact_path"] = {"decoder": "f64 (ldpc_dec_kernel<double,1,true>)", "value": 2 * xb / xdt, "unit": "slots/s",
                                      "n_gpus": 1, "slots": 2 * xb, "block_errors": int(xc[0]), "blocks": int(xc[1])}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                # the CPU leg runs on rank 0 at N = 1 only (contract)
             base, parity = cpu_baseline(link, args.snr)
             out["cpu_baseline"] = base
             out["parity_vs_cpu_oracle"] = parity
