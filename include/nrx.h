@@ -344,6 +344,26 @@ int32_t nrx_chest_noise_f64(const void* rx, const void* pilots, const int32_t* p
                             int32_t K, int32_t nr, int32_t P, const void* hk, const void* tw, const double* win,
                             int32_t rise, void* cir_ws, void* deltas, int32_t n_batch, void* stream);
 
+/* ------------------------------------------------------------------------------------- per-PRG precoding
+ * pdsch.py:1132-1165 (getPrecodingMatrix with prgSize 2/4, or the wideband precoder of a partial allocation: a list of
+ * (rbList, F) groups) + grid.py:482-493 (Grid.precode with that list).  The group lists are host bookkeeping (the
+ * reference closes a group when the first PRB of the next one arrives, so PRB 0 stands alone and trailing PRBs may be
+ * left without a precoder); the device work is:
+ *   nrx_group_mean_f64      Hm (n,G,E) = mean over L symbols x the group's n_k contiguous subcarriers of H (n,L,K,E)
+ *   nrx_svd_precoder_f64    on the n*G means (n_avg = 1)
+ *   nrx_precode_prg_*       out (n,Nt,L,K) = F[b][k2g[k]] x grid (n,Nl,L,K); k2g (device int32, K entries, -1 = no
+ *                           group: zero output); f_stride = elements between items' F blocks (0 = shared)
+ *   nrx_effective_channel_prg_f64   H @ F[k2g[k]] for the perfect-CSI harness path. */
+int32_t nrx_group_mean_f64(const void* H, int32_t n_items, int32_t L, int32_t K, int32_t E, const int32_t* k0,
+                           const int32_t* nk, int32_t G, void* Hm, void* stream);
+int32_t nrx_precode_prg_f32(const void* grid, const void* f, int64_t f_stride, const int32_t* k2g, int32_t nl, int32_t nt,
+                            int32_t L, int32_t K, void* out, int32_t n_batch, void* stream);
+int32_t nrx_precode_prg_f64(const void* grid, const void* f, int64_t f_stride, const int32_t* k2g, int32_t nl, int32_t nt,
+                            int32_t L, int32_t K, void* out, int32_t n_batch, void* stream);
+int32_t nrx_effective_channel_prg_f64(const void* H, const void* F, int64_t f_stride, const int32_t* k2g, int32_t n_items,
+                                      int32_t L, int32_t K, int32_t n_rx, int32_t n_tx, int32_t n_layers, void* out,
+                                      void* stream);
+
 /* nrx_chest_ls_f64 + nrx_mmse_equalize_f64 in one call without materialising the (L, K, Nr, P) estimate (at most two
  * DMRS time groups): hk_ws is caller-owned scratch of n_batch * (n_ds/l_cdm) * K * nr * P complex128; eq (n,P,L,K)
  * complex128, scale (n,P,L,K) float64.  Results are identical to the two separate calls. */

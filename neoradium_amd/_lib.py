@@ -82,6 +82,10 @@ SIGNATURES.update({
     'nrx_chest_ls_mmse_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp]),
     'nrx_chest_ls_ex_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
     'nrx_chest_noise_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]),
+    'nrx_group_mean_f64': (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
+    'nrx_precode_prg_f32': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),
+    'nrx_precode_prg_f64': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),
+    'nrx_effective_channel_prg_f64': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_polar_encode': (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     'nrx_polar_rate_match': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'nrx_polar_rate_recover_f64': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),

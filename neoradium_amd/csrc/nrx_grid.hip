@@ -33,6 +33,76 @@ precode_kernel(const cx<T>* __restrict__ grid, const cx<T>* __restrict__ f, int6
   }
 }
 
+// Per-PRG precoder (grid.py:482-493 with the (rbList, F) list of pdsch.py:1132-1165): subcarrier k uses matrix
+// k2g[k] of item b; k2g[k] < 0 = no group covers the subcarrier -> the output is zero there, like the reference's
+// zero-initialised (K, Nt, Nl) precoder tensor.
+template <typename T>
+__global__ void __launch_bounds__(256)
+precode_prg_kernel(const cx<T>* __restrict__ grid, const cx<T>* __restrict__ f, int64_t f_stride,
+                   const int32_t* __restrict__ k2g, int nl, int nt, int L, int K, cx<T>* __restrict__ out, int n_batch) {
+  const int lk = L * K;
+  const int64_t total = (int64_t)n_batch * lk;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / lk), i = (int)(g - (int64_t)b * lk);
+    const int grp = k2g[i % K];
+    if (grp < 0) {
+      for (int t = 0; t < nt; ++t) out[((size_t)b * nt + t) * lk + i] = cx<T>(0, 0);
+      continue;
+    }
+    cd x[8];
+    for (int n = 0; n < nl; ++n) x[n] = cd(grid[((size_t)b * nl + n) * lk + i]);
+    const cx<T>* fb = f + (size_t)b * f_stride + (size_t)grp * nt * nl;
+    for (int t = 0; t < nt; ++t) {
+      cd acc(0, 0);
+      for (int n = 0; n < nl; ++n) nrx::cmac(acc, cd(fb[t * nl + n]), x[n]);
+      out[((size_t)b * nt + t) * lk + i] = cx<T>(acc);
+    }
+  }
+}
+
+// Mean channel of each PRG (pdsch.py:1125-1127): Hm[b][g][e] = mean over the L symbols and the group's n_k subcarriers
+// (contiguous, starting at k0) of H[b][l][k][e], e = (r, t).  One thread per (b, g, e).
+__global__ void __launch_bounds__(256)
+group_mean_kernel(const cd* __restrict__ H, int L, int K, int E, const int32_t* __restrict__ k0, const int32_t* __restrict__ nk,
+                  int G, cd* __restrict__ Hm, int n_batch) {
+  const int64_t total = (int64_t)n_batch * G * E;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(gi % E), g = (int)((gi / E) % G), b = (int)(gi / ((int64_t)E * G));
+    const cd* src = H + (size_t)b * L * K * E + e;
+    double sr = 0, si = 0;
+    for (int l = 0; l < L; ++l)
+      for (int k = 0; k < nk[g]; ++k) {
+        const cd v = src[((size_t)l * K + k0[g] + k) * E];
+        sr += v.re;
+        si += v.im;
+      }
+    const double cnt = (double)L * (double)nk[g];
+    Hm[gi] = cd(sr / cnt, si / cnt);
+  }
+}
+
+// Hest[b][l][k][r][p] = sum_t H[b][l][k][r][t] * F[b][k2g[k]][t][p]   (perfect CSI with per-PRG precoders; zero
+// where no group covers k)
+__global__ void __launch_bounds__(256)
+eff_channel_prg_kernel(const cd* __restrict__ H, const cd* __restrict__ F, int64_t f_stride, const int32_t* __restrict__ k2g,
+                       int L, int K, int nr, int nt, int nl, cd* __restrict__ out, int64_t total) {
+  const int lk = L * K;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(g % nl);
+    const int r = (int)((g / nl) % nr);
+    const int64_t i = g / ((int64_t)nl * nr);  // b*lk + re
+    const int b = (int)(i / lk);
+    const int grp = k2g[(int)(i % K)];
+    cd acc(0, 0);
+    if (grp >= 0) {
+      const cd* h = H + ((size_t)i * nr + r) * nt;
+      const cd* f = F + (size_t)b * f_stride + (size_t)grp * nt * nl;
+      for (int t = 0; t < nt; ++t) nrx::cmac(acc, h[t], f[t * nl + p]);
+    }
+    out[g] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ applyChannel
 // out[b][r][lk] = sum_t H[b][lk][r][t] * grid[b][t][lk]        (grid.py:1006-1011)
 template <typename T>
@@ -343,5 +413,44 @@ extern "C" int32_t nrx_random_bits(uint8_t* out, int64_t n_per, int32_t n_batch,
   hipLaunchKernelGGL(random_bits_kernel, dim3(nrx::stream_grid(((long)n_per + 127) / 128 * n_batch, 256)), dim3(256), 0,
                      (hipStream_t)stream, out, n_per, n_batch, seed, stream_id, batch_offset);
   NRX_CHECK_LAUNCH("nrx_random_bits");
+  return NRX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------- per-PRG precoding
+template <typename T>
+static int32_t precode_prg_entry(const void* grid, const void* f, int64_t f_stride, const int32_t* k2g, int32_t nl, int32_t nt,
+                                 int32_t L, int32_t K, void* out, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(grid && f && k2g && out, NRX_E_ARG, "nrx_precode_prg: NULL buffer");
+  NRX_REQUIRE(nl >= 1 && nl <= 8 && nt >= 1 && L >= 0 && K >= 0 && n_batch >= 0, NRX_E_ARG, "nrx_precode_prg: bad sizes (layers 1..8)");
+  if ((int64_t)L * K == 0 || n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(precode_prg_kernel<T>, dim3(nrx::stream_grid((long)L * K * n_batch, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const cx<T>*)grid, (const cx<T>*)f, f_stride, k2g, nl, nt, L, K, (cx<T>*)out, n_batch);
+  NRX_CHECK_LAUNCH("nrx_precode_prg");
+  return NRX_OK;
+}
+extern "C" int32_t nrx_precode_prg_f32(const void* grid, const void* f, int64_t f_stride, const int32_t* k2g, int32_t nl, int32_t nt, int32_t L, int32_t K, void* out, int32_t n_batch, void* stream) { return precode_prg_entry<float>(grid, f, f_stride, k2g, nl, nt, L, K, out, n_batch, stream); }
+extern "C" int32_t nrx_precode_prg_f64(const void* grid, const void* f, int64_t f_stride, const int32_t* k2g, int32_t nl, int32_t nt, int32_t L, int32_t K, void* out, int32_t n_batch, void* stream) { return precode_prg_entry<double>(grid, f, f_stride, k2g, nl, nt, L, K, out, n_batch, stream); }
+
+extern "C" int32_t nrx_group_mean_f64(const void* H, int32_t n_items, int32_t L, int32_t K, int32_t E, const int32_t* k0,
+                                      const int32_t* nk, int32_t G, void* Hm, void* stream) {
+  NRX_REQUIRE(H && k0 && nk && Hm, NRX_E_ARG, "nrx_group_mean: NULL buffer");
+  NRX_REQUIRE(L >= 1 && K >= 1 && E >= 1 && G >= 0 && n_items >= 0, NRX_E_ARG, "nrx_group_mean: bad sizes");
+  if (G == 0 || n_items == 0) return NRX_OK;
+  hipLaunchKernelGGL(group_mean_kernel, dim3(nrx::stream_grid((long)n_items * G * E, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const cd*)H, L, K, E, k0, nk, G, (cd*)Hm, n_items);
+  NRX_CHECK_LAUNCH("nrx_group_mean");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_effective_channel_prg_f64(const void* H, const void* F, int64_t f_stride, const int32_t* k2g,
+                                                 int32_t n_items, int32_t L, int32_t K, int32_t n_rx, int32_t n_tx,
+                                                 int32_t n_layers, void* out, void* stream) {
+  NRX_REQUIRE(H && F && k2g && out, NRX_E_ARG, "nrx_effective_channel_prg: NULL buffer");
+  const int64_t total = (int64_t)n_items * L * K * n_rx * n_layers;
+  if (total == 0) return NRX_OK;
+  hipLaunchKernelGGL(eff_channel_prg_kernel, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const cd*)H, (const cd*)F, f_stride, k2g, L, K, n_rx, n_tx, n_layers, (cd*)out, total);
+  NRX_CHECK_LAUNCH("nrx_effective_channel_prg");
   return NRX_OK;
 }

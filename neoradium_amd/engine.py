@@ -29,8 +29,6 @@ class PdschLink:
                  decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False):
         if pdsch.numCW != 1:
             raise NotImplementedError("PdschLink: two-codeword PDSCH (more than 4 layers) is not built")
-        if pdsch.prgSize != 0:
-            raise NotImplementedError("PdschLink: only the wideband precoder (prgSize=0) is built")
         if pdsch.dmrs is None:
             raise ValueError("PdschLink: the PDSCH needs a DMRS configuration (pdsch.setDMRS)")
         if chanEst not in ("LS", "Perfect"):
@@ -88,6 +86,29 @@ class PdschLink:
         self.scr = D(pdsch._scrambling(0, self.G))
         self.cfg = _lib.ldpc_config(baseGraphNo, self.tbs + 24)
         self.first_prb = int(pdsch.prbSet[0])
+        # ---- precoder groups exactly as PDSCH.getPrecodingMatrix forms them (pdsch.py:1142-1163: a group is closed when
+        # the FIRST PRB of the next group arrives and the last one is never closed).  One group covering a full-band
+        # wideband allocation = the single-matrix path; otherwise the per-PRG path (prgSize 2/4, or a partial
+        # allocation whose "wideband" precoder the reference applies to its first PRB only).
+        groups, cur, rbs = [], -1, []
+        for prb in pdsch.prbSet:
+            grp = 0 if pdsch.prgSize == 0 else (int(prb) + bwp.startRb) // pdsch.prgSize
+            rbs.append(int(prb))
+            if grp != cur:
+                groups.append(rbs)
+                cur, rbs = grp, []
+        self.prg = not (len(pdsch.prbSet) == bwp.numRbs and pdsch.prgSize == 0)
+        if self.prg:
+            k2g = np.full(self.K, -1, dtype=np.int32)
+            k0, nk = [], []
+            for gi, g_rbs in enumerate(groups):
+                if g_rbs != list(range(g_rbs[0], g_rbs[0] + len(g_rbs))):
+                    raise NotImplementedError("PdschLink: a precoding group must be a run of consecutive PRBs")
+                k0.append(12 * g_rbs[0])
+                nk.append(12 * len(g_rbs))
+                k2g[12 * g_rbs[0]:12 * (g_rbs[0] + len(g_rbs))] = gi
+            self.prg_k0, self.prg_nk, self.prg_k2g = D(np.int32(k0)), D(np.int32(nk)), D(k2g)
+            self.prg_groups = groups
 
         # ---- channel: static ray coefficients + tap matrix on the device
         A, nu, Alos, nulos = channel._staticOnDevice()
@@ -186,21 +207,28 @@ class PdschLink:
         times = D(self.gain_times(slots))
         gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
         cir1, off = ops.cir(gains1, self.coeff, self.L)
-        hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
-        F = ops.svd_precoder(hsub, self.nl)                                     # wideband SVD precoder (first PRB)
         H = None
-        if self.freqDomain or self.chanEst == "Perfect":
+        if self.freqDomain or self.chanEst == "Perfect" or self.prg:
             H = ops.channel_matrix(cir1, off, self.L, self.K, self.nfft)
+        if self.prg:        # one SVD precoder per PRG: mean channel of the group -> right singular vectors
+            hm = ops.group_mean(H, self.prg_k0, self.prg_nk)                    # (n, G, Nr, Nt)
+            G = hm.shape[1]
+            F = ops.svd_precoder(hm.reshape(n * G, 1, self.nr, self.nt), self.nl).reshape(n, G, self.nt, self.nl)
+            grid = ops.precode_prg(grid, F, self.prg_k2g)                       # (n, Nt, L, K); F is applied from here on
+        else:
+            hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+            F = ops.svd_precoder(hsub, self.nl)                                 # wideband SVD precoder (first PRB)
 
         if self.freqDomain:
-            rx = ops.apply_channel_fd(ops.precode(grid, F), H)
+            rx = ops.apply_channel_fd(grid if self.prg else ops.precode(grid, F), H)
             _, sigma, nv = ops.noise_level(rx, snr_lin=snr_lin)                 # grid.py:1040-1046
             rxg = ops.add_noise(rx, noise.to(dev), sigma) if noise is not None else \
                 ops.awgn(rx, sigma, seed, stream_id=2, batch_offset=int(slots[0]))
         else:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
-            tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay, f=F)   # precoder fused
+            tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay,
+                                   f=None if self.prg else F)                   # wideband precoder fused into the load
             ry = ops.apply_td_paths(tx, gains1, self.taps, self.tap_off, [int(v) for v in self.sym_lens[sis]],
                                     hist=self.td_hist)
             width = ry.shape[-1]
@@ -214,7 +242,7 @@ class PdschLink:
         # ---- Rx
         hest = None
         if self.chanEst == "Perfect":
-            hest = ops.effective_channel(H, F)
+            hest = ops.effective_channel_prg(H, F, self.prg_k2g) if self.prg else ops.effective_channel(H, F)
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
         elif self.polarInt:
             hest = ops.chest_ls_ex(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,

@@ -639,6 +639,50 @@ def effective_channel(H, F):
     return out
 
 
+def group_mean(H, k0, nk):
+    """Mean channel per PRG: H (n,L,K,Nr,Nt), groups [k0[g], k0[g]+nk[g]) -> (n,G,Nr,Nt) (pdsch.py:1125-1127)."""
+    H = H.to(torch.complex128).contiguous()
+    n, L, K, nr, nt = H.shape
+    dev = _dev(H)
+    k0, nk = _i32(k0, dev), _i32(nk, dev)
+    G = k0.numel()
+    out = torch.empty((n, G, nr, nt), dtype=torch.complex128, device=dev)
+    check(lib().nrx_group_mean_f64(ptr(H), n, L, K, nr * nt, ptr(k0), ptr(nk), G, ptr(out), stream()))
+    return out
+
+
+def precode_prg(grid, f, k2g):
+    """Grid.precode with a per-PRG list: grid (n,Nl,L,K), f (n,G,Nt,Nl) or (G,Nt,Nl), k2g (K,) int32 (-1: no group)."""
+    grid = grid.contiguous()
+    sfx, _ = _ct(grid)
+    n, nl, L, K = grid.shape
+    f = f.to(grid.dtype).contiguous()
+    shared = f.dim() == 3
+    G, nt = f.shape[-3], f.shape[-2]
+    if f.shape[-1] != nl or (not shared and f.shape[0] != n):
+        raise ValueError("The last dimension of 'f' (%d) must match the first dimension of the grid (%d)" % (f.shape[-1], nl))
+    k2g = _i32(k2g, _dev(grid))
+    if k2g.numel() != K:
+        raise ValueError("k2g must hold one group index per subcarrier")
+    out = torch.empty((n, nt, L, K), dtype=grid.dtype, device=_dev(grid))
+    fn = getattr(lib(), 'nrx_precode_prg_' + sfx)
+    check(fn(ptr(grid), ptr(f), 0 if shared else G * nt * nl, ptr(k2g), nl, nt, L, K, ptr(out), n, stream()))
+    return out
+
+
+def effective_channel_prg(H, F, k2g):
+    """H (n,L,K,Nr,Nt) @ F[k2g[k]] with F (n,G,Nt,Nl) -> (n,L,K,Nr,Nl); zero where k2g < 0."""
+    H = H.to(torch.complex128).contiguous()
+    F = F.to(torch.complex128).contiguous()
+    n, L, K, nr, nt = H.shape
+    G, nl = F.shape[-3], F.shape[-1]
+    k2g = _i32(k2g, _dev(H))
+    out = torch.empty((n, L, K, nr, nl), dtype=torch.complex128, device=_dev(H))
+    check(lib().nrx_effective_channel_prg_f64(ptr(H), ptr(F), 0 if F.dim() == 3 else G * nt * nl, ptr(k2g), n, L, K, nr, nt, nl,
+                                              ptr(out), stream()))
+    return out
+
+
 def random_bits(n_batch, n_per, seed, device, stream_id=0, batch_offset=0):
     """(n_batch, n_per) uniform random bits from the counter-based device generator."""
     out = torch.empty((n_batch, n_per), dtype=torch.uint8, device=device)

@@ -57,7 +57,7 @@ def _slot(nr, c, link_mode=False):
     nr.random.setSeed(c['seed'])
     car = nr.Carrier(numRbs=c['numRbs'], spacing=c['spacing'])
     bwp = car.curBwp
-    p = nr.PDSCH(bwp, numLayers=c['layers'], nID=car.cellId, modulation=c['mod'])
+    p = nr.PDSCH(bwp, numLayers=c['layers'], nID=car.cellId, modulation=c['mod'], prgSize=c.get('prgSize', 0))
     p.setDMRS(**c['dm'])
     ch_ = c['chan']
     if ch_[0] == 'cdl':
@@ -149,15 +149,17 @@ def test_harq_ir_loop_vs_reference(dev):
     assert cw.decBuffer is None or cw.decBuffer.is_cuda          # soft buffers stay in HBM
 
 
-@pytest.mark.parametrize("freqDomain,chanEst", [(False, "LS"), (True, "Perfect"), (False, "Perfect"), (True, "LS")])
-def test_engine_matches_class_surface(dev, freqDomain, chanEst):
+@pytest.mark.parametrize("freqDomain,chanEst,prg", [(False, "LS", 0), (True, "Perfect", 0), (False, "Perfect", 0), (True, "LS", 0),
+                                                    (False, "LS", 4), (True, "Perfect", 4), (False, "Perfect", 2)])
+def test_engine_matches_class_surface(dev, freqDomain, chanEst, prg):
     """The batched engine (one launch per stage for all slots) reproduces slot-by-slot class-surface results for the
-    same transport blocks and noise draws (parity mode), including slots in the middle of a run."""
+    same transport blocks and noise draws (parity mode), including slots in the middle of a run -- with the wideband
+    precoder and with per-PRG precoders (prgSize 2 / 4, groups formed like the reference forms them)."""
     import torch
     import neoradium_amd as nr
     from neoradium_amd._dev import D
     cfg = dict(seed=11, numRbs=25, spacing=15, mod='16QAM', layers=2, dm=dict(configType=1, additionalPos=1),
-               chan=('cdl', 'C', 100, 30, [1, 2], [1, 1]), slot0=0)
+               chan=('cdl', 'C', 100, 30, [1, 2], [1, 1]), slot0=0, prgSize=prg)
     rate, snr, nit, n_slots = 0.45, 13.0, 8, 3
     car, bwp, p, ch = _slot(nr, cfg)
     link = nr.PdschLink(p, ch, rate, baseGraphNo=1, numIter=nit, freqDomain=freqDomain, chanEst=chanEst, decoder="f64")
@@ -183,9 +185,19 @@ def test_engine_matches_class_surface(dev, freqDomain, chanEst):
         p.populateGrid(grid, rm)
         idx = p.getReIndexes(grid, "PDSCH")
         H = ch.getChannelMatrix()
-        F = d['F'][s].cpu().numpy()                          # the engine's own SVD precoder
+        F = d['F'][s].cpu().numpy()                          # the engine's own SVD precoder(s)
         Fref = p.getPrecodingMatrix(H)
-        assert np.abs(F @ F.conj().T - Fref @ Fref.conj().T).max() < 1e-9
+        if prg:
+            assert isinstance(Fref, list) and len(Fref) == F.shape[0] and [list(r) for r, _ in Fref] == link.prg_groups
+            for (rbs, fr), fe in zip(Fref, F):
+                assert np.abs(fe @ fe.conj().T - fr @ fr.conj().T).max() < 1e-9
+            F = [(rbs, fe) for (rbs, _), fe in zip(Fref, F)]
+            Fk = np.zeros((link.K,) + F[0][1].shape, dtype=np.complex128)   # per-subcarrier precoder (zero: no group)
+            for rbs, fe in F:
+                for rb in rbs:
+                    Fk[12 * rb:12 * rb + 12] = fe
+        else:
+            assert np.abs(F @ F.conj().T - Fref @ Fref.conj().T).max() < 1e-9
         pg = grid.precode(F)
         if freqDomain:
             rx = pg.applyChannel(H).addNoise(snrDb=snr, useRxPower=True, ranGen=FixedNoise(z[s]))
@@ -193,7 +205,10 @@ def test_engine_matches_class_surface(dev, freqDomain, chanEst):
             w = pg.ofdmModulate().pad(ch.getMaxDelay())
             r = ch.applyToSignal(w).addNoise(snrDb=snr, bwp=bwp, useRxPower=True, ranGen=FixedNoise(z[s]))
             rx = r.sync(ch.getTimingOffset()).ofdmDemodulate(bwp)
-        hest = (H @ F[None, ...]) if chanEst == "Perfect" else rx.estimateChannelLS(p.dmrs)[0]
+        if chanEst != "Perfect":
+            hest = rx.estimateChannelLS(p.dmrs)[0]
+        else:
+            hest = (H @ Fk[None]) if prg else (H @ F[None, ...])
         eq, sc = rx.equalize(hest)
         llr = p.getLLRsFromGrid(eq, idx, sc)[0]
         ref = d['llr'][s].cpu().numpy()
@@ -284,3 +299,34 @@ def test_engine_two_pass_decoding_is_equivalent(dev):
 def torch_equal(x, y):
     import torch
     return torch.equal(x, y)
+
+
+def test_prg_precoding_vs_reference(dev):
+    """PDSCH.getPrecodingMatrix with prgSize 2 / 4 (and the wideband precoder of a partial allocation) reproduces the
+    reference's groups -- including its habit of closing a group when the first PRB of the next one arrives, which
+    leaves PRB 0 alone in the first group -- and Grid.precode applies the per-group list like the reference."""
+    import neoradium_amd as nr
+    g = np.load(os.path.join(GOLD, 'prg.npz'))
+    for name in g['names']:
+        cfg = eval(str(g[name + '_cfg']))
+        car = nr.Carrier(numRbs=cfg['numRbs'], spacing=cfg['spacing'])
+        kw = dict(numLayers=cfg['layers'], nID=car.cellId, modulation='16QAM', prgSize=cfg['prgSize'])
+        if cfg['prbSet'] is not None:
+            kw['prbSet'] = cfg['prbSet']
+        p = nr.PDSCH(car.curBwp, **kw)
+        p.setDMRS(configType=1, additionalPos=1)
+        H = g[name + '_H']
+        F = p.getPrecodingMatrix(H)
+        n = int(g[name + '_n_groups'])
+        assert isinstance(F, list) and len(F) == n
+        ref = []
+        for i in range(n):
+            rbs, f = g[f'{name}_rbs{i}'], g[f'{name}_f{i}']
+            assert list(F[i][0]) == list(rbs)
+            # singular vectors are defined up to a phase per column: compare the projectors
+            assert np.abs(F[i][1] @ F[i][1].conj().T - f @ f.conj().T).max() < 1e-10
+            ref.append((list(rbs), f))
+        grid = car.curBwp.createGrid(cfg['layers'])
+        grid.grid = g[name + '_grid'].copy()
+        out = grid.precode(ref).grid
+        assert np.abs(out - g[name + '_precoded']).max() <= 1e-12 * np.abs(g[name + '_precoded']).max()

@@ -11,6 +11,7 @@ Outputs (all data: inputs + the reference's outputs, nothing of its source):
   tests/golden/host.npz          Carrier / PDSCH / DMRS index + pilot tables, TBS values, SnrScheduler walks
   tests/golden/channels.npz      CDL / TDL per-slot gains + coefficient matrices for seeded channels
   tests/golden/chest.npz         DMRS LS estimates (linear / polar subcarrier interpolation) + noise estimates
+  tests/golden/prg.npz           per-PRG precoders (group lists + matrices) and the precoded grid
   tests/golden/polar.npz         polar DCI/PBCH/UCI chains: bits, LLRs, SCL candidate lists and path costs
   tests/golden/e2e_*.npz         whole PDSCH slots (inputs: seed-derived bits/noise; outputs: LLRs, bits, CRC)
 """
@@ -242,6 +243,41 @@ def chest():
     np.savez_compressed(os.path.join(GOLD, 'chest.npz'), **out)
 
 
+def prg():
+    """PRG precoding (prgSize 2 / 4 and wideband on a partial allocation): PDSCH.getPrecodingMatrix groups + matrices and
+    Grid.precode with the per-group list (inputs: channel matrix and populated grid)."""
+    out = {}
+    cases = [('p2', 21, 13, 15, 2, 2, None), ('p4', 22, 13, 15, 2, 4, None), ('w_part', 23, 13, 15, 1, 0, list(range(3, 11)))]
+    out['names'] = np.array([c[0] for c in cases])
+    for name, seed, numRbs, spacing, layers, prg, prbs in cases:
+        nr.random.setSeed(seed)
+        car = nr.Carrier(numRbs=numRbs, spacing=spacing)
+        bwp = car.curBwp
+        kw = dict(numLayers=layers, nID=car.cellId, modulation='16QAM', prgSize=prg)
+        if prbs is not None:
+            kw['prbSet'] = prbs
+        p = nr.PDSCH(bwp, **kw)
+        p.setDMRS(configType=1, additionalPos=1)
+        ch = nr.CdlChannel(bwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                           txAntenna=nr.AntennaPanel([1, 2], polarization='x'), rxAntenna=nr.AntennaPanel([1, 1], polarization='x'))
+        g = p.getGrid()
+        p.populateGrid(g, nr.random.bits(p.getBitSizes(g)[0]))
+        H = ch.getChannelMatrix()
+        F = p.getPrecodingMatrix(H)
+        assert isinstance(F, list)
+        pg = g.precode(F)
+        out[name + '_cfg'] = np.array(repr(dict(seed=seed, numRbs=numRbs, spacing=spacing, layers=layers, prgSize=prg, prbSet=prbs)))
+        out[name + '_H'] = H
+        out[name + '_grid'] = g.grid
+        out[name + '_n_groups'] = np.int64(len(F))
+        for i, (rbs, f) in enumerate(F):
+            out[f'{name}_rbs{i}'] = np.int64(rbs)
+            out[f'{name}_f{i}'] = f
+        out[name + '_precoded'] = pg.grid
+        print('prg', name, 'groups', [list(map(int, r)) for r, _ in F])
+    np.savez_compressed(os.path.join(GOLD, 'prg.npz'), **out)
+
+
 def e2e():
     """Whole slots.  The random stream (bits -> channel construction -> noise) is reproducible from the seed with
     NumPy's PCG64, so only outputs are stored."""
@@ -404,5 +440,6 @@ if __name__ == '__main__':
     harq_loop()
     polar()
     chest()
+    prg()
     e2e()
     print('fixtures written to', GOLD)
