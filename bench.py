@@ -96,7 +96,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=64, help="slots per step per GPU")
+    ap.add_argument('--batch', type=int, default=256, help="slots per step per GPU (15 GB of device buffers at 256)")
     ap.add_argument('--snr', type=float, default=31.0)
     ap.add_argument('--decoder', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-cpu', action='store_true', help="skip the CPU-oracle baseline leg")
