@@ -23,7 +23,7 @@ from .antenna import AntennaElement, AntennaPanel, AntennaArray  # noqa: F401
 from .pdsch import PDSCH, DMRS, PTRS                           # noqa: F401
 from .random import random                                     # noqa: F401
 from .snrhelper import SnrScheduler                            # noqa: F401
-from .engine import PdschLink                                  # noqa: F401
+from .engine import PdschLink, run_sweep                       # noqa: F401
 
 try:                                                           # polar codec (control channel path)
     from .polar import PolarEncoder, PolarDecoder              # noqa: F401

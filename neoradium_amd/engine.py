@@ -333,3 +333,36 @@ class PdschLink:
                      throughput=100.0 * rx.sum() / max(tx.sum(), 1), bler=100.0 * (tx.sum() - rx.sum()) / max(tx.sum(), 1),
                      meanTries=float(((rx * np.arange(maxTries)).sum() + nto * maxTries) / max(rx.sum() + nto, 1)))
         return stats, state
+
+
+# ------------------------------------------------------------------------------------------------------ sweeps
+def shard_slots(slot0, n_slots, world, rank):
+    """Contiguous share of [slot0, slot0 + n_slots) owned by ``rank`` (slots are independent given their
+    absolute index, so a sweep shards by slot range with no data-path communication)."""
+    per = -(-int(n_slots) // int(world))
+    lo = min(int(n_slots), rank * per)
+    hi = min(int(n_slots), lo + per)
+    return slot0 + lo, hi - lo
+
+
+def run_sweep(link, snrs_db, n_slots, seed=0, batch=64, slot0=0):
+    """BLER sweep over a fixed SNR grid, sharded over the ranks of the default process group (if initialised).
+
+    Every rank simulates its own slot range of every SNR point (``link.run`` in throughput mode: the device generator is
+    keyed by (seed, absolute slot), so the union of the ranks' results does not depend on the number of ranks), then
+    ONE all-reduce (RCCL over xGMI with backend 'nccl') sums the int64 [nSnr, 4] counter table
+    (blockErrors, totalBlocks, bitErrors, totalBits) -- the path's only collective.  Returns the table as NumPy."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    lo, cnt = shard_slots(slot0, n_slots, world, rank)
+    table = torch.zeros((len(snrs_db), 4), dtype=torch.int64, device=link.dev)
+    for i, snr in enumerate(snrs_db):
+        done = 0
+        while done < cnt:
+            nb = min(int(batch), cnt - done)
+            link.run(lo + done, nb, float(snr), seed=seed, counters=table[i])
+            done += nb
+    if on and world > 1:
+        dist.all_reduce(table)
+    return table.cpu().numpy()

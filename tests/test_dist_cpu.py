@@ -54,3 +54,48 @@ def test_counter_allreduce_world2():
     want = [int(errs.sum() * 3), len(slots) * 72, int(errs.sum() * 1000), len(slots) * 606504]
     for rank, counters, tmax in res:
         assert counters == want and tmax == 0.75
+
+
+class _StubLink:
+    """Stands in for PdschLink on the host: per-slot outcomes are a pure function of (absolute slot, SNR, seed), which is
+    what the device generator's keying guarantees for the real engine."""
+    dev = torch.device('cpu')
+
+    def run(self, slot0, n_slots, snr_db, seed=0, counters=None):
+        slots = np.arange(slot0, slot0 + n_slots)
+        errs = ((slots * 2654435761 + seed * 97 + int(snr_db * 10) * 31) % 101 < 40 - int(snr_db)).astype(np.int64)
+        counters += torch.tensor([errs.sum() * 2, n_slots * 16, errs.sum() * 500, n_slots * 129128], dtype=torch.int64)
+        return counters
+
+
+def _sweep_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from neoradium_amd.engine import run_sweep, shard_slots
+    table = run_sweep(_StubLink(), [8.0, 10.5, 13.0], 37, seed=5, batch=8, slot0=100)
+    q.put((rank, table.tolist(), shard_slots(100, 37, world, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sweep_world2_equals_single_process():
+    """neoradium_amd.run_sweep (slot ranges per rank, one all-reduce of the [nSnr, 4] table) with two gloo ranks gives
+    every rank the table a single process computes; the ranks' slot ranges are disjoint and cover the sweep."""
+    sys.path.insert(0, ROOT)
+    from neoradium_amd.engine import run_sweep
+    want = run_sweep(_StubLink(), [8.0, 10.5, 13.0], 37, seed=5, batch=8, slot0=100).tolist()
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 77) % 500
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[2] for r in res] == [(100, 19), (119, 18)]
+    for _, table, _ in res:
+        assert table == want

@@ -359,3 +359,17 @@ def test_end_to_end_notebook_flow_with_polar_interpolation(dev):
     llr = p.getLLRsFromGrid(eq, p.getReIndexes(grid, "PDSCH"), sc)[0]
     out, crc = dec.checkCrcAndMerge(dec.decode(dec.recoverRate(llr, tbs[0]), numIter=10))
     assert np.all(crc) and np.array_equal(out[:-24], tb)
+
+
+def test_run_sweep_equals_per_point_runs(dev):
+    """run_sweep (the multi-GPU entry: slot ranges per rank + one all-reduce; one rank here) = link.run per SNR point."""
+    import neoradium_amd as nr
+    cfg = dict(seed=5, numRbs=24, spacing=30, mod='64QAM', layers=2, dm=dict(configType=1, additionalPos=1),
+               chan=('cdl', 'D', 30, 5, [1, 2], [1, 1]), slot0=0)
+    car, bwp, p, ch = _slot(nr, cfg)
+    link = nr.PdschLink(p, ch, 0.5, numIter=10, decoder="f32")
+    snrs = [14.0, 17.0, 20.0]
+    table = nr.run_sweep(link, snrs, 7, seed=9, batch=3, slot0=4)
+    for i, snr in enumerate(snrs):
+        assert np.array_equal(table[i], link.run(4, 7, snr, seed=9).cpu().numpy())
+    assert table[0][0] >= table[2][0] and table[:, 1].tolist() == [7 * link.cfg.C] * 3
