@@ -154,6 +154,74 @@ mmse_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ hf, int64_t 
   }
 }
 
+// Wide-MIMO fallback (5..8 layers, two-codeword PDSCH; any Nr <= 8): the same Cholesky solve as nrx::mmse_solve with
+// run-time sizes (local arrays, not unrolled).  Not on the throughput path.
+template <typename T>
+__global__ void __launch_bounds__(64)
+mmse_wide_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ hf, int64_t h_stride,
+                 const T* __restrict__ noise_var, int nv_stride, int nr, int nl, int lk, cx<T>* __restrict__ eq,
+                 T* __restrict__ scale, int n_batch) {
+  constexpr int M8 = 8;
+  const int64_t total = (int64_t)n_batch * lk;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / lk), i = (int)(g - (int64_t)b * lk);
+    double nv = (double)noise_var[(size_t)b * nv_stride];
+    nv = nv > 1e-8 ? nv : 1e-8;  // grid.py:676
+    const cx<T>* hb = hf + (size_t)b * h_stride + (size_t)i * nr * nl;
+    cd A[M8][M8], Lm[M8][M8], Mi[M8][M8], z[M8], u[M8];
+    double dinv[M8];
+    for (int p = 0; p < nl; ++p) {
+      cd zz(0, 0);
+      for (int r = 0; r < nr; ++r) nrx::cmacc(zz, cd(hb[r * nl + p]), cd(rx[((size_t)b * nr + r) * lk + i]));
+      z[p] = zz;
+      for (int q = 0; q <= p; ++q) {
+        cd a(0, 0);
+        for (int r = 0; r < nr; ++r) nrx::cmacc(a, cd(hb[r * nl + q]), cd(hb[r * nl + p]));
+        A[p][q] = nrx::conj(a);
+      }
+      A[p][p].re += nv;
+    }
+    for (int j = 0; j < nl; ++j) {
+      double d = A[j][j].re;
+      for (int k = 0; k < j; ++k) d -= nrx::norm2(Lm[j][k]);
+      const double ljj = sqrt(d);
+      dinv[j] = 1.0 / ljj;
+      Lm[j][j] = cd(ljj, 0);
+      for (int r = j + 1; r < nl; ++r) {
+        cd s2 = A[r][j];
+        for (int k = 0; k < j; ++k) {
+          s2.re -= Lm[r][k].re * Lm[j][k].re + Lm[r][k].im * Lm[j][k].im;
+          s2.im -= Lm[r][k].im * Lm[j][k].re - Lm[r][k].re * Lm[j][k].im;
+        }
+        Lm[r][j] = s2 * dinv[j];
+      }
+    }
+    for (int c = 0; c < nl; ++c) {
+      Mi[c][c] = cd(dinv[c], 0);
+      for (int r = c + 1; r < nl; ++r) {
+        cd s2(0, 0);
+        for (int k = c; k < r; ++k) nrx::cmac(s2, Lm[r][k], Mi[k][c]);
+        Mi[r][c] = cd(-s2.re * dinv[r], -s2.im * dinv[r]);
+      }
+    }
+    for (int r = 0; r < nl; ++r) {
+      cd s2(0, 0);
+      for (int c = 0; c <= r; ++c) nrx::cmac(s2, Mi[r][c], z[c]);
+      u[r] = s2;
+    }
+    for (int p = 0; p < nl; ++p) {
+      cd s2(0, 0);
+      double dg = 0;
+      for (int k = p; k < nl; ++k) {
+        nrx::cmacc(s2, Mi[k][p], u[k]);
+        dg += nrx::norm2(Mi[k][p]);
+      }
+      eq[((size_t)b * nl + p) * lk + i] = cx<T>(s2);
+      scale[((size_t)b * nl + p) * lk + i] = (T)(1.0 / dg);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------- complex variance
 // np.var of a complex array = mean |x - mean(x)|^2 (grid.py:1046, waveform.py:117): per batch item, float64,
 // two-level reduction: (sum x, sum |x|^2) per workgroup into acc[b][workgroup][3], summed in workgroup order by
@@ -310,8 +378,13 @@ int32_t mmse_entry(const void* rx, const void* hf, int64_t h_stride, const void*
     case 8: rc = mmse_dispatch_nl<T, 8>(nl, grid, st, (const cx<T>*)rx, (const cx<T>*)hf, h_stride, (const T*)noise_var, nv_stride, lk, (cx<T>*)eq, (T*)scale, n_batch); break;
     default: break;
   }
+  if (rc == NRX_E_UNSUPPORTED && nr <= 8 && nl <= 8) {   // 5..8 layers (or an odd antenna count): run-time sizes
+    hipLaunchKernelGGL(mmse_wide_kernel<T>, dim3(nrx::stream_grid((long)lk * n_batch, 64)), dim3(64), 0, st, (const cx<T>*)rx,
+                       (const cx<T>*)hf, h_stride, (const T*)noise_var, nv_stride, nr, nl, lk, (cx<T>*)eq, (T*)scale, n_batch);
+    rc = NRX_OK;
+  }
   NRX_REQUIRE(rc != NRX_E_UNSUPPORTED, NRX_E_UNSUPPORTED,
-              "nrx_mmse_equalize: (Nr=%d, layers=%d) not built (Nr in {1,2,4,8}, layers 1..4)", nr, nl);
+              "nrx_mmse_equalize: (Nr=%d, layers=%d) not built (at most 8 x 8)", nr, nl);
   NRX_CHECK_LAUNCH("nrx_mmse_equalize");
   return rc;
 }

@@ -340,6 +340,50 @@ def e2e():
     one('cdl_fail_td_ls', 77, 25, 15, '16QAM', 2, 0.6, 1, ('cdl', 'D', 100, 30, [1, 2], [1, 1]), dm1, 8, 6.0, False, False, 0)
 
 
+def e2e_2cw():
+    """A two-codeword slot (6 layers = 3 + 3, different modulation and rate per codeword, 8x8 CDL-C, double-symbol DMRS for
+    6 ports): frequency-domain channel + noise, DMRS-LS estimate, MMSE, per-codeword LLRs / decode / CRC."""
+    seed, numRbs, spacing, layers = 31, 24, 30, 6
+    mods, rates, numIter, snr = ['16QAM', '64QAM'], [0.45, 0.55], 10, 28.0
+    dm = dict(configType=1, additionalPos=1, symbols=2)
+    nr.random.setSeed(seed)
+    car = nr.Carrier(numRbs=numRbs, spacing=spacing)
+    bwp = car.curBwp
+    p = nr.PDSCH(bwp, numLayers=layers, nID=car.cellId, modulation=mods)
+    p.setDMRS(**dm)
+    ch = nr.CdlChannel(bwp, 'C', delaySpread=100, carrierFreq=4e9, dopplerShift=5,
+                       txAntenna=nr.AntennaPanel([2, 2], polarization='x'), rxAntenna=nr.AntennaPanel([2, 2], polarization='x'))
+    g = p.getGrid()
+    tbs = p.getTxBlockSize(rates)
+    nb = p.getBitSizes(g)
+    cw_layers = [layers // 2, layers - layers // 2]
+    encs = [nr.LdpcEncoder(baseGraphNo=1, modulation=mods[c], txLayers=cw_layers[c], targetRate=rates[c]) for c in range(2)]
+    tbl = [nr.random.bits(tbs[c]) for c in range(2)]
+    rm = [encs[c].getRateMatchedCodeBlocks(tbl[c], nb[c]) for c in range(2)]
+    p.populateGrid(g, rm)
+    idx = p.getReIndexes(g, "PDSCH")
+    H = ch.getChannelMatrix()
+    F = p.getPrecodingMatrix(H)
+    rx = g.precode(F).applyChannel(H).addNoise(snrDb=snr, useRxPower=True)
+    hest = rx.estimateChannelLS(p.dmrs, polarInt=False, kernel='linear')[0]
+    eq, sc = rx.equalize(hest)
+    llrs = p.getLLRsFromGrid(eq, idx, sc)
+    out = dict(cfg=np.array(repr(dict(seed=seed, numRbs=numRbs, spacing=spacing, layers=layers, mods=mods, rates=rates, dm=dm,
+                                      numIter=numIter, snr=snr))),
+               tbs=np.int64(tbs), G=np.int64(nb), F=F, noise_var=np.float64(rx.noiseVar), eq_sample=eq.grid[:, ::3, ::5],
+               hest_sample=hest[::3, ::5])
+    for c in range(2):
+        dec = encs[c].getDecoder()
+        db = dec.decode(dec.recoverRate(llrs[c], tbs[c]), numIter=numIter)
+        tb_out, crc = dec.checkCrcAndMerge(db)
+        out[f'tb{c}'] = np.packbits(tbl[c].astype(np.uint8))
+        out[f'llr{c}'] = llrs[c]
+        out[f'decoded{c}'] = np.packbits(np.uint8(tb_out))
+        out[f'crc{c}'] = np.asarray(crc, bool)
+        print('2cw', c, 'TBS', tbs[c], 'G', nb[c], 'crc', np.asarray(crc), 'bit errors', int(np.abs(tb_out[:-24] - tbl[c]).sum()))
+    np.savez_compressed(os.path.join(GOLD, 'e2e_2cw.npz'), **out)
+
+
 def harq_loop():
     """Playground/HARQ/Harq.ipynb cell 7 with both random streams seeded (60 transmissions, Eb/No 0.5 dB)."""
     from neoradium.utils import toLinear
@@ -441,5 +485,6 @@ if __name__ == '__main__':
     polar()
     chest()
     prg()
+    e2e_2cw()
     e2e()
     print('fixtures written to', GOLD)
