@@ -27,8 +27,6 @@ from .waveform import Waveform
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
                  decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False):
-        if pdsch.numCW != 1:
-            raise NotImplementedError("PdschLink: two-codeword PDSCH (more than 4 layers) is not built")
         if pdsch.dmrs is None:
             raise ValueError("PdschLink: the PDSCH needs a DMRS configuration (pdsch.setDMRS)")
         if chanEst not in ("LS", "Perfect"):
@@ -51,6 +49,7 @@ class PdschLink:
             raise ValueError("firstPassIter must be between 1 and numIter-1")
         self.codeRate = codeRate
         self.nl = pdsch.numLayers
+        self.numCW = pdsch.numCW
         self.qm = pdsch.modems[0].qm
         self.nr, self.nt = channel.nrNt
         self.K, self.L, self.nfft = 12 * bwp.numRbs, bwp.symbolsPerSlot, bwp.nFFT
@@ -68,7 +67,8 @@ class PdschLink:
             pil.append(p)
             if idx0 is None:
                 idx0 = tuple(i.copy() for i in pdsch.dataIndices)
-                self.tbs = int(pdsch.getTxBlockSize(codeRate)[0])
+                tbs_all = [int(v) for v in pdsch.getTxBlockSize(codeRate)]
+                self.tbs = tbs_all[0]
                 self.port_ks, self.dmrs_syms = ks, [int(v) for v in ds]
             else:
                 assert all(np.array_equal(a, b) for a, b in zip(idx0, pdsch.dataIndices))
@@ -79,12 +79,21 @@ class PdschLink:
         self.port_ks_d = D(np.ascontiguousarray(np.int32(self.port_ks)))
         assert 0 <= int(np.min(self.port_ks)) and int(np.max(self.port_ks)) < self.K
         self.n_tg = len(self.dmrs_syms) // self.l_cdm                   # DMRS time groups
-        n_re = len(idx0[0])
-        self.G = n_re * self.qm
-        lm = pdsch.getLayerMapIndexes(idx0, [n_re])[0]
-        self.re_index = D(np.int32((np.int64(lm[0]) * self.L + lm[1]) * self.K + lm[2]))
-        self.scr = D(pdsch._scrambling(0, self.G))
-        self.cfg = _lib.ldpc_config(baseGraphNo, self.tbs + 24)
+        # ---- per codeword (TS 38.211 7.3.1.3: one codeword up to 4 layers, two above: floor(v/2) + the rest): transport
+        # block size, LDPC configuration, modulation order, layers, coded bits, layer-mapped RE index, scrambling
+        n_res = pdsch.getNumREsFromIndexes(idx0)
+        lms = pdsch.getLayerMapIndexes(idx0, n_res)
+        cw_layers = [self.nl] if self.numCW == 1 else [self.nl // 2, self.nl - self.nl // 2]
+        self.cw = []
+        for q in range(self.numCW):
+            qm = pdsch.modems[q].qm
+            G = n_res[q] * qm
+            lm = lms[q]
+            self.cw.append(dict(tbs=tbs_all[q], qm=qm, nl=cw_layers[q], G=G, cfg=_lib.ldpc_config(baseGraphNo, tbs_all[q] + 24),
+                                re_index=D(np.int32((np.int64(lm[0]) * self.L + lm[1]) * self.K + lm[2])),
+                                scr=D(pdsch._scrambling(q, G))))
+        c0 = self.cw[0]     # (single-codeword attribute names kept: bench.py, the oracle harness and the tests use them)
+        self.G, self.re_index, self.scr, self.cfg = c0['G'], c0['re_index'], c0['scr'], c0['cfg']
         self.first_prb = int(pdsch.prbSet[0])
         # ---- precoder groups exactly as PDSCH.getPrecodingMatrix forms them (pdsch.py:1142-1163: a group is closed when
         # the FIRST PRB of the next group arrives and the last one is never closed).  One group covering a full-band
@@ -165,8 +174,8 @@ class PdschLink:
 
         Throughput mode (default): transport blocks and noise come from the counter-based device generator keyed by
         (seed, slot index), so results do not depend on batch size or on how slots are sharded over GPUs.
-        Parity mode: pass ``tb_bits`` (n_slots, TBS) and ``noise`` (standard-normal complex pairs, shape of the
-        noisy signal) to reproduce a host NumPy PCG64 stream."""
+        Parity mode: pass ``tb_bits`` (n_slots, TBS) -- a list of two such tensors for a two-codeword PDSCH -- and
+        ``noise`` (standard-normal complex pairs, shape of the noisy signal) to reproduce a host NumPy PCG64 stream."""
         dev = self.dev
         if counters is None:
             counters = torch.zeros(4, dtype=torch.int64, device=dev)
@@ -179,8 +188,13 @@ class PdschLink:
         det = []
         for _, sel in geoms.items():
             sel = np.asarray(sel)
-            d = self._run_group(slots[sel], snr_db, seed, None if tb_bits is None else tb_bits[sel],
-                                None if noise is None else noise[sel], counters, details)
+            if tb_bits is None:
+                tbs_sel = None
+            elif isinstance(tb_bits, (list, tuple)):            # two codewords: one (n_slots, TBS_q) tensor per codeword
+                tbs_sel = [t[sel] for t in tb_bits]
+            else:
+                tbs_sel = tb_bits[sel]
+            d = self._run_group(slots[sel], snr_db, seed, tbs_sel, None if noise is None else noise[sel], counters, details)
             if details:
                 det.append((sel, d))
         return (counters, det) if details else counters
@@ -196,12 +210,20 @@ class PdschLink:
             if np.isscalar(snr_db) else D(10.0 ** (np.float64(snr_db) / 10.0))
 
         # ---- Tx
-        tb = ops.random_bits(n, self.tbs, seed, dev, stream_id=1, batch_offset=int(slots[0])) if tb_bits is None \
-            else tb_bits.to(dev).to(torch.uint8).contiguous()
-        coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
-        bits = ops.ldpc_rate_match(coded, cfg, self.G, self.nl, self.qm, rv=0 if harq is None else harq[0])
+        if self.numCW > 1 and harq is not None:
+            raise NotImplementedError("run_harq: two-codeword PDSCH is not built")
         grid = self.templates.index_select(0, sif)                              # DMRS-filled (n, Nl, L, K)
-        ops.qam_map(bits, self.qm, scr=self.scr, re_index=self.re_index, out=grid)
+        tbs_in = []
+        for q, cw in enumerate(self.cw):
+            if tb_bits is None:     # stream ids: 1 = first codeword (as before), 3 = second; 2 is the noise
+                tb = ops.random_bits(n, cw['tbs'], seed, dev, stream_id=1 + 2 * q, batch_offset=int(slots[0]))
+            else:
+                tb = (tb_bits[q] if self.numCW > 1 else tb_bits).to(dev).to(torch.uint8).contiguous()
+            tbs_in.append(tb)
+            coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'])
+            bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[0])
+            ops.qam_map(bits, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], out=grid)
+        tb = tbs_in[0]
 
         # ---- channel state of each slot
         times = D(self.gain_times(slots))
@@ -248,34 +270,41 @@ class PdschLink:
             hest = ops.chest_ls_ex(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,
                                    pil_set=sif.to(torch.int32), polar=True)
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
-        elif details or self.n_tg > 2:
+        elif details or self.n_tg > 2 or self.nl > 4:
             hest = ops.chest_ls(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,
                                 pil_set=sif.to(torch.int32))
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
         else:       # estimate + equalise fused: the (L, K, Nr, Nl) estimate is never written out
             eq, sc = ops.chest_ls_mmse(rxg, self.pilots, self.port_ks_d, self.dmrs_syms, nv, l_cdm=self.l_cdm,
                                        k_cdm=self.k_cdm, pil_set=sif.to(torch.int32))
-        llr = ops.qam_demap(eq, nv, self.qm, scr=self.scr, re_index=self.re_index, scales=sc, nv_floor=1e-10,
-                            llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
-        if harq is None:
-            rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm)
-        else:
-            rr = ops.ldpc_rate_recover(llr, cfg, self.nl, self.qm, rv=harq[0], circ=harq[1], reset=harq[2])
-        if self.firstPassIter is None:
-            dec = ops.ldpc_decode(rr, cfg, self.numIter)
-            tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
-        else:
-            dec = ops.ldpc_decode(rr, cfg, self.firstPassIter)
-            _, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb=False)
-            fail = (cb_ok.reshape(-1) == 0).nonzero().reshape(-1)              # host read: how many blocks go on
-            if fail.numel():
-                dec.index_copy_(0, fail, ops.ldpc_decode(rr.index_select(0, fail), cfg, self.numIter))
-            tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
-        if counters is not None:
-            ops.count_errors(cb_ok, tb_out, tb, counters)
+        per_cw = []
+        for q, cw in enumerate(self.cw):
+            ccfg = cw['cfg']
+            llr = ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
+                                llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
+            if harq is None:
+                rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'])
+            else:
+                rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'], rv=harq[0], circ=harq[1], reset=harq[2])
+            if self.firstPassIter is None:
+                dec = ops.ldpc_decode(rr, ccfg, self.numIter)
+                tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb_crc=False)
+            else:
+                dec = ops.ldpc_decode(rr, ccfg, self.firstPassIter)
+                _, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb=False)
+                fail = (cb_ok.reshape(-1) == 0).nonzero().reshape(-1)          # host read: how many blocks go on
+                if fail.numel():
+                    dec.index_copy_(0, fail, ops.ldpc_decode(rr.index_select(0, fail), ccfg, self.numIter))
+                tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb_crc=False)
+            if counters is not None:
+                ops.count_errors(cb_ok, tb_out, tbs_in[q], counters)
+            per_cw.append(dict(tb=tbs_in[q], cb_ok=cb_ok, tb_out=tb_out, llr=llr))
+        cb_ok = per_cw[0]['cb_ok']
         if details:
-            return dict(tb=tb, cb_ok=cb_ok, tb_out=tb_out, llr=llr, eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv,
-                        sigma=sigma, grid=grid)
+            d = dict(per_cw[0], eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv, sigma=sigma, grid=grid)
+            if self.numCW > 1:
+                d['cw'] = per_cw
+            return d
         return dict(cb_ok=cb_ok) if harq is not None else None
 
     # ----------------------------------------------------------------------------------------------- HARQ
