@@ -3,7 +3,8 @@
 // Same algorithm and reference quirks as nrx_ldpc_dec.hip (reference ldpc.py:1495-1581); what changes is the
 // data movement, designed around the CDNA4 issue model (a SIMD issues one VALU instruction every 2 cycles only
 // when >= 2 waves feed it; a lone wave gets one every 4):
-//   * two code blocks (2 x 6 wave64) per CU: <= 168 VGPRs, 40 KB LDS per workgroup;
+//   * two code blocks (2 x 6 wave64) per CU in ONE workgroup: <= 168 VGPRs (3 waves per SIMD), 157.5 KB of LDS
+//     (26 core columns x 384 floats x 2 ping-pong buffers x 2 code blocks);
 //   * ROTATED COLUMN STORAGE: every core column sits in LDS rotated by the shift of the layer that touched it
 //     last, so a layer WRITES at its own lane index (address = lane*4 + immediate) and READS at lane + delta,
 //     delta = (shift_this - shift_previous) mod Zc precomputed per (Zc, edge) in constant memory; no address is
