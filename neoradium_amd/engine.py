@@ -26,7 +26,7 @@ from .waveform import Waveform
 
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
-                 decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False):
+                 decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True):
         if pdsch.dmrs is None:
             raise ValueError("PdschLink: the PDSCH needs a DMRS configuration (pdsch.setDMRS)")
         if chanEst not in ("LS", "Perfect"):
@@ -40,6 +40,7 @@ class PdschLink:
         self.freqDomain, self.chanEst, self.decoder = freqDomain, chanEst, decoder
         self.numIter = int(numIter)
         self.polarInt = bool(polarInt)        # estimateChannelLS(polarInt=True, kernel='linear') of PDSCH-endToEnd.ipynb
+        self.useMax = bool(useMax)            # getLLRsFromGrid(useMax=...): max-log (default) or exact log-sum-exp LLRs
         # Opt-in two-pass decoding (NOT the reference's schedule, off by default): every code block is first decoded
         # with `firstPassIter` iterations; the blocks whose CRC fails are then decoded again FROM SCRATCH with the full
         # `numIter` iterations, so a failing block gets exactly the reference's result and a passing block is the
@@ -281,7 +282,7 @@ class PdschLink:
         for q, cw in enumerate(self.cw):
             ccfg = cw['cfg']
             llr = ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
-                                llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
+                                exact=not self.useMax, llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
             if harq is None:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'])
             else:

@@ -477,3 +477,38 @@ def test_engine_two_codewords_matches_class_surface(dev):
     a = link.run(5, 4, snr, seed=3).cpu().numpy()
     b = (link.run(5, 1, snr, seed=3) + link.run(6, 3, snr, seed=3)).cpu().numpy()
     assert np.array_equal(a, b) and a[1] == 4 * sum(cw['cfg'].C for cw in link.cw)
+
+
+def test_engine_exact_llrs_match_class_surface(dev):
+    """PdschLink(useMax=False): log-sum-exp LLRs (modulation.py:191-204, exponent clip at +-700) like
+    PDSCH.getLLRsFromGrid(useMax=False) of the class surface, which the modem tests pin against the reference."""
+    import torch
+    import neoradium_amd as nr
+    from neoradium_amd._dev import D
+    cfg = dict(seed=19, numRbs=25, spacing=15, mod='64QAM', layers=2, dm=dict(configType=1, additionalPos=1),
+               chan=('cdl', 'C', 100, 30, [1, 2], [1, 1]), slot0=0)
+    car, bwp, p, ch = _slot(nr, cfg)
+    link = nr.PdschLink(p, ch, 0.5, baseGraphNo=1, numIter=5, freqDomain=True, chanEst="Perfect", decoder="f64", useMax=False)
+    rng = np.random.default_rng(8)
+    tb = rng.integers(0, 2, (1, link.tbs)).astype(np.uint8)
+    z = rng.standard_normal((1, link.nr, link.L, link.K, 2))
+    _, det = link.run(0, 1, 16.0, tb_bits=torch.from_numpy(tb), noise=D(z[..., 0] + 1j * z[..., 1]), details=True)
+    d = det[0][1]
+
+    class FixedNoise:
+        def __init__(self, zz): self.zz = zz
+        def normal(self, loc, scale, shape): return self.zz
+
+    enc = nr.LdpcEncoder(baseGraphNo=1, modulation=cfg['mod'], txLayers=cfg['layers'], targetRate=0.5)
+    grid = p.getGrid()
+    p.populateGrid(grid, enc.getRateMatchedCodeBlocks(tb[0].astype(np.int8), p.getBitSizes(grid)[0]))
+    H = ch.getChannelMatrix()
+    F = d['F'][0].cpu().numpy()
+    rx = grid.precode(F).applyChannel(H).addNoise(snrDb=16.0, useRxPower=True, ranGen=FixedNoise(z[0]))
+    eq, sc = rx.equalize(H @ F[None, ...])
+    idx = p.getReIndexes(grid, "PDSCH")
+    exact = p.getLLRsFromGrid(eq, idx, sc, useMax=False)[0]
+    maxlog = p.getLLRsFromGrid(eq, idx, sc, useMax=True)[0]
+    got = d['llr'][0].cpu().numpy()
+    assert np.abs(got - exact).max() <= 1e-9 * np.abs(exact).max()
+    assert np.abs(exact - maxlog).max() > 1e-3 * np.abs(exact).max()      # the two demappers really differ here

@@ -4,7 +4,8 @@ transport blocks and noise draws, slot by slot.  Writes profiles/r1_bler_overlay
 
     python tests/tools/bler_overlay.py [--slots 24] [--out profiles/r1_bler_overlay.json]
 
-Configurations: BASELINE cfg1 (25 PRB, QPSK, BG2, SISO TDL-A 30 ns) and a 2x2 CDL-C 16-QAM case; both time-domain
+Configurations: BASELINE cfg1 (25 PRB, QPSK, BG2, SISO TDL-A 30 ns), a 2x2 CDL-C 16-QAM case and (--configs metric) the
+bench configuration itself (273 PRB, 7 s of CPU oracle per slot: use --slots 6); all time-domain
 channel + DMRS-LS + MMSE, 20 iterations.  Per SNR point: block errors of both paths and whether every per-slot CRC
 vector was identical, for the engine's f32 (throughput) and f64 (bit-exact) decoders."""
 import argparse
@@ -30,6 +31,9 @@ def build(nr, which, decoder):
         ch = nr.TdlChannel(bwp, 'A', delaySpread=30, carrierFreq=4e9, dopplerShift=5)
         return nr.PdschLink(p, ch, 0.35, baseGraphNo=2, numIter=20, freqDomain=False, chanEst="LS", decoder=decoder), \
             [0.0, 0.4, 0.8, 1.2, 1.6, 2.0]
+    if which == 'metric':        # the bench configuration: 273 PRB, 64-QAM, 4 layers, 4x4 CDL-C, BG1, 50 iterations
+        import bench
+        return bench.build_link(nr, decoder=decoder), [29.0, 32.0, 35.0]
     car = nr.Carrier(numRbs=51, spacing=30)
     bwp = car.curBwp
     p = nr.PDSCH(bwp, numLayers=2, nID=car.cellId, modulation='16QAM')
@@ -45,12 +49,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--slots', type=int, default=24)
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r1_bler_overlay.json'))
+    ap.add_argument('--configs', default='cfg1,cdl_2x2_16qam', help="comma list of cfg1, cdl_2x2_16qam, metric")
     a = ap.parse_args()
     import neoradium_amd as nr
     from neoradium_amd._dev import D
     from oracle import link as olink
     res = {}
-    for which in ('cfg1', 'cdl_2x2_16qam'):
+    for which in a.configs.split(','):
         link, snrs = build(nr, which, 'f32')
         link64, _ = build(nr, which, 'f64')
         st = olink.static_from_link(link)
