@@ -175,7 +175,12 @@ def main():
                          "avg_launch_ms": dec_ms, "launch_share_of_step": dec_ms / (dt / K * 1e3),
                          "note": "decoder re-uses its LDS/VGPR-resident working set 50x: it is VALU/LDS-issue bound, "
                                  "HBM only at entry/exit (SURVEY 8d)",
-                         "edge_visits_per_s": edge_visits / (dec_ms * 1e-3)},
+                         "edge_visits_per_s": edge_visits / (dec_ms * 1e-3),
+                         # what actually bounds this kernel: VALU issue.  42.9 SIMD cycles per wave-edge for
+                         # its instruction mix by the measured gfx950 issue-rate table (profiles/r1_valu_issue_rates.txt)
+                         # => 1024 SIMDs x 64 lanes x 2.4 GHz / 42.9 edge-visits/s if nothing but the per-edge work ran
+                         "valu_issue": {"bound_edge_visits_per_s": 1024 * 64 * 2.4e9 / 42.9,
+                                        "frac": edge_visits / (dec_ms * 1e-3) / (1024 * 64 * 2.4e9 / 42.9)}},
         }
         if args.decoder == 'f32' and not args.no_exact and world == 1:
             # the same step with the float64 decoder (the reference's arithmetic, hard bits identical to the NumPy path)
