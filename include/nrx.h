@@ -124,6 +124,19 @@ int32_t nrx_ldpc_decode_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg*
                             int32_t out_cols, uint8_t* hard_out, double* belief_out, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* The same decoder restricted to the first n_rows rows of the base graph (4 <= n_rows <= 46 | 42), hard decisions of
+ * the K information bits.  PRECONDITION (caller): the extension (degree-1 parity) column of every dropped row carries
+ * all-zero LLRs in every code block -- i.e. that parity was punctured by rate matching and never received (first
+ * transmission: rows >= ceil((F + E_max) / Zc) - 20 for E_max > K - 2Zc - F; ldpc.py:1093-1159, 1330-1418).  Such a row
+ * has min1 = 0 at its extension edge, so ldpc.py:1556-1576 sends +-0 to all its other columns: the posteriors of the
+ * core columns -- and with them these outputs -- are bit-identical to running all rows, in float32 and float64
+ * (tests/test_gpu_ldpc.py::test_punctured_rows_are_exact_no_ops).  NR LDPC is built for exactly this (a raptor-like
+ * extension: each higher-rate code is the sub-matrix of the transmitted parity), the reference just does not use it. */
+int32_t nrx_ldpc_decode_rows_f32(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
+                                 uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream);
+int32_t nrx_ldpc_decode_rows_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
+                                 uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ldpc.py:1584-1619 checkCrcAndMerge (+ the TB-level checkCrc('24A') the harness applies).
  * dec: (n_tb*C) x K hard bits.  tb_out (nullable): n_tb x M bits, M = C*(cb_len - 24) for C>1 (>= B: the TB incl.
  * its CRC24A followed by the segmentation zero padding, exactly what the reference returns), M = B for C==1.

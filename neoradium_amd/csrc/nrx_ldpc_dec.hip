@@ -133,7 +133,7 @@ template <typename T> struct ExactWs {
 template <typename T, int BG, bool EXACT>
 __global__ void __launch_bounds__(ZMAX, EXACT ? 3 : 1)   // f64: state in the workspace, two code blocks per CU (LDS 2 x 80 KB)
 ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out_cols, int n_cols_in,
-                uint8_t* __restrict__ hard, T* __restrict__ belief, char* __restrict__ ws, int tab_off) {
+                uint8_t* __restrict__ hard, T* __restrict__ belief, char* __restrict__ ws, int tab_off, int n_rows) {
   using G = BgT<BG>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* P = (T*)smem;  // [CORE][ZMAX]
@@ -212,6 +212,10 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
         constexpr int D = G::row_start(L + 1) - E0;
         constexpr int Ln = (L + 1) % G::ROWS;
         constexpr bool NEXT_EXT = G::col(G::row_start(Ln + 1) - 1) >= G::CORE;
+        // rows >= n_rows are skipped (kernel argument, uniform): the caller guarantees that their extension columns carry
+        // all-zero LLRs (punctured parity), and such a row sends +-0 to every core column -- see nrx_ldpc_decode_rows_*
+        if (L >= n_rows) return;
+        const bool last_row = L + 1 == n_rows;   // the next active layer is layer 0 of the next iteration
         // Opaque copies: the (z+shift) mod Zc addresses and the kernarg shift loads are invariant over the
         // iteration loop; without this the compiler hoists all ~300 of them and spills.
         int zz = z;
@@ -225,9 +229,9 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
         const uint32_t zo = (uint32_t)zz * (uint32_t)sizeof(T);
         const T cm1 = pf_m1, cm2 = pf_m2, cur_rx = pf_rx;
         if constexpr (EXACT) {
-          pf_m1 = *wsL(wb, W::off_m1(R, Ln), zo);
-          pf_m2 = *wsL(wb, W::off_m2(R, Ln), zo);
-          if constexpr (NEXT_EXT) pf_rx = *wsL(wb, W::off_rext(R, Ln), zo);
+          pf_m1 = *wsL(wb, last_row ? W::off_m1(R, 0) : W::off_m1(R, Ln), zo);
+          pf_m2 = *wsL(wb, last_row ? W::off_m2(R, 0) : W::off_m2(R, Ln), zo);
+          if constexpr (NEXT_EXT) pf_rx = *wsL(wb, W::off_rext(R, Ln), zo);   // (unused by layer 0 when wrapping early)
         }
         if (active) {
           T om1, om2;
@@ -370,7 +374,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
 
 template <typename T, int BG, bool EXACT>
 int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int out_cols, uint8_t* hard, T* belief,
-               void* ws, size_t ws_bytes, hipStream_t st, int tab_off) {
+               void* ws, size_t ws_bytes, hipStream_t st, int tab_off, int n_rows) {
   using G = BgT<BG>;
   const int threads = ((cfg->Zc + 63) / 64) * 64;
   int grid = n_cb < 512 ? n_cb : 512;
@@ -389,19 +393,19 @@ int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int 
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, llr, n_cb, cfg->Zc, n_iter, out_cols, G::COLS - 2,
-                     hard, belief, (char*)ws, tab_off);
+                     hard, belief, (char*)ws, tab_off, n_rows);
   NRX_CHECK_LAUNCH("nrx_ldpc_decode");
   return NRX_OK;
 }
 
 }  // namespace
 int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                    uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec2.hip
+                                    int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec2.hip
 namespace {
 
 template <typename T, bool EXACT>
 int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t out_cols,
-                     uint8_t* hard, T* belief, void* ws, size_t ws_bytes, void* stream) {
+                     uint8_t* hard, T* belief, void* ws, size_t ws_bytes, void* stream, int32_t n_rows = 0) {
   NRX_REQUIRE(llr && cfg, NRX_E_ARG, "nrx_ldpc_decode: NULL llr/cfg");
   NRX_REQUIRE(hard || belief, NRX_E_ARG, "nrx_ldpc_decode: need hard_out or belief_out");
   NRX_REQUIRE(cfg->bg == 1 || cfg->bg == 2, NRX_E_ARG, "nrx_ldpc_decode: bg must be 1|2");
@@ -412,12 +416,17 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
   NRX_REQUIRE(out_cols == cfg->K || out_cols == cols * cfg->Zc, NRX_E_SHAPE,
               "nrx_ldpc_decode: out_cols must be K (%d) or all %d columns", cfg->K, cols * cfg->Zc);
   NRX_REQUIRE(cfg->N == (cols - 2) * cfg->Zc, NRX_E_SHAPE, "nrx_ldpc_decode: cfg->N inconsistent");
+  const int rows_all = cfg->bg == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
+  if (n_rows == 0) n_rows = rows_all;
+  NRX_REQUIRE(n_rows >= 4 && n_rows <= rows_all, NRX_E_ARG, "nrx_ldpc_decode_rows: n_rows must be in [4, %d]", rows_all);
+  NRX_REQUIRE(n_rows == rows_all || out_cols == cfg->K, NRX_E_ARG,
+              "nrx_ldpc_decode_rows: dropping rows is only defined for the K information columns");
   if (n_cb == 0) return NRX_OK;
   if constexpr (!EXACT) {
     // throughput kernel: hard decisions of the K information bits (what the link loop consumes)
     static const bool force_v1 = getenv("NRX_LDPC_V1") != nullptr;
     if (hard && !belief && out_cols == cfg->K && !force_v1)
-      return nrx_ldpc_decode_fast_launch((const float*)llr, n_cb, cfg, n_iter, hard, (hipStream_t)stream);
+      return nrx_ldpc_decode_fast_launch((const float*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream);
   }
   int zi = -1;
   for (int i = 0; i < 51; ++i)
@@ -426,8 +435,8 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
               cfg->Zc, cfg->iLS);
   const int tab = zi * SHIFT_STRIDE;
   hipStream_t st = (hipStream_t)stream;
-  if (cfg->bg == 1) return launch<T, 1, EXACT>(llr, n_cb, cfg, n_iter, out_cols, hard, belief, ws, ws_bytes, st, tab);
-  return launch<T, 2, EXACT>(llr, n_cb, cfg, n_iter, out_cols, hard, belief, ws, ws_bytes, st, tab);
+  if (cfg->bg == 1) return launch<T, 1, EXACT>(llr, n_cb, cfg, n_iter, out_cols, hard, belief, ws, ws_bytes, st, tab, n_rows);
+  return launch<T, 2, EXACT>(llr, n_cb, cfg, n_iter, out_cols, hard, belief, ws, ws_bytes, st, tab, n_rows);
 }
 
 }  // namespace
@@ -448,4 +457,17 @@ extern "C" int32_t nrx_ldpc_decode_f64(const double* llr, int32_t n_cb, const nr
                                        int32_t out_cols, uint8_t* hard_out, double* belief_out, void* ws,
                                        size_t ws_bytes, void* stream) {
   return decode_entry<double, true>(llr, n_cb, cfg, n_iter, out_cols, hard_out, belief_out, ws, ws_bytes, stream);
+}
+
+// Decoding with the first n_rows rows of the base graph only (hard decisions of the K information bits).
+extern "C" int32_t nrx_ldpc_decode_rows_f32(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                            int32_t n_rows, uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream) {
+  NRX_REQUIRE(cfg, NRX_E_ARG, "nrx_ldpc_decode_rows: NULL cfg");
+  return decode_entry<float, false>(llr, n_cb, cfg, n_iter, cfg->K, hard_out, nullptr, ws, ws_bytes, stream, n_rows);
+}
+
+extern "C" int32_t nrx_ldpc_decode_rows_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                            int32_t n_rows, uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream) {
+  NRX_REQUIRE(cfg, NRX_E_ARG, "nrx_ldpc_decode_rows: NULL cfg");
+  return decode_entry<double, true>(llr, n_cb, cfg, n_iter, cfg->K, hard_out, nullptr, ws, ws_bytes, stream, n_rows);
 }

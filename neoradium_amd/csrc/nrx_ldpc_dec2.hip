@@ -60,6 +60,15 @@ template <> struct G<2> {
   static constexpr int shift(int ils, int e) { return kBg2Shift[ils][e]; }
 };
 
+// The first RA rows of a base graph (RA = all rows: the graph itself).  NR LDPC codes are raptor-like: the code of a
+// higher rate is the sub-matrix of the rows whose extension parity was transmitted; a row whose extension column is
+// punctured (all-zero LLRs) sends +-0 to its other columns, so dropping it changes nothing (nrx_ldpc_decode_rows_*).
+template <int BG, int RA> struct GR : G<BG> {
+  static_assert(RA >= 4 && RA <= G<BG>::ROWS, "active rows out of range");
+  static constexpr int ROWS = RA;
+  static constexpr int EDGES = G<BG>::row_start(RA);
+};
+
 // d4[zi][cls][e]: core edge: byte offset 4*((shift_e - rot_prev) mod Zc) with rot_prev = rotation the column was
 // left in by the previous layer that touched it (cls 0: first iteration, columns start unrotated; cls 1: steady
 // state, wraps around from the last layer of the previous iteration).  Extension edge: 4*(shift_e mod Zc).
@@ -104,18 +113,46 @@ __constant__ FastTab kTab2 = kTabC2;
 template <int BG> constexpr int ctab_d4(int zi, int cls, int e) { return BG == 1 ? kTabC1.d4[zi][cls][e] : kTabC2.d4[zi][cls][e]; }
 template <int BG> constexpr int ctab_rho4(int zi, int c) { return BG == 1 ? kTabC1.rho4[zi][c] : kTabC2.rho4[zi][c]; }
 
+struct OneTab {
+  int32_t d4[ESTRIDE];   // steady-state read offsets (cls 1 of FastTab)
+  int32_t rho4[32];
+};
+template <int BG, int RA> constexpr OneTab make_one(int zi) {
+  using B = GR<BG, RA>;
+  OneTab t{};
+  const int z = kZ.z[zi], ils = kZ.ils[zi];
+  int fin[32] = {};
+  for (int e = 0; e < B::EDGES; ++e)
+    if (B::col(e) < B::CORE) fin[B::col(e)] = B::shift(ils, e) % z;
+  for (int c = 0; c < 32; ++c) t.rho4[c] = 4 * fin[c];
+  int rot[32] = {};
+  for (int c = 0; c < 32; ++c) rot[c] = fin[c];
+  for (int e = 0; e < B::EDGES; ++e) {
+    const int s = B::shift(ils, e) % z;
+    const int c = B::col(e);
+    if (c < B::CORE) {
+      t.d4[e] = 4 * (((s - rot[c]) % z + z) % z);
+      rot[c] = s;
+    } else {
+      t.d4[e] = 4 * s;
+    }
+  }
+  return t;
+}
+template <int BG, int RA, int ZI> inline constexpr OneTab kOne = make_one<BG, RA>(ZI < 0 ? 0 : ZI);
+
 // Wrap masks of the specialised kernels: m[w][e] = lanes of wave w (of a code block) whose read of edge e, element
 // (z + delta_e), runs past the end of the column and wraps to (z + delta_e - Zc).  Wave-uniform 64-bit values: the
 // kernel fetches a layer's masks with one scalar load and uses them directly as v_cndmask selectors.
 struct WrapTab {
   uint64_t m[ZMAX / 64][ESTRIDE];
 };
-template <int BG, int ZI> constexpr WrapTab make_wrap() {
+template <int BG, int ZI, int RA = G<BG>::ROWS> constexpr WrapTab make_wrap() {
   WrapTab t{};
   const int zc = kZ.z[ZI];
   for (int w = 0; w < ZMAX / 64; ++w)
-    for (int e = 0; e < G<BG>::EDGES; ++e) {
-      const int d = ctab_d4<BG>(ZI, 1, e) / 4;
+    for (int e = 0; e < GR<BG, RA>::EDGES; ++e) {
+      const int d = kOne<BG, RA, ZI>.d4[e] / 4;
       uint64_t m = 0;
       for (int l = 0; l < 64; ++l)
         if (64 * w + l + d >= zc) m |= 1ull << l;
@@ -150,8 +187,8 @@ __device__ __forceinline__ uint32_t wrap4(uint32_t a4, uint32_t zc4) {  // a4 in
 // (42 for BG1, 38 for BG2) so that ring slot = ordinal mod PFN stays consistent across iterations
 template <int BG> constexpr int pfn() { return BG == 1 ? 3 : 2; }
 
-template <int BG> struct Lay {  // compile-time layer facts
-  using B = G<BG>;
+template <int BG, int RA = G<BG>::ROWS> struct Lay {  // compile-time layer facts (of the first RA rows)
+  using B = GR<BG, RA>;
   static constexpr int deg(int L) { return B::row_start(L + 1) - B::row_start(L); }
   static constexpr bool has_ext(int L) { return B::col(B::row_start(L + 1) - 1) >= B::CORE; }
   static constexpr int ext_col(int L) { return B::col(B::row_start(L + 1) - 1); }
@@ -255,14 +292,15 @@ typedef const int32_t __attribute__((address_space(4))) * ctab_t;
 // NS = code blocks per workgroup.  A 5- or 6-wave workgroup lands 2,2,1,1 on the four SIMDs and, at 168 VGPRs
 // (3 waves per SIMD), the hardware never co-schedules a second one (measured: tools/ubench/occ_test.hip), so a CU
 // would run 1.5 waves per SIMD.  Two code blocks side by side in one 10-/12-wave workgroup fill 3 waves per SIMD.
-template <int BG, int ZI, int NS>
+template <int BG, int ZI, int NS, int RA = G<BG>::ROWS>
 __global__ void __launch_bounds__(ZMAX * NS, 3)
 ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_iter, uint8_t* __restrict__ hard,
                      ctab_t tab0, ctab_t tab1, ctab_t rho4, mtab_t wtab) {
   static_assert(ext_shifts_are_zero<BG>(), "extension columns are expected to be unshifted");
-  using B = G<BG>;
-  using Y = Lay<BG>;
+  using B = GR<BG, RA>;
+  using Y = Lay<BG, RA>;
   constexpr bool SPEC = ZI >= 0;
+  static_assert(SPEC || RA == G<BG>::ROWS, "dropping rows is built for the specialised lifting sizes only");
   constexpr int ZC = SPEC ? kZ.z[SPEC ? ZI : 0] : ZMAX;   // compile-time lifting size (SPEC)
   constexpr int ZS = (ZC + 63) / 64 * 64;                  // column stride in floats (whole waves, see `live`)
   constexpr int BUF = B::CORE * ZS;                        // one buffer of one code block, floats
@@ -309,7 +347,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         // + 0.0f turns an input -0.0 into +0.0 (the reference's sign test is (v < 0))
         if constexpr (SPEC) {
           // stored pre-rotated by the column's end-of-iteration rotation, so iteration 0 uses the steady-state deltas
-          constexpr uint32_t r4 = (uint32_t)ctab_rho4<BG>(SPEC ? ZI : 0, c);
+          constexpr uint32_t r4 = (uint32_t)kOne<BG, RA, ZI>.rho4[c];
           Ps[c * ZS + z] = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + (int)(wrap4(4u * (uint32_t)z + r4, zc4) >> 2)]) + 0.0f;
         } else {
           Ps[c * ZS + z] = (c < 2) ? 0.0f : clip10(in[(c - 2) * zc + z]) + 0.0f;
@@ -350,10 +388,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
 
     for (int it = 0; it < n_iter; ++it) {
       ctab_t tab_it = (SPEC || it != 0) ? tab1 : tab0;
-#ifndef NRX_DEC2_LAYERS
-#define NRX_DEC2_LAYERS B::ROWS
-#endif
-      static_for<NRX_DEC2_LAYERS>([&](auto lc) __attribute__((always_inline)) {
+      static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
         constexpr int E0 = B::row_start(L);
         constexpr int D = Y::deg(L);
@@ -379,7 +414,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             constexpr int col = B::col(E0 + j);
             constexpr uint32_t cof = (uint32_t)((Y::touch_par(L, col) * B::CORE + col) * ZS * 4);   // read buffer
             if constexpr (SPEC) {
-              constexpr uint32_t dl4 = (uint32_t)ctab_d4<BG>(SPEC ? ZI : 0, 1, E0 + j);   // 4 * rotation
+              constexpr uint32_t dl4 = (uint32_t)kOne<BG, RA, ZI>.d4[E0 + j];   // 4 * rotation
               constexpr uint32_t off = cof + dl4;
               const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + delta >= Zc
               if constexpr (off < 65536) t[j] = *(const float*)((const char*)Praw + (wraps ? zbw : zb) + off);
@@ -533,7 +568,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
     if (active) {
       static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        const uint32_t r4 = SPEC ? (uint32_t)ctab_rho4<BG>(SPEC ? ZI : 0, c) : (uint32_t)rho4[c];
+        const uint32_t r4 = SPEC ? (uint32_t)kOne<BG, RA, ZI>.rho4[c] : (uint32_t)rho4[c];
         const uint32_t e4 = wrap4(4u * (uint32_t)z + r4, zc4);
         hard[(size_t)cb * K + c * zc + (e4 >> 2)] = Ps[c * ZS + z] < 0.0f ? 1 : 0;
       });
@@ -551,6 +586,11 @@ constexpr int zindex_c(int zc) {
 __constant__ WrapTab kWrap1_384 = make_wrap<1, zindex_c(384)>();
 __constant__ WrapTab kWrap1_352 = make_wrap<1, zindex_c(352)>();
 __constant__ WrapTab kWrap2_256 = make_wrap<2, zindex_c(256)>();
+// BG1, Zc = 384 with the first 13 / 16 / 22 / 31 rows only (row counts with a whole number of prefetch rings)
+__constant__ WrapTab kWrap1_384_r13 = make_wrap<1, zindex_c(384), 13>();
+__constant__ WrapTab kWrap1_384_r16 = make_wrap<1, zindex_c(384), 16>();
+__constant__ WrapTab kWrap1_384_r22 = make_wrap<1, zindex_c(384), 22>();
+__constant__ WrapTab kWrap1_384_r31 = make_wrap<1, zindex_c(384), 31>();
 
 int zindex(int zc, int ils) {
   for (int i = 0; i < NZ; ++i)
@@ -560,9 +600,11 @@ int zindex(int zc, int ils) {
 
 }  // namespace nrx_dec2
 
-// Called by nrx_ldpc_decode_f32 (nrx_ldpc_dec.hip) for the (hard bits, K columns) case.
+// Called by nrx_ldpc_decode_f32 / nrx_ldpc_decode_rows_f32 (nrx_ldpc_dec.hip) for the (hard bits, K columns) case.
+// n_rows < all rows: the caller guarantees that the dropped rows' extension columns are all-zero (see the header); the
+// smallest built row count >= n_rows runs (extra rows are exact no-ops too).
 int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                    uint8_t* hard, hipStream_t st) {
+                                    int32_t n_rows, uint8_t* hard, hipStream_t st) {
   using namespace nrx_dec2;
   const int zi = zindex(cfg->Zc, cfg->iLS);
   NRX_REQUIRE(zi >= 0, NRX_E_ARG, "nrx_ldpc_decode: (Zc=%d, iLS=%d) is not a lifting size", cfg->Zc, cfg->iLS);
@@ -584,34 +626,41 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   const int32_t* t1 = &base[bi]->d4[zi][1][0];
   const int32_t* rh = &base[bi]->rho4[zi][0];
   static const bool no_spec = getenv("NRX_LDPC_NOSPEC") != nullptr;
-  static const uint64_t* wrap[3] = {nullptr, nullptr, nullptr};   // device addresses of the wrap-mask tables
+  static const bool all_rows = getenv("NRX_LDPC_ALLROWS") != nullptr;   // developer switch: ignore n_rows
+  static const uint64_t* wrap[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wrap-mask tables
   if (!wrap[0]) {
-    void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
-    const hipError_t e0 = hipGetSymbolAddress(&p0, HIP_SYMBOL(kWrap1_384));
-    const hipError_t e1 = hipGetSymbolAddress(&p1, HIP_SYMBOL(kWrap1_352));
-    const hipError_t e2 = hipGetSymbolAddress(&p2, HIP_SYMBOL(kWrap2_256));
-    NRX_REQUIRE(e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess && p0 && p1 && p2, NRX_E_HIP,
-                "nrx_ldpc_decode: hipGetSymbolAddress(wrap masks) failed");
-    wrap[1] = (const uint64_t*)p1;
-    wrap[2] = (const uint64_t*)p2;
-    wrap[0] = (const uint64_t*)p0;
+    void* p[7] = {};
+    const hipError_t e[7] = {hipGetSymbolAddress(&p[0], HIP_SYMBOL(kWrap1_384)), hipGetSymbolAddress(&p[1], HIP_SYMBOL(kWrap1_352)),
+                             hipGetSymbolAddress(&p[2], HIP_SYMBOL(kWrap2_256)), hipGetSymbolAddress(&p[3], HIP_SYMBOL(kWrap1_384_r13)),
+                             hipGetSymbolAddress(&p[4], HIP_SYMBOL(kWrap1_384_r16)), hipGetSymbolAddress(&p[5], HIP_SYMBOL(kWrap1_384_r22)),
+                             hipGetSymbolAddress(&p[6], HIP_SYMBOL(kWrap1_384_r31))};
+    for (int i = 0; i < 7; ++i)
+      NRX_REQUIRE(e[i] == hipSuccess && p[i], NRX_E_HIP, "nrx_ldpc_decode: hipGetSymbolAddress(wrap masks) failed");
+    for (int i = 6; i >= 0; --i) wrap[i] = (const uint64_t*)p[i];
   }
   const uint64_t* wt = nullptr;
-#define NRX_DEC2_LAUNCH(BGN, ZIV, NSV)                                                                               \
-  hipLaunchKernelGGL((ldpc_dec_fast_kernel<BGN, ZIV, NSV>), dim3(grid), dim3(threads), 0, st, llr, n_cb, cfg->Zc, n_iter, \
-                     hard, (ctab_t)t0, (ctab_t)t1, (ctab_t)rh, (mtab_t)wt)
+#define NRX_DEC2_LAUNCH(BGN, ZIV, NSV, RAV)                                                                               \
+  hipLaunchKernelGGL((ldpc_dec_fast_kernel<BGN, ZIV, NSV, RAV>), dim3(grid), dim3(threads), 0, st, llr, n_cb, cfg->Zc,     \
+                     n_iter, hard, (ctab_t)t0, (ctab_t)t1, (ctab_t)rh, (mtab_t)wt)
   // lifting sizes with a specialised instantiation (the sizes of the BASELINE configurations); everything else
   // runs the generic kernel
   constexpr int ZI384 = zindex_c(384), ZI352 = zindex_c(352), ZI256 = zindex_c(256);
+  if (all_rows) n_rows = cfg->bg == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
   if (cfg->bg == 1) {
-    if (!no_spec && zi == ZI384) { wt = wrap[0]; NRX_DEC2_LAUNCH(1, ZI384, 2); }
-    else if (!no_spec && zi == ZI352) { wt = wrap[1]; NRX_DEC2_LAUNCH(1, ZI352, 2); }
-    else if (ns == 2) NRX_DEC2_LAUNCH(1, -1, 2);
-    else NRX_DEC2_LAUNCH(1, -1, 1);
+    if (!no_spec && zi == ZI384) {
+      if (n_rows <= 13) { wt = wrap[3]; NRX_DEC2_LAUNCH(1, ZI384, 2, 13); }
+      else if (n_rows <= 16) { wt = wrap[4]; NRX_DEC2_LAUNCH(1, ZI384, 2, 16); }
+      else if (n_rows <= 22) { wt = wrap[5]; NRX_DEC2_LAUNCH(1, ZI384, 2, 22); }
+      else if (n_rows <= 31) { wt = wrap[6]; NRX_DEC2_LAUNCH(1, ZI384, 2, 31); }
+      else { wt = wrap[0]; NRX_DEC2_LAUNCH(1, ZI384, 2, NRX_BG1_ROWS); }
+    }
+    else if (!no_spec && zi == ZI352) { wt = wrap[1]; NRX_DEC2_LAUNCH(1, ZI352, 2, NRX_BG1_ROWS); }
+    else if (ns == 2) NRX_DEC2_LAUNCH(1, -1, 2, NRX_BG1_ROWS);
+    else NRX_DEC2_LAUNCH(1, -1, 1, NRX_BG1_ROWS);
   } else {
-    if (!no_spec && zi == ZI256) { wt = wrap[2]; NRX_DEC2_LAUNCH(2, ZI256, 1); }
-    else if (ns == 2) NRX_DEC2_LAUNCH(2, -1, 2);
-    else NRX_DEC2_LAUNCH(2, -1, 1);
+    if (!no_spec && zi == ZI256) { wt = wrap[2]; NRX_DEC2_LAUNCH(2, ZI256, 1, NRX_BG2_ROWS); }
+    else if (ns == 2) NRX_DEC2_LAUNCH(2, -1, 2, NRX_BG2_ROWS);
+    else NRX_DEC2_LAUNCH(2, -1, 1, NRX_BG2_ROWS);
   }
 #undef NRX_DEC2_LAUNCH
   NRX_CHECK_LAUNCH("nrx_ldpc_decode_f32(fast)");

@@ -26,7 +26,8 @@ from .waveform import Waveform
 
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
-                 decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True):
+                 decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
+                 skipPuncturedRows=True):
         if pdsch.dmrs is None:
             raise ValueError("PdschLink: the PDSCH needs a DMRS configuration (pdsch.setDMRS)")
         if chanEst not in ("LS", "Perfect"):
@@ -90,7 +91,12 @@ class PdschLink:
             qm = pdsch.modems[q].qm
             G = n_res[q] * qm
             lm = lms[q]
-            self.cw.append(dict(tbs=tbs_all[q], qm=qm, nl=cw_layers[q], G=G, cfg=_lib.ldpc_config(baseGraphNo, tbs_all[q] + 24),
+            ccfg = _lib.ldpc_config(baseGraphNo, tbs_all[q] + 24)
+            # rows of the base graph whose extension parity is actually transmitted (first transmission, rv 0): the
+            # others are exact no-ops for the information bits and are not run (ops.ldpc_active_rows)
+            e_max = max(_lib.ldpc_cb_lens(G, ccfg.C, cw_layers[q], qm))
+            self.cw.append(dict(tbs=tbs_all[q], qm=qm, nl=cw_layers[q], G=G, cfg=ccfg,
+                                rows=ops.ldpc_active_rows(ccfg, e_max) if skipPuncturedRows else None,
                                 re_index=D(np.int32((np.int64(lm[0]) * self.L + lm[1]) * self.K + lm[2])),
                                 scr=D(pdsch._scrambling(q, G))))
         c0 = self.cw[0]     # (single-codeword attribute names kept: bench.py, the oracle harness and the tests use them)
@@ -287,15 +293,16 @@ class PdschLink:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'])
             else:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'], rv=harq[0], circ=harq[1], reset=harq[2])
+            rows = cw['rows'] if harq is None else None        # HARQ soft buffers fill other columns: all rows
             if self.firstPassIter is None:
-                dec = ops.ldpc_decode(rr, ccfg, self.numIter)
+                dec = ops.ldpc_decode(rr, ccfg, self.numIter, rows=rows)
                 tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb_crc=False)
             else:
-                dec = ops.ldpc_decode(rr, ccfg, self.firstPassIter)
+                dec = ops.ldpc_decode(rr, ccfg, self.firstPassIter, rows=rows)
                 _, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb=False)
                 fail = (cb_ok.reshape(-1) == 0).nonzero().reshape(-1)          # host read: how many blocks go on
                 if fail.numel():
-                    dec.index_copy_(0, fail, ops.ldpc_decode(rr.index_select(0, fail), ccfg, self.numIter))
+                    dec.index_copy_(0, fail, ops.ldpc_decode(rr.index_select(0, fail), ccfg, self.numIter, rows=rows))
                 tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb_crc=False)
             if counters is not None:
                 ops.count_errors(cb_ok, tb_out, tbs_in[q], counters)

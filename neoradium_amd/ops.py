@@ -130,10 +130,27 @@ def _decode_ws(cfg, device):
     return ws
 
 
-def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False):
+def ldpc_active_rows(cfg, e_max, rv=0, accumulated=False):
+    """Rows of the base graph that can change an information bit when at most ``e_max`` rate-matched bits per code block
+    were received in ONE transmission with redundancy version 0 into an empty soft buffer (ldpc.py:1093-1159, 1330-1418):
+    the transmitted bits fill the circular buffer (fillers skipped) from position 0, i.e. punctured-codeword columns
+    0 .. (F + e_max - 1) // Zc; the extension column of row r is base-graph column r + 22.  Everything else (rv != 0,
+    HARQ accumulation, wrap-around) needs all rows."""
+    rows_all = 46 if cfg.bg == 1 else 42
+    if rv != 0 or accumulated or e_max >= cfg.N - cfg.F:
+        return rows_all
+    last = e_max - 1 + (cfg.F if e_max > cfg.K - 2 * cfg.Zc - cfg.F else 0)      # position in the punctured code word
+    col = last // cfg.Zc + 2                                                     # base-graph column
+    core = 26 if cfg.bg == 1 else 14
+    return min(rows_all, max(4, col - core + 1 + 4))
+
+
+def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False, rows=None):
     """ldpc.py:1495-1581 decode: (n_cb, N) LLRs -> (n_cb, K or N+2Zc) hard bits (uint8) or beliefs.
 
-    float64 input runs the bit-exact float64 kernel, float32 input the single-precision throughput kernel."""
+    float64 input runs the bit-exact float64 kernel, float32 input the single-precision throughput kernel.
+    ``rows`` (hard information bits only): decode with the first `rows` rows of the base graph; identical output when
+    the dropped rows' extension columns are all-zero (see nrx_ldpc_decode_rows_* and :func:`ldpc_active_rows`)."""
     if llr.dtype not in _FT:
         raise ValueError("LLRs must be float32 or float64")
     llr = llr.contiguous()
@@ -144,6 +161,17 @@ def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False):
     dev = _dev(llr)
     hard = None if belief else torch.empty((n_cb, cols), dtype=torch.uint8, device=dev)
     bel = torch.empty((n_cb, cols), dtype=llr.dtype, device=dev) if belief else None
+    if rows is not None and int(rows) < (46 if cfg.bg == 1 else 42):
+        if belief or not only_info:
+            raise ValueError("rows: only the hard decisions of the information bits are defined with dropped rows")
+        if llr.dtype == torch.float64:
+            ws = _decode_ws(cfg, dev)
+            check(lib().nrx_ldpc_decode_rows_f64(ptr(llr), n_cb, C.byref(cfg), int(n_iter), int(rows), ptr(hard), ptr(ws),
+                                                 ws.numel(), stream()))
+        else:
+            check(lib().nrx_ldpc_decode_rows_f32(ptr(llr), n_cb, C.byref(cfg), int(n_iter), int(rows), ptr(hard), None, 0,
+                                                 stream()))
+        return hard
     if llr.dtype == torch.float64:
         ws = _decode_ws(cfg, dev)
         check(lib().nrx_ldpc_decode_f64(ptr(llr), n_cb, C.byref(cfg), int(n_iter), cols, ptr(hard), ptr(bel), ptr(ws),

@@ -203,19 +203,22 @@ def rate_recover(llr, p, nl, qm, rv=0, nref=0, circ=None):
     return full, circ
 
 
-def decode(rx, bgn, ils, zc, num_iter=5, only_info=True, belief=False, dtype=np.float64):
+def decode(rx, bgn, ils, zc, num_iter=5, only_info=True, belief=False, dtype=np.float64, rows=None):
     """ldpc.py:1495-1581 decode: layered normalised (0.75) min-sum, fixed iteration count, float64.
 
     QUIRKs kept: clip to +-1e10; sign(0)=+1 via (v<0); first-index argmin; second minimum obtained by adding
     +100000 to the (signed) argmin entry before taking min|.| (ldpc.py:1563); scaling after the un-shift.
-    ``dtype=np.float32`` gives the single-precision statement used to bound the fp32 GPU variant."""
+    ``dtype=np.float32`` gives the single-precision statement used to bound the fp32 GPU variant.
+    ``rows`` (test hook, not in the reference): run only the first `rows` rows of the base graph -- identical for the
+    information/core columns whenever the extension columns of the dropped rows carry all-zero LLRs (punctured parity):
+    such a row sends +-0 to every core column."""
     T = dtype
     rx = np.clip(np.asarray(rx, dtype=np.float64), -LLR_CLIP, LLR_CLIP).astype(T)
     C = rx.shape[0]
     bg = base_graph(bgn, ils, zc)
     r = np.concatenate([np.zeros((C, 2, zc), dtype=T), rx.reshape(C, -1, zc)], axis=1)
     assert r.shape[1] == bg.shape[1]
-    cols = [np.nonzero(row >= 0)[0] for row in bg]
+    cols = [np.nonzero(row >= 0)[0] for row in bg][:rows]
     msg = [np.zeros((C, len(c), zc), dtype=T) for c in cols]
     ci = np.arange(C)[:, None]
     zi = np.arange(zc)[None, :]

@@ -249,3 +249,45 @@ def test_empty_batches(dev):
     assert tuple(x.shape) == (0, 128) and tuple(enc.rateMatchDevice(x).shape) == (0, 120)
     msg, ok = pdec.decodeDevice(torch.empty((0, 128), dtype=torch.float64, device=dev))
     assert tuple(msg.shape) == (0, 54) and ok.numel() == 0
+
+
+@pytest.mark.parametrize("bg,zc,n_tx_cols", [(1, 384, 35), (1, 384, 31), (1, 384, 40), (1, 384, 50), (1, 352, 35), (1, 128, 33),
+                                             (2, 256, 20), (2, 64, 16)])
+def test_punctured_rows_are_exact_no_ops(dev, bg, zc, n_tx_cols):
+    """Decoding with only the rows whose extension parity was received gives the same hard bits as running all rows
+    (nrx_ldpc_decode_rows_*): a row whose degree-1 extension column holds all-zero LLRs has min1 = 0 there and sends +-0
+    to every other column.  Checked for the float32 throughput kernel (compile-time row counts 13/16/22/31 for Zc = 384,
+    all rows otherwise), the generic float32 kernel and the float64 kernel (run-time row count), on noisy LLRs where
+    part of the blocks do not converge, with a partially filled last column and exact zeros sprinkled into core columns;
+    and against the oracle's float64 beliefs."""
+    import torch
+    from neoradium_amd import ops, _lib
+    kb, core, rows_all, ncols = (22, 26, 46, 68) if bg == 1 else (10, 14, 42, 52)
+    ils = next(i for i, b in enumerate((2, 3, 5, 7, 9, 11, 13, 15)) if zc % b == 0 and (zc // b) & (zc // b - 1) == 0)
+    cfg = _lib.LdpcCfg()
+    cfg.bg, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F, cfg.C, cfg.B, cfg.cb_len = bg, zc, ils, kb * zc, (ncols - 2) * zc, 0, 1, 0, 0
+    rng = np.random.default_rng(zc + n_tx_cols)
+    n_cb = 10
+    sig = 0.95 if bg == 1 else 1.1
+    llr = 2 / sig ** 2 + (2 / sig) * rng.standard_normal((n_cb, cfg.N))
+    e_max = n_tx_cols * zc - zc // 3                      # the last received column is only partly filled
+    llr[:, e_max:] = 0.0
+    llr[rng.random(llr.shape) < 0.002] = 0.0              # a few exact zeros among the received LLRs
+    rows = ops.ldpc_active_rows(cfg, e_max)
+    assert rows == min(rows_all, max(4, (e_max - 1) // zc + 2 - core + 1 + 4)) and rows < rows_all
+    for ft in (torch.float32, torch.float64):
+        x = torch.from_numpy(llr).to(dev).to(ft)
+        full = ops.ldpc_decode(x, cfg, 14)
+        part = ops.ldpc_decode(x, cfg, 14, rows=rows)
+        more = ops.ldpc_decode(x, cfg, 14, rows=min(rows + 3, rows_all))
+        assert torch.equal(full, part) and torch.equal(full, more)
+    if zc <= 128:                                          # the oracle (float64 beliefs of the core columns) agrees
+        from oracle import coding as oc
+        a = oc.decode(llr[:3], bg, ils, zc, num_iter=14, only_info=False, belief=True)
+        b = oc.decode(llr[:3], bg, ils, zc, num_iter=14, only_info=False, belief=True, rows=rows)
+        assert np.array_equal(a[:, :core * zc], b[:, :core * zc])
+        assert np.array_equal((a[:, :kb * zc] < 0).astype(np.uint8), ops.ldpc_decode(torch.from_numpy(llr[:3]).to(dev), cfg, 14, rows=rows).cpu().numpy())
+    with pytest.raises(ValueError):
+        ops.ldpc_decode(torch.from_numpy(llr).to(dev), cfg, 5, rows=3)
+    with pytest.raises(ValueError):
+        ops.ldpc_decode(torch.from_numpy(llr).to(dev), cfg, 5, rows=rows, belief=True)
