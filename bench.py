@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_link(nr, decoder="f32", num_iter=50):
+def build_link(nr, decoder="f32", num_iter=50, **kw):
     nr.random.setSeed(123)
     car = nr.Carrier(numRbs=273, spacing=30)
     bwp = car.curBwp
@@ -31,7 +31,7 @@ def build_link(nr, decoder="f32", num_iter=50):
     ch = nr.CdlChannel(bwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
                        txAntenna=nr.AntennaPanel([1, 2], polarization="x"),
                        rxAntenna=nr.AntennaPanel([1, 2], polarization="x"))
-    return nr.PdschLink(p, ch, 666 / 1024, baseGraphNo=1, numIter=num_iter, freqDomain=False, chanEst="LS", decoder=decoder)
+    return nr.PdschLink(p, ch, 666 / 1024, baseGraphNo=1, numIter=num_iter, freqDomain=False, chanEst="LS", decoder=decoder, **kw)
 
 
 class DecodeTimer:
@@ -150,16 +150,27 @@ def main():
     if rank == 0:
         cfg = link.cfg
         slots = world * B * K
-        # algorithmic HBM bytes of the dominant kernel (layered min-sum decoder), SURVEY 8d: C*N*4 in + C*K/8 out per slot
-        alg_bytes = B * (cfg.C * cfg.N * 4 + cfg.C * cfg.K / 8)
+        # algorithmic HBM bytes of the dominant kernel (layered min-sum decoder), SURVEY 8d: C*N*4 in + C*K/8 out per slot;
+        # with the punctured rows dropped only the received columns are read: (24 core + rows-4 extension) * Zc * 4 B
+        rows = link.cw[0]['rows'] or 46
+        n_in = cfg.N if rows >= 46 else (24 + rows - 4) * cfg.Zc
+        alg_bytes = B * (cfg.C * n_in * 4 + cfg.C * cfg.K)    # hard decisions are one byte per bit (uint8), like the reference's int8
         achieved = alg_bytes / (dec_ms * 1e-3) / 1e9
+        # edges of the rows that run (the kernel is built for 13/16/22/31/46 rows: the next count >= rows)
+        BG1_ROW_START = [0, 19, 38, 57, 76, 79, 87, 96, 103, 113, 122, 129, 137, 144, 150, 157, 164, 170, 176, 182, 188, 194, 200,
+                         205, 210, 216, 221, 226, 230, 235, 240, 245, 250, 255, 260, 265, 270, 275, 279, 284, 289, 293, 298, 302,
+                         307, 312, 316]
+        rows_run = next(r for r in (13, 16, 22, 31, 46) if r >= rows)
+        edge_visits = B * cfg.C * link.numIter * BG1_ROW_START[rows_run] * cfg.Zc
         traffic = None
         try:                                              # HBM bytes per launch from the committed PMC passes
             tr = json.load(open(os.path.join(ROOT, 'profiles', 'r1_decoder_traffic.json')))
-            traffic = (tr['FETCH_SIZE_KB_per_launch'] + tr['WRITE_SIZE_KB_per_launch']) * 1024.0 * B / tr['batch_slots']
+            traffic = (tr['FETCH_SIZE_KB_per_launch'] * tr.get('fetch_correction', 1.0) + tr['WRITE_SIZE_KB_per_launch']) \
+                * 1024.0 * B / tr['batch_slots']
+            if rows_run != 16 or args.decoder != 'f32':   # the committed counters belong to the 16-row float32 kernel
+                traffic = None
         except Exception:
             pass
-        edge_visits = B * cfg.C * link.numIter * 316 * cfg.Zc
         out = {
             "metric": "PDSCH slots/sec at 273 PRB 64-QAM 4x4 LDPC-BG1; BLER match vs CPU ref",
             "value": slots / dt, "unit": "slots/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -170,7 +181,11 @@ def main():
                                    "TBS 606504 (72 CB, Zc 384), time-domain channel, DMRS-LS + MMSE, 50-iteration min-sum",
                        "slots_per_step_per_gpu": B, "snr_db": args.snr, "sharding": "slot ranges per rank, 1 all-reduce"},
             "bler": {"block_errors": int(c[0]), "blocks": int(c[1]), "bit_errors": int(c[2]), "bits": int(c[3])},
-            "roofline": {"bound": "hbm", "kernel": ("ldpc_dec_fast_kernel<1,Zc384,2>" if args.decoder == "f32" else "ldpc_dec_kernel<double,1,true>"),
+            "ldpc_rows": {"needed": rows, "run": rows_run, "of": 46,
+                          "note": "rows whose extension parity was not transmitted are exact no-ops for the information bits "
+                                  "(they send +-0) and are not run; counters identical to all 46 rows "
+                                  "(NRX_LDPC_ALLROWS=1 python bench.py reproduces the all-rows number)"},
+            "roofline": {"bound": "hbm", "kernel": (f"ldpc_dec_fast_kernel<1,Zc384,2,rows={rows_run}>" if args.decoder == "f32" else "ldpc_dec_kernel<double,1,true>"),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "avg_launch_ms": dec_ms, "launch_share_of_step": dec_ms / (dt / K * 1e3),
                          "note": "decoder re-uses its LDS/VGPR-resident working set 50x: it is VALU/LDS-issue bound, "
@@ -197,6 +212,19 @@ def main():
             xc = xc.cpu().numpy()
             out["bit_exact_path"] = {"decoder": "f64 (ldpc_dec_kernel<double,1,true>)", "value": 2 * xb / xdt, "unit": "slots/s",
                                      "n_gpus": 1, "slots": 2 * xb, "block_errors": int(xc[0]), "blocks": int(xc[1])}
+        if args.decoder == 'f32' and not args.no_exact and world == 1:
+            # the same steps with all 46 rows of the base graph (what the reference runs): identical counters, slower
+            al = build_link(nr, decoder='f32', skipPuncturedRows=False)
+            al.run(slot_base, B, args.snr, seed=123)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            ac = torch.zeros(4, dtype=torch.int64, device=dev)
+            for k in range(K):
+                al.run(slot_base + (W + k) * B, B, args.snr, seed=123, counters=ac)
+            torch.cuda.synchronize()
+            adt = time.perf_counter() - t2
+            out["ldpc_rows"]["all_rows"] = {"value": B * K / adt, "unit": "slots/s",
+                                            "counters_identical": bool((ac.cpu().numpy() == c).all())}
         if not args.no_cpu and world == 1:                # the CPU leg runs on rank 0 at N = 1 only (contract)
             base, parity = cpu_baseline(link, args.snr)
             out["cpu_baseline"] = base
