@@ -156,18 +156,18 @@ def main():
         n_in = cfg.N if rows >= 46 else (24 + rows - 4) * cfg.Zc
         alg_bytes = B * (cfg.C * n_in * 4 + cfg.C * cfg.K)    # hard decisions are one byte per bit (uint8), like the reference's int8
         achieved = alg_bytes / (dec_ms * 1e-3) / 1e9
-        # edges of the rows that run (the kernel is built for 13/16/22/31/46 rows: the next count >= rows)
+        # edges of the rows that run (the kernel is built for 13/15/16/22/31/46 rows: the next count >= rows)
         BG1_ROW_START = [0, 19, 38, 57, 76, 79, 87, 96, 103, 113, 122, 129, 137, 144, 150, 157, 164, 170, 176, 182, 188, 194, 200,
                          205, 210, 216, 221, 226, 230, 235, 240, 245, 250, 255, 260, 265, 270, 275, 279, 284, 289, 293, 298, 302,
                          307, 312, 316]
-        rows_run = next(r for r in (13, 16, 22, 31, 46) if r >= rows)
+        rows_run = next(r for r in (13, 15, 16, 22, 31, 46) if r >= rows)
         edge_visits = B * cfg.C * link.numIter * BG1_ROW_START[rows_run] * cfg.Zc
         traffic = None
         try:                                              # HBM bytes per launch from the committed PMC passes
             tr = json.load(open(os.path.join(ROOT, 'profiles', 'r1_decoder_traffic.json')))
             traffic = (tr['FETCH_SIZE_KB_per_launch'] * tr.get('fetch_correction', 1.0) + tr['WRITE_SIZE_KB_per_launch']) \
                 * 1024.0 * B / tr['batch_slots']
-            if rows_run != 16 or args.decoder != 'f32':   # the committed counters belong to the 16-row float32 kernel
+            if rows_run not in (15, 16) or args.decoder != 'f32':   # the committed counters: 16-row float32 kernel (15: same columns but one)
                 traffic = None
         except Exception:
             pass

@@ -186,6 +186,12 @@ __device__ __forceinline__ uint32_t wrap4(uint32_t a4, uint32_t zc4) {  // a4 in
 // prefetch distance (layers) of the extension-column channel LLRs; must divide the number of extension layers
 // (42 for BG1, 38 for BG2) so that ring slot = ordinal mod PFN stays consistent across iterations
 template <int BG> constexpr int pfn() { return BG == 1 ? 3 : 2; }
+// ... for a truncated graph with n_ext extension layers: the largest ring <= pfn<BG>() that divides n_ext
+template <int BG> constexpr int pfn_for(int n_ext) {
+  for (int k = pfn<BG>(); k > 1; --k)
+    if (n_ext % k == 0) return k;
+  return 1;
+}
 
 template <int BG, int RA = G<BG>::ROWS> struct Lay {  // compile-time layer facts (of the first RA rows)
   using B = GR<BG, RA>;
@@ -319,7 +325,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
   float* const Ps = Praw + ZS + slot * SLOT;
   const uint32_t zc4 = 4u * (uint32_t)zc;
   const int N = (B::COLS - 2) * zc, K = B::KB * zc;
-  constexpr int PFN = pfn<BG>();
+  constexpr int PFN = pfn_for<BG>(Y::n_ext());
   static_assert(Y::n_ext() % PFN == 0, "prefetch ring must divide the number of extension layers");
   static_assert(Y::barriers_ok(), "barrier placement leaves a column hazard");
   constexpr uint32_t HI = 49152;                           // second DS base: immediates are 16 bit
@@ -586,8 +592,10 @@ constexpr int zindex_c(int zc) {
 __constant__ WrapTab kWrap1_384 = make_wrap<1, zindex_c(384)>();
 __constant__ WrapTab kWrap1_352 = make_wrap<1, zindex_c(352)>();
 __constant__ WrapTab kWrap2_256 = make_wrap<2, zindex_c(256)>();
-// BG1, Zc = 384 with the first 13 / 16 / 22 / 31 rows only (row counts with a whole number of prefetch rings)
+// BG1, Zc = 384 with the first 13 / 15 / 16 / 22 / 31 rows only (15 = the metric configuration, with a one-deep
+// prefetch ring: 11 extension layers)
 __constant__ WrapTab kWrap1_384_r13 = make_wrap<1, zindex_c(384), 13>();
+__constant__ WrapTab kWrap1_384_r15 = make_wrap<1, zindex_c(384), 15>();
 __constant__ WrapTab kWrap1_384_r16 = make_wrap<1, zindex_c(384), 16>();
 __constant__ WrapTab kWrap1_384_r22 = make_wrap<1, zindex_c(384), 22>();
 __constant__ WrapTab kWrap1_384_r31 = make_wrap<1, zindex_c(384), 31>();
@@ -627,16 +635,16 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   const int32_t* rh = &base[bi]->rho4[zi][0];
   static const bool no_spec = getenv("NRX_LDPC_NOSPEC") != nullptr;
   static const bool all_rows = getenv("NRX_LDPC_ALLROWS") != nullptr;   // developer switch: ignore n_rows
-  static const uint64_t* wrap[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wrap-mask tables
+  static const uint64_t* wrap[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wrap-mask tables
   if (!wrap[0]) {
-    void* p[7] = {};
-    const hipError_t e[7] = {hipGetSymbolAddress(&p[0], HIP_SYMBOL(kWrap1_384)), hipGetSymbolAddress(&p[1], HIP_SYMBOL(kWrap1_352)),
+    void* p[8] = {};
+    const hipError_t e[8] = {hipGetSymbolAddress(&p[0], HIP_SYMBOL(kWrap1_384)), hipGetSymbolAddress(&p[1], HIP_SYMBOL(kWrap1_352)),
                              hipGetSymbolAddress(&p[2], HIP_SYMBOL(kWrap2_256)), hipGetSymbolAddress(&p[3], HIP_SYMBOL(kWrap1_384_r13)),
                              hipGetSymbolAddress(&p[4], HIP_SYMBOL(kWrap1_384_r16)), hipGetSymbolAddress(&p[5], HIP_SYMBOL(kWrap1_384_r22)),
-                             hipGetSymbolAddress(&p[6], HIP_SYMBOL(kWrap1_384_r31))};
-    for (int i = 0; i < 7; ++i)
+                             hipGetSymbolAddress(&p[6], HIP_SYMBOL(kWrap1_384_r31)), hipGetSymbolAddress(&p[7], HIP_SYMBOL(kWrap1_384_r15))};
+    for (int i = 0; i < 8; ++i)
       NRX_REQUIRE(e[i] == hipSuccess && p[i], NRX_E_HIP, "nrx_ldpc_decode: hipGetSymbolAddress(wrap masks) failed");
-    for (int i = 6; i >= 0; --i) wrap[i] = (const uint64_t*)p[i];
+    for (int i = 7; i >= 0; --i) wrap[i] = (const uint64_t*)p[i];
   }
   const uint64_t* wt = nullptr;
 #define NRX_DEC2_LAUNCH(BGN, ZIV, NSV, RAV)                                                                               \
@@ -649,6 +657,7 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   if (cfg->bg == 1) {
     if (!no_spec && zi == ZI384) {
       if (n_rows <= 13) { wt = wrap[3]; NRX_DEC2_LAUNCH(1, ZI384, 2, 13); }
+      else if (n_rows <= 15) { wt = wrap[7]; NRX_DEC2_LAUNCH(1, ZI384, 2, 15); }
       else if (n_rows <= 16) { wt = wrap[4]; NRX_DEC2_LAUNCH(1, ZI384, 2, 16); }
       else if (n_rows <= 22) { wt = wrap[5]; NRX_DEC2_LAUNCH(1, ZI384, 2, 22); }
       else if (n_rows <= 31) { wt = wrap[6]; NRX_DEC2_LAUNCH(1, ZI384, 2, 31); }
