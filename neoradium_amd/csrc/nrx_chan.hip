@@ -113,14 +113,14 @@ chan_matrix_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int n_rt, 
     const int o = off[b];
     const int use = cl < nfft ? cl : nfft;  // longer responses are truncated (channelmodel.py:384-388)
     __syncthreads();
-    for (int i = threadIdx.x; i < nfft; i += blockDim.x) buf[i] = cd(0, 0);
+    for (int i = threadIdx.x; i < nfft; i += blockDim.x) buf[nrx::fft_idx(i)] = cd(0, 0);
     __syncthreads();
-    for (int l = threadIdx.x; l < use; l += blockDim.x) buf[(l - o + nfft) & (nfft - 1)] = src[l];
+    for (int l = threadIdx.x; l < use; l += blockDim.x) buf[nrx::fft_idx((l - o + nfft) & (nfft - 1))] = src[l];
     __syncthreads();
     nrx::fft_dif_lds(buf, tw, nfft, log2n, false);
     cd* dst = H + (((size_t)b * nc + c) * K) * n_rt + rt;
     for (int k = threadIdx.x; k < K; k += blockDim.x)
-      dst[(size_t)k * n_rt] = buf[nrx::fft_bitrev((k - K / 2 + nfft) & (nfft - 1), log2n)];
+      dst[(size_t)k * n_rt] = buf[nrx::fft_idx(nrx::fft_bitrev((k - K / 2 + nfft) & (nfft - 1), log2n))];
   }
 }
 
@@ -396,7 +396,7 @@ extern "C" int32_t nrx_channel_matrix_f64(const void* cir, int32_t n_items, int3
   if (n_tasks == 0) return NRX_OK;
   const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_channel_matrix: FFT twiddle table unavailable");
-  const size_t lds = sizeof(cd) * (size_t)nfft;
+  const size_t lds = sizeof(cd) * nrx::fft_lds_elems((size_t)nfft);
   (void)hipFuncSetAttribute((const void*)chan_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(chan_matrix_kernel, dim3(n_tasks < 2048 ? n_tasks : 2048), dim3(256), lds, (hipStream_t)stream,
                      (const cd*)cir, n_t, nc, n_rx * n_tx, cl, chan_offset, K, nfft, ilog2(nfft), (cd*)H, n_tasks, tw);

@@ -15,6 +15,13 @@ constexpr int FFT_TW_N = 8192;
 // Device pointer of the table; the first call fills it on `stream` and waits for that once (nrx_fft_tab.hip).
 const cx<double>* fft_twiddle_table(hipStream_t stream);
 
+// LDS layout of an FFT buffer: logical element i lives at i + (i >> 4), one element of padding per 16.  In the last fused
+// pass every thread owns 16 CONSECUTIVE elements (lane stride 256 B: all lanes on the same four banks, the pass ran
+// serialised); with the padding the lane stride is 17 elements and eight neighbouring lanes cover all 32 banks.
+// Every access to a buffer handed to fft_dif_lds goes through fft_idx; its size is fft_lds_elems(n).
+__host__ __device__ __forceinline__ constexpr int fft_idx(int i) { return i + (i >> 4); }
+__host__ __device__ __forceinline__ constexpr size_t fft_lds_elems(size_t n) { return n + (n >> 4); }
+
 // LG consecutive radix-2 DIF stages (starting at stage s) fused in registers: a thread loads the 2^LG points that
 // only interact with each other during those stages, runs the butterflies, stores them back.  Same arithmetic and
 // same (bit-reversed) result order as stage-by-stage radix-2, but one LDS round trip and one barrier per LG stages.
@@ -27,32 +34,41 @@ __device__ __forceinline__ void fft_dif_fused(cx<T>* buf, const cx<double>* __re
   for (int gi = threadIdx.x; gi < (n >> LG); gi += blockDim.x) {
     const int lo = gi & (q - 1);
     const int a = ((gi >> lq) << (lq + LG)) | lo;
-    cx<T> x[P];
-#pragma unroll
-    for (int m = 0; m < P; ++m) x[m] = buf[a + (m << lq)];
+    // the P - 1 distinct twiddles of the fused stages (stage t uses P >> (t+1) of them, each for 2^t butterflies): all
+    // fetched up front, so their latency is paid once per pass instead of once per dependent batch of butterflies
+    cx<T> wt[P - 1];
 #pragma unroll
     for (int t = 0; t < LG; ++t) {
-      constexpr int dummy = 0;
+      const int half = P >> (t + 1);
+#pragma unroll
+      for (int r = 0; r < half; ++r) {
+        const int j = (lo + (r << lq)) << (s + t);
+        const cx<double> wd = tw[(size_t)j * tws];
+        wt[(P - 2 * half) + r] = cx<T>((T)wd.re, inverse ? -(T)wd.im : (T)wd.im);   // offsets 0, P/2, 3P/4, ...
+      }
+    }
+    cx<T> x[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) x[m] = buf[fft_idx(a + (m << lq))];
+#pragma unroll
+    for (int t = 0; t < LG; ++t) {
       const int half = P >> (t + 1);   // partner distance in m
 #pragma unroll
       for (int m = 0; m < P; ++m) {
         if (m & half) continue;        // m is the upper element of its pair
-        const int j = (lo + ((m & (half - 1)) << lq)) << (s + t + dummy);
-        const cx<double> wd = tw[(size_t)j * tws];
-        cx<T> w((T)wd.re, (T)wd.im);
-        if (inverse) w.im = -w.im;
+        const cx<T> w = wt[(P - 2 * half) + (m & (half - 1))];
         const cx<T> u = x[m], v = x[m + half];
         x[m] = u + v;
         x[m + half] = (u - v) * w;
       }
     }
 #pragma unroll
-    for (int m = 0; m < P; ++m) buf[a + (m << lq)] = x[m];
+    for (int m = 0; m < P; ++m) buf[fft_idx(a + (m << lq))] = x[m];
   }
   __syncthreads();
 }
 
-// In-place DIF FFT of buf[0..n): X[k] ends up at buf[bitrev(k)].  inverse: conjugated twiddles, no scaling.
+// In-place DIF FFT of the (padded, see fft_idx) buffer: X[k] ends up at buf[fft_idx(bitrev(k))].  inverse: conjugated twiddles, no scaling.
 // All threads of the workgroup must call it; it ends with a barrier.
 template <typename T>
 __device__ __forceinline__ void fft_dif_lds(cx<T>* buf, const cx<double>* __restrict__ tw, int n, int log2n,

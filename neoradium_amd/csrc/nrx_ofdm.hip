@@ -25,7 +25,7 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
                 const cx<T>* __restrict__ f, int64_t f_stride, int nl, int ports, const cx<double>* __restrict__ tw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
-  cx<T>* tail = buf + nfft;     // [w] windowed tail of the previous symbol
+  cx<T>* tail = buf + nrx::fft_lds_elems((size_t)nfft);   // [w] windowed tail of the previous symbol (behind the padded FFT buffer)
   cx<T>* head0 = tail + w;      // [w] windowed head of symbol 0 (completed by the last symbol's tail)
   const int row = blockIdx.x;   // item * ports + port
   // f != null: the grid holds `nl` layers per item and this row is antenna port `row % ports` of the wideband
@@ -54,7 +54,7 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
           v = src[(size_t)l * K + k];
         }
       }
-      buf[i] = v;
+      buf[nrx::fft_idx(i)] = v;
     }
     __syncthreads();
     nrx::fft_dif_lds(buf, tw, nfft, log2n, true);
@@ -62,7 +62,7 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
     // extended symbol ex[i], i in [0, n_l + w): sample time t = i - w - cp of the periodic extension
     for (int i = threadIdx.x; i < n_l + w; i += blockDim.x) {
       const int t = (i - w - cp + 2 * nfft) & (nfft - 1);
-      const cx<T> x = buf[nrx::fft_bitrev(t, log2n)];
+      const cx<T> x = buf[nrx::fft_idx(nrx::fft_bitrev(t, log2n))];
       double win = 1.0;
       if (i < w) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * i) / (double)(2 * w)));
       else if (i >= n_l) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * (n_l + w - 1 - i)) / (double)(2 * w)));
@@ -80,7 +80,7 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
     for (int q = threadIdx.x; q < w; q += blockDim.x) {
       const int i = n_l + q;
       const int t = (i - w - cp + 2 * nfft) & (nfft - 1);
-      const cx<T> x = buf[nrx::fft_bitrev(t, log2n)];
+      const cx<T> x = buf[nrx::fft_idx(nrx::fft_bitrev(t, log2n))];
       const double win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * (w - 1 - q)) / (double)(2 * w)));
       tail[q] = cx<T>((T)((double)x.re * inv_n * win), (T)((double)x.im * inv_n * win));
     }
@@ -114,6 +114,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
     const int cp = g.cp[l];
     const int off = (int)rint((double)cp * 0.5);  // np.round(cpLens * cpOffsetRatio), waveform.py:507
     __syncthreads();
+#pragma unroll 4
     for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
       const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));  // waveform.py:509
       cx<T> v = s < wave_len ? src[s] : cx<T>(0, 0);
@@ -122,14 +123,15 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
       if (sigma && s < wave_len)
         v = nrx::awgn_add<T>(v, (double)sigma[(size_t)item * sigma_stride], seed, stream_id, (uint64_t)(batch_offset + item),
                              (int64_t)(row - item * n_ant) * wave_len + s);
-      buf[i] = v;
+      buf[nrx::fft_idx(i)] = v;
     }
     __syncthreads();
     nrx::fft_dif_lds(buf, tw, nfft, log2n, false);
     cx<T>* dst = grid + ((size_t)row * g.n_sym + l) * K;
+#pragma unroll 4
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
       const int q = (k - K / 2 + nfft) & (nfft - 1);  // fftshift + centre K bins (waveform.py:514-520)
-      dst[k] = buf[nrx::fft_bitrev(q, log2n)];
+      dst[k] = buf[nrx::fft_idx(nrx::fft_bitrev(q, log2n))];
     }
   }
 }
@@ -155,6 +157,9 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
   cx<T>* dst = wave + (size_t)row * wave_stride;
   const int pad_lo = (nfft - K + 1) / 2;  // grid.py:543
   const double inv_n = 1.0 / (double)nfft;
+  // (unrolled by 4: the loads of four iterations are in flight together -- with two 4-wave workgroups per CU a
+  //  load-use-load chain of 16 iterations was most of this kernel's time)
+#pragma unroll 4
   for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
     const int j = (i + nfft / 2) & (nfft - 1);
     const int k = j - pad_lo;
@@ -168,14 +173,15 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
         v = src[(size_t)l * K + k];
       }
     }
-    buf[i] = v;
+    buf[nrx::fft_idx(i)] = v;
   }
   __syncthreads();
   nrx::fft_dif_lds(buf, tw, nfft, log2n, true);
   const int cp = g.cp[l], n_l = cp + nfft;
+#pragma unroll 4
   for (int i = threadIdx.x; i < n_l + w; i += blockDim.x) {
     const int t = (i - w - cp + 2 * nfft) & (nfft - 1);
-    const cx<T> x = buf[nrx::fft_bitrev(t, log2n)];
+    const cx<T> x = buf[nrx::fft_idx(nrx::fft_bitrev(t, log2n))];
     double win = 1.0;
     if (i < w) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * i) / (double)(2 * w)));
     else if (i >= n_l) win = 0.5 * (1.0 - sinpi((double)(w - 1 - 2 * (n_l + w - 1 - i)) / (double)(2 * w)));
@@ -249,7 +255,7 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
   const cx<double>* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_ofdm_modulate: FFT twiddle table unavailable");
   if (tails || window_len == 0) {   // symbol-parallel form
-    const size_t lds = sizeof(cx<T>) * (size_t)nfft;
+    const size_t lds = sizeof(cx<T>) * nrx::fft_lds_elems((size_t)nfft);
     auto kern = ofdm_mod_sym_kernel<T>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(n_rows * n_sym), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
@@ -263,7 +269,7 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
     NRX_CHECK_LAUNCH("nrx_ofdm_modulate");
     return NRX_OK;
   }
-  const size_t lds = sizeof(cx<T>) * ((size_t)nfft + 2 * (size_t)window_len);
+  const size_t lds = sizeof(cx<T>) * (nrx::fft_lds_elems((size_t)nfft) + 2 * (size_t)window_len);
   auto kern = ofdm_mod_kernel<T>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(n_rows), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft, ilog2(nfft), g,
@@ -291,7 +297,7 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
   if (n_tasks == 0) return NRX_OK;
   const cx<double>* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_ofdm_demodulate: FFT twiddle table unavailable");
-  const size_t lds = sizeof(cx<T>) * (size_t)nfft;
+  const size_t lds = sizeof(cx<T>) * nrx::fft_lds_elems((size_t)nfft);
   auto kern = ofdm_demod_kernel<T>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid_dim = n_tasks < 4096 ? n_tasks : 4096;
