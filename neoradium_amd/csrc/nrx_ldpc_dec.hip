@@ -401,6 +401,8 @@ int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int 
 }  // namespace
 int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
                                     int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec2.hip
+int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                      int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec3.hip
 namespace {
 
 template <typename T, bool EXACT>
@@ -427,6 +429,13 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
     static const bool force_v1 = getenv("NRX_LDPC_V1") != nullptr;
     if (hard && !belief && out_cols == cfg->K && !force_v1)
       return nrx_ldpc_decode_fast_launch((const float*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream);
+  }
+  if constexpr (EXACT) {
+    // float64, hard decisions of the information bits, few enough rows: the whole working set fits on chip
+    if (hard && !belief && out_cols == cfg->K) {
+      const int32_t rc = nrx_ldpc_decode_chip64_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream);
+      if (rc != 1) return rc;      // 1 = no on-chip instantiation for this (bg, Zc, rows): workspace kernel below
+    }
   }
   int zi = -1;
   for (int i = 0; i < 51; ++i)

@@ -15,59 +15,12 @@
 //     in 42 registers;
 //   * min1/min2 by v_min_f32 / v_med3_f32, sign bits shifted in with v_alignbit_b32.
 #include <stdlib.h>
-#include <utility>
-#include "gen_ldpc_bg.h"
+#include "nrx_ldpc_graph.h"
 #include "nrx_common.h"
 
 namespace nrx_dec2 {
+using namespace nrx_ldpc;
 
-constexpr int ZMAX = 384;
-constexpr int NZ = 51;
-constexpr int ESTRIDE = 320;
-
-struct ZList {
-  int16_t z[NZ];
-  int8_t ils[NZ];
-};
-constexpr ZList make_zlist() {
-  ZList l{};
-  int n = 0;
-  for (int z = 2; z <= 384; ++z) {
-    const int base[8] = {2, 3, 5, 7, 9, 11, 13, 15};
-    for (int i = 0; i < 8; ++i)
-      for (int v = base[i]; v <= 384; v *= 2)
-        if (v == z) {
-          l.z[n] = (int16_t)z;
-          l.ils[n] = (int8_t)i;
-          ++n;
-        }
-  }
-  return l;
-}
-constexpr ZList kZ = make_zlist();
-
-template <int BG> struct G;
-template <> struct G<1> {
-  static constexpr int ROWS = NRX_BG1_ROWS, COLS = NRX_BG1_COLS, EDGES = NRX_BG1_EDGES, KB = 22, CORE = 26;
-  static constexpr int row_start(int r) { return kBg1RowStart[r]; }
-  static constexpr int col(int e) { return kBg1Col[e]; }
-  static constexpr int shift(int ils, int e) { return kBg1Shift[ils][e]; }
-};
-template <> struct G<2> {
-  static constexpr int ROWS = NRX_BG2_ROWS, COLS = NRX_BG2_COLS, EDGES = NRX_BG2_EDGES, KB = 10, CORE = 14;
-  static constexpr int row_start(int r) { return kBg2RowStart[r]; }
-  static constexpr int col(int e) { return kBg2Col[e]; }
-  static constexpr int shift(int ils, int e) { return kBg2Shift[ils][e]; }
-};
-
-// The first RA rows of a base graph (RA = all rows: the graph itself).  NR LDPC codes are raptor-like: the code of a
-// higher rate is the sub-matrix of the rows whose extension parity was transmitted; a row whose extension column is
-// punctured (all-zero LLRs) sends +-0 to its other columns, so dropping it changes nothing (nrx_ldpc_decode_rows_*).
-template <int BG, int RA> struct GR : G<BG> {
-  static_assert(RA >= 4 && RA <= G<BG>::ROWS, "active rows out of range");
-  static constexpr int ROWS = RA;
-  static constexpr int EDGES = G<BG>::row_start(RA);
-};
 
 // d4[zi][cls][e]: core edge: byte offset 4*((shift_e - rot_prev) mod Zc) with rot_prev = rotation the column was
 // left in by the previous layer that touched it (cls 0: first iteration, columns start unrotated; cls 1: steady
@@ -162,12 +115,6 @@ template <int BG, int ZI, int RA = G<BG>::ROWS> constexpr WrapTab make_wrap() {
 }
 typedef const uint64_t __attribute__((address_space(4))) * mtab_t;
 
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
-    (f(std::integral_constant<int, I>{}), ...);
-  }(std::make_integer_sequence<int, N>{});
-}
 
 __device__ __forceinline__ float clip10(float x) { return fminf(fmaxf(x, -1e10f), 1e10f); }
 __device__ __forceinline__ float sign_from(uint32_t signsrc, float mag) {  // mag >= 0
@@ -183,96 +130,6 @@ __device__ __forceinline__ uint32_t wrap4(uint32_t a4, uint32_t zc4) {  // a4 in
   return a4 < b ? a4 : b;
 }
 
-// prefetch distance (layers) of the extension-column channel LLRs; must divide the number of extension layers
-// (42 for BG1, 38 for BG2) so that ring slot = ordinal mod PFN stays consistent across iterations
-template <int BG> constexpr int pfn() { return BG == 1 ? 3 : 2; }
-// ... for a truncated graph with n_ext extension layers: the largest ring <= pfn<BG>() that divides n_ext
-template <int BG> constexpr int pfn_for(int n_ext) {
-  for (int k = pfn<BG>(); k > 1; --k)
-    if (n_ext % k == 0) return k;
-  return 1;
-}
-
-template <int BG, int RA = G<BG>::ROWS> struct Lay {  // compile-time layer facts (of the first RA rows)
-  using B = GR<BG, RA>;
-  static constexpr int deg(int L) { return B::row_start(L + 1) - B::row_start(L); }
-  static constexpr bool has_ext(int L) { return B::col(B::row_start(L + 1) - 1) >= B::CORE; }
-  static constexpr int ext_col(int L) { return B::col(B::row_start(L + 1) - 1); }
-  static constexpr bool wide(int L) { return deg(L) > 10; }  // needs a whole 32-bit sign/argmin word
-  static constexpr int n_wide() { int n = 0; for (int l = 0; l < B::ROWS; ++l) n += wide(l) ? 1 : 0; return n; }
-  // slot of layer L among the wide / narrow layers
-  static constexpr int wide_idx(int L) { int n = 0; for (int l = 0; l < L; ++l) n += wide(l) ? 1 : 0; return n; }
-  static constexpr int narrow_idx(int L) { int n = 0; for (int l = 0; l < L; ++l) n += wide(l) ? 0 : 1; return n; }
-  static constexpr int n_narrow() { return B::ROWS - n_wide(); }
-  static constexpr int ext_idx(int L) { int n = 0; for (int l = 0; l < L; ++l) n += has_ext(l) ? 1 : 0; return n; }
-  static constexpr int n_ext() { return ext_idx(B::ROWS); }
-  static constexpr int first_ext() { for (int l = 0; l < B::ROWS; ++l) if (has_ext(l)) return l; return -1; }
-  // Core columns of layer L as a bit mask (every column of a layer is both read and written by it).
-  static constexpr uint32_t core_mask(int L) {
-    uint32_t m = 0;
-    for (int e = B::row_start(L); e < B::row_start(L + 1); ++e)
-      if (B::col(e) < B::CORE) m |= 1u << B::col(e);
-    return m;
-  }
-  // A workgroup barrier is needed before layer L only if L touches a column that some layer since the previous
-  // barrier touched.  Most extension rows of both base graphs meet their neighbour in no core column at all, so
-  // about a third of the barriers go (BG1: 32 of 46 remain).  Steady-state placement, computed over the cyclic
-  // layer order; `barriers_ok` re-checks it from a cold start.
-  // Ping-pong buffers: the k-th layer of an iteration that touches column c reads buffer (k & 1) and writes the other.
-  static constexpr int touch_par(int L, int c) {
-    int k = 0;
-    for (int l = 0; l < L; ++l) k += (core_mask(l) >> c) & 1u;
-    return k & 1;
-  }
-  // columns touched an odd number of times per iteration end up in buffer 1 and are copied back (step ROWS)
-  static constexpr uint32_t odd_mask() {
-    uint32_t m = 0;
-    for (int c = 0; c < B::CORE; ++c) m |= (uint32_t)touch_par(B::ROWS, c) << c;
-    return m;
-  }
-  static constexpr uint32_t step_mask(int s) { return s < B::ROWS ? core_mask(s) : odd_mask(); }
-  // A workgroup barrier goes before step s (layers 0..ROWS-1, then the copy-back) only if s touches a column that
-  // some step since the previous barrier touched: then both hazards between two touchers of a column (the later
-  // one reads what the earlier wrote, and overwrites what the earlier read) are closed, and inside a layer reads and
-  // writes hit different buffers.  Most extension rows meet their neighbours in no core column, so about a third of
-  // the barriers go (BG1: 33 of 47 steps).  Steady-state placement over the cyclic order, re-checked from a cold start.
-  static constexpr int STEPS = B::ROWS + 1;
-  struct BarPlan { bool need[B::ROWS + 1]; bool ok; int count; };
-  static constexpr BarPlan make_plan() {
-    BarPlan p{};
-    uint32_t mask[STEPS] = {};
-    for (int l = 0; l < STEPS; ++l) mask[l] = step_mask(l);
-    uint32_t touched = 0;
-    for (int it = 0; it < 3; ++it)
-      for (int l = 0; l < STEPS; ++l) {
-        const bool need = (mask[l] & touched) != 0;
-        touched = need ? mask[l] : (touched | mask[l]);
-        if (it == 2) p.need[l] = need;
-      }
-    p.ok = true;
-    p.count = 0;
-    touched = 0;   // cold start: the initial fill is followed by a barrier
-    for (int it = 0; it < 3; ++it)
-      for (int l = 0; l < STEPS; ++l) {
-        if (p.need[l]) touched = 0;
-        if (mask[l] & touched) p.ok = false;
-        touched |= mask[l];
-      }
-    for (int l = 0; l < STEPS; ++l) p.count += p.need[l] ? 1 : 0;
-    return p;
-  }
-  static constexpr BarPlan plan = make_plan();
-  static constexpr bool barrier_before(int s) { return plan.need[s]; }
-  static constexpr bool barriers_ok() { return plan.ok; }
-  // the k-th layer (cyclically) with an extension column after layer L
-  static constexpr int next_ext(int L, int k) {
-    int l = L;
-    for (int i = 0; i < k; ++i) {
-      do { l = (l + 1) % B::ROWS; } while (!has_ext(l));
-    }
-    return l;
-  }
-};
 
 // every extension (degree-1 parity) column of both base graphs has shift 0: row z meets element z of its column
 template <int BG> constexpr bool ext_shifts_are_zero() {
@@ -583,11 +440,6 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
   }
 }
 
-constexpr int zindex_c(int zc) {
-  for (int i = 0; i < NZ; ++i)
-    if (kZ.z[i] == zc) return i;
-  return -1;
-}
 
 __constant__ WrapTab kWrap1_384 = make_wrap<1, zindex_c(384)>();
 __constant__ WrapTab kWrap1_352 = make_wrap<1, zindex_c(352)>();

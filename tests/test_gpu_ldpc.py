@@ -281,7 +281,8 @@ def test_punctured_rows_are_exact_no_ops(dev, bg, zc, n_tx_cols):
         part = ops.ldpc_decode(x, cfg, 14, rows=rows)
         more = ops.ldpc_decode(x, cfg, 14, rows=min(rows + 3, rows_all))
         assert torch.equal(full, part) and torch.equal(full, more)
-    if zc <= 128:                                          # the oracle (float64 beliefs of the core columns) agrees
+    if zc <= 128 or (bg == 1 and zc == 384 and rows <= 15):   # the oracle (float64 beliefs of the core columns) agrees;
+                                                           # Zc 384 with <= 15 rows = the on-chip float64 kernel (nrx_ldpc_dec3.hip)
         from oracle import coding as oc
         a = oc.decode(llr[:3], bg, ils, zc, num_iter=14, only_info=False, belief=True)
         b = oc.decode(llr[:3], bg, ils, zc, num_iter=14, only_info=False, belief=True, rows=rows)
