@@ -224,17 +224,20 @@ int32_t nrx_add_noise_f32(const void* x, const void* z, const void* sigma, int32
                           void* out, int32_t n_batch, void* stream);
 int32_t nrx_add_noise_f64(const void* x, const void* z, const void* sigma, int32_t sigma_stride, int64_t n_per,
                           void* out, int32_t n_batch, void* stream);
-/* Throughput-mode AWGN: Philox4x32-10 counter RNG keyed by (seed, stream_id, batch_offset+b, element) +
- * Box-Muller in float64; independent of launch geometry, batch split and GPU count. */
+/* Throughput-mode AWGN: Philox4x32-10 counter RNG keyed by (seed, stream_id, item, element) + Box-Muller in float64;
+ * independent of launch geometry, batch split and GPU count.  item of batch entry b = item_ids[b] when item_ids (nullable,
+ * device int64[n_batch]: e.g. the absolute slot numbers of a non-contiguous slot selection) is given, else batch_offset+b. */
 int32_t nrx_awgn_f32(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out,
-                     int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream);
+                     int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids,
+                     void* stream);
 int32_t nrx_awgn_f64(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out,
-                     int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream);
+                     int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids,
+                     void* stream);
 
 /* Synthetic transport blocks (random.py:202 bits) for the throughput mode: n_batch x n_per uniform bits from the
  * same counter-based generator (independent of launch geometry / batch split / GPU count). */
 int32_t nrx_random_bits(uint8_t* out, int64_t n_per, int32_t n_batch, uint64_t seed, uint64_t stream_id,
-                        int64_t batch_offset, void* stream);
+                        int64_t batch_offset, const int64_t* item_ids, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------ OFDM
  * grid.py:521-582 Grid.ofdmModulate (f0=0) + waveform.py:380-470 applyWindowing: grid rows (n_rows = items*ports,
@@ -250,15 +253,17 @@ int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32
  * offset of item b at t_off[b*t_off_stride]. */
 /* nrx_awgn_* followed by nrx_ofdm_demodulate_* in one pass (throughput mode: the noisy waveform is never written):
  * wave is the NOISELESS received waveform, rows contiguous (wave_stride == wave_len); sigma[item*sigma_stride] and
- * (seed, stream_id, batch_offset) as for nrx_awgn_* over the item's n_ant*wave_len elements.  Identical output. */
+ * (seed, stream_id, batch_offset, item_ids) as for nrx_awgn_* over the item's n_ant*wave_len elements.  Identical output. */
 int32_t nrx_ofdm_demodulate_awgn_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
                                      int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
                                      const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride,
-                                     uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* grid, void* stream);
+                                     uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid,
+                                     void* stream);
 int32_t nrx_ofdm_demodulate_awgn_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
                                      int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
                                      const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride,
-                                     uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* grid, void* stream);
+                                     uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid,
+                                     void* stream);
 /* Grid.precode (wideband F, grid.py:505-516) fused into the modulator's load: layers (n_items, n_layers, n_sym, K),
  * f: per item (f_stride = n_ports*n_layers) or shared (f_stride = 0) n_ports x n_layers; wave rows = item*n_ports+port.
  * Same arithmetic as nrx_precode_* followed by nrx_ofdm_modulate_*; the precoded grid is never materialised.

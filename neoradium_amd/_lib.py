@@ -59,12 +59,12 @@ for _t in ('f32', 'f64'):
         'nrx_mmse_equalize_' + _t: (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
         'nrx_noise_level_' + _t: (i32, [vp, i64, i64, vp, i64, i32, vp, vp, vp, i32, f64, vp, vp, f64, vp]),
         'nrx_add_noise_' + _t: (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
-        'nrx_awgn_' + _t: (i32, [vp, vp, i32, i64, vp, i32, u64_, u64_, i64, vp]),
+        'nrx_awgn_' + _t: (i32, [vp, vp, i32, i64, vp, i32, u64_, u64_, i64, vp, vp]),
         'nrx_ofdm_modulate_' + _t: (i32, [vp, i32, i32, i32, _i32p, i32, i32, vp, i64, vp]),
         'nrx_ofdm_modulate_precoded_' + _t: (i32, [vp, i32, i32, i32, vp, i64, i32, i32, _i32p, i32, i32, vp, i64, vp, vp]),
         'nrx_ofdm_demodulate_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, vp, vp]),
         'nrx_ofdm_demodulate_awgn_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, vp, i32, u64_, u64_,
-                                                 i64, vp, vp]),
+                                                 i64, vp, vp, vp]),
         'nrx_chest_ls_' + _t: (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     })
 for _t in ('f32', 'f64', 'f64o32'):
@@ -75,7 +75,7 @@ SIGNATURES.update({
     'nrx_channel_matrix_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     'nrx_apply_td_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, _i32p, vp, vp]),
     'nrx_apply_td_paths_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, vp, vp, i32, i32, _i32p, vp, vp]),
-    'nrx_random_bits': (i32, [vp, i64, i32, u64_, u64_, i64, vp]),
+    'nrx_random_bits': (i32, [vp, i64, i32, u64_, u64_, i64, vp, vp]),
     'nrx_channel_matrix_sub_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp]),
     'nrx_svd_precoder_f64': (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_effective_channel_f64': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),

@@ -15,17 +15,24 @@ __global__ void fft_tw_init_kernel() {
   }
 }
 
+// One table per device (a __device__ symbol has one address per device); filled on first use on that device.  A failed
+// initialisation (e.g. a synchronisation refused during stream capture) is not remembered: the next call tries again.
 const cx<double>* fft_twiddle_table(hipStream_t stream) {
-  static std::once_flag once;
-  static const cx<double>* table = nullptr;
-  std::call_once(once, [&]() {
+  constexpr int MAX_DEV = 16;
+  static std::mutex mu;
+  static const cx<double>* table[MAX_DEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!table[dev]) {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fft_tw)) != hipSuccess || !p) return;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fft_tw)) != hipSuccess || !p) return nullptr;
     hipLaunchKernelGGL(fft_tw_init_kernel, dim3(FFT_TW_N / 2 / 256), dim3(256), 0, stream);
-    if (hipStreamSynchronize(stream) != hipSuccess) return;   // one-time: later calls may come on any stream
-    table = (const cx<double>*)p;
-  });
-  return table;
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;   // one-time per device: later calls may come on any stream
+    table[dev] = (const cx<double>*)p;
+  }
+  return table[dev];
 }
 
 }  // namespace nrx

@@ -305,25 +305,27 @@ using nrx::philox4x32;
 template <typename T>
 __global__ void __launch_bounds__(256)
 awgn_philox_kernel(const cx<T>* __restrict__ x, const T* __restrict__ sigma, int sigma_stride, int64_t n_per,
-                   cx<T>* __restrict__ out, int n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset) {
+                   cx<T>* __restrict__ out, int n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset,
+                   const int64_t* __restrict__ item_ids) {
   const int64_t total = (int64_t)n_batch * n_per;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(g / n_per);
     const int64_t e = g - (int64_t)b * n_per;
-    out[g] = nrx::awgn_add<T>(x[g], (double)sigma[(size_t)b * sigma_stride], seed, stream_id, (uint64_t)(batch_offset + b), e);
+    out[g] = nrx::awgn_add<T>(x[g], (double)sigma[(size_t)b * sigma_stride], seed, stream_id,
+                               (uint64_t)(item_ids ? item_ids[b] : batch_offset + b), e);
   }
 }
 
 // Synthetic transport blocks for the throughput mode: bit e of item b = one Philox output bit, keyed like awgn.
 __global__ void __launch_bounds__(256)
 random_bits_kernel(uint8_t* __restrict__ out, int64_t n_per, int n_batch, uint64_t seed, uint64_t stream_id,
-                   int64_t batch_offset) {
+                   int64_t batch_offset, const int64_t* __restrict__ item_ids) {
   const int64_t words = (n_per + 127) / 128;  // one Philox call = 128 bits
   const int64_t total = (int64_t)n_batch * words;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(g / words);
     const int64_t w = g - (int64_t)b * words;
-    const uint64_t item = (uint64_t)(batch_offset + b);
+    const uint64_t item = (uint64_t)(item_ids ? item_ids[b] : batch_offset + b);
     uint32_t c[4] = {(uint32_t)w, (uint32_t)((uint64_t)w >> 32), (uint32_t)item, (uint32_t)(item >> 32) ^ (uint32_t)stream_id};
     philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     uint8_t* dst = out + (size_t)b * n_per + w * 128;
@@ -467,24 +469,25 @@ extern "C" int32_t nrx_add_noise_f64(const void* x, const void* z, const void* s
 
 template <typename T>
 static int32_t awgn_entry(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out,
-                          int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) {
+                          int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids,
+                          void* stream) {
   NRX_REQUIRE(x && sigma && out, NRX_E_ARG, "nrx_awgn: NULL buffer");
   if (n_per == 0 || n_batch == 0) return NRX_OK;
   hipLaunchKernelGGL(awgn_philox_kernel<T>, dim3(nrx::stream_grid((long)n_per * n_batch, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const cx<T>*)x, (const T*)sigma, sigma_stride, n_per, (cx<T>*)out, n_batch,
-                     seed, stream_id, batch_offset);
+                     seed, stream_id, batch_offset, item_ids);
   NRX_CHECK_LAUNCH("nrx_awgn");
   return NRX_OK;
 }
-extern "C" int32_t nrx_awgn_f32(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) { return awgn_entry<float>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, stream); }
-extern "C" int32_t nrx_awgn_f64(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* stream) { return awgn_entry<double>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, stream); }
+extern "C" int32_t nrx_awgn_f32(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* stream) { return awgn_entry<float>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, item_ids, stream); }
+extern "C" int32_t nrx_awgn_f64(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out, int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* stream) { return awgn_entry<double>(x, sigma, sigma_stride, n_per, out, n_batch, seed, stream_id, batch_offset, item_ids, stream); }
 
 extern "C" int32_t nrx_random_bits(uint8_t* out, int64_t n_per, int32_t n_batch, uint64_t seed, uint64_t stream_id,
-                                   int64_t batch_offset, void* stream) {
+                                   int64_t batch_offset, const int64_t* item_ids, void* stream) {
   NRX_REQUIRE(out && n_per >= 0 && n_batch >= 0, NRX_E_ARG, "nrx_random_bits: bad argument");
   if (n_per == 0 || n_batch == 0) return NRX_OK;
   hipLaunchKernelGGL(random_bits_kernel, dim3(nrx::stream_grid(((long)n_per + 127) / 128 * n_batch, 256)), dim3(256), 0,
-                     (hipStream_t)stream, out, n_per, n_batch, seed, stream_id, batch_offset);
+                     (hipStream_t)stream, out, n_per, n_batch, seed, stream_id, batch_offset, item_ids);
   NRX_CHECK_LAUNCH("nrx_random_bits");
   return NRX_OK;
 }

@@ -387,11 +387,7 @@ int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int 
   }
   const size_t lds = (size_t)G::CORE * ZMAX * sizeof(T);
   auto kern = ldpc_dec_kernel<T, BG, EXACT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // per device: every launch
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, llr, n_cb, cfg->Zc, n_iter, out_cols, G::COLS - 2,
                      hard, belief, (char*)ws, tab_off, n_rows);
   NRX_CHECK_LAUNCH("nrx_ldpc_decode");

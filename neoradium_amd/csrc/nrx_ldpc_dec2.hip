@@ -15,6 +15,7 @@
 //     in 42 registers;
 //   * min1/min2 by v_min_f32 / v_med3_f32, sign bits shifted in with v_alignbit_b32.
 #include <stdlib.h>
+#include <mutex>
 #include "nrx_ldpc_graph.h"
 #include "nrx_common.h"
 
@@ -473,8 +474,17 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   const int threads = tz * ns;
   const int n_wg = (n_cb + ns - 1) / ns;
   const int grid = n_wg < 1024 ? n_wg : 1024;
-  // device address of the per-(BG) constant table (resolved once per process and device)
-  static const FastTab* base[2] = {nullptr, nullptr};
+  // device addresses of the constant tables: one set per device (a __constant__ symbol has one address per device),
+  // resolved on first use on that device
+  constexpr int MAX_DEV = 16;
+  struct DevTabs { const FastTab* base[2]; const uint64_t* wrap[8]; bool wrap_ok; };
+  static DevTabs tabs[MAX_DEV] = {};
+  static std::mutex mu;
+  int dev = 0;
+  NRX_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEV, NRX_E_HIP, "nrx_ldpc_decode: hipGetDevice failed");
+  std::lock_guard<std::mutex> lock(mu);
+  const FastTab** base = tabs[dev].base;
+  const uint64_t** wrap = tabs[dev].wrap;
   const int bi = cfg->bg - 1;
   if (!base[bi]) {
     void* p = nullptr;
@@ -487,8 +497,7 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
   const int32_t* rh = &base[bi]->rho4[zi][0];
   static const bool no_spec = getenv("NRX_LDPC_NOSPEC") != nullptr;
   static const bool all_rows = getenv("NRX_LDPC_ALLROWS") != nullptr;   // developer switch: ignore n_rows
-  static const uint64_t* wrap[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wrap-mask tables
-  if (!wrap[0]) {
+  if (!tabs[dev].wrap_ok) {
     void* p[8] = {};
     const hipError_t e[8] = {hipGetSymbolAddress(&p[0], HIP_SYMBOL(kWrap1_384)), hipGetSymbolAddress(&p[1], HIP_SYMBOL(kWrap1_352)),
                              hipGetSymbolAddress(&p[2], HIP_SYMBOL(kWrap2_256)), hipGetSymbolAddress(&p[3], HIP_SYMBOL(kWrap1_384_r13)),
@@ -497,6 +506,7 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
     for (int i = 0; i < 8; ++i)
       NRX_REQUIRE(e[i] == hipSuccess && p[i], NRX_E_HIP, "nrx_ldpc_decode: hipGetSymbolAddress(wrap masks) failed");
     for (int i = 7; i >= 0; --i) wrap[i] = (const uint64_t*)p[i];
+    tabs[dev].wrap_ok = true;
   }
   const uint64_t* wt = nullptr;
 #define NRX_DEC2_LAUNCH(BGN, ZIV, NSV, RAV)                                                                               \

@@ -18,6 +18,7 @@
 // No HBM traffic between the initial fill and the hard decisions.  Arithmetic and its order are those of
 // ldpc_dec_kernel<double, BG, true> (which stays the path for every other lifting size / row count and for soft output).
 #include <stdlib.h>
+#include <mutex>
 #include "nrx_ldpc_graph.h"
 #include "nrx_common.h"
 
@@ -282,8 +283,10 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
   if (off || cfg->bg != 1 || cfg->Zc != 384 || cfg->iLS != 1 || n_rows > 15) return 1;
   // device addresses of the wrap-mask tables: per device (a __constant__ symbol has one address per device)
   static DevTab tabs[16] = {};
+  static std::mutex mu;
   int dev = 0;
   NRX_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, NRX_E_HIP, "nrx_ldpc_decode_f64: hipGetDevice failed");
+  std::lock_guard<std::mutex> lock(mu);
   DevTab& dt = tabs[dev];
   if (!dt.ok) {
     void* p[2] = {};

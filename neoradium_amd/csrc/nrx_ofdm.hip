@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(256)
 ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t wave_len,
                   const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
                   cx<T>* __restrict__ grid, int n_tasks, const cx<double>* __restrict__ tw,
-                  const T* __restrict__ sigma, int sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset) {
+                  const T* __restrict__ sigma, int sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset,
+                  const int64_t* __restrict__ item_ids) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
@@ -121,7 +122,8 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
       // sigma != null: the received waveform is noiseless and the AWGN of nrx_awgn_* (same generator, same element
       // numbering: element = antenna * wave_len + sample of the item) is added while loading
       if (sigma && s < wave_len)
-        v = nrx::awgn_add<T>(v, (double)sigma[(size_t)item * sigma_stride], seed, stream_id, (uint64_t)(batch_offset + item),
+        v = nrx::awgn_add<T>(v, (double)sigma[(size_t)item * sigma_stride], seed, stream_id,
+                             (uint64_t)(item_ids ? item_ids[item] : batch_offset + item),
                              (int64_t)(row - item * n_ant) * wave_len + s);
       buf[nrx::fft_idx(i)] = v;
     }
@@ -282,7 +284,7 @@ template <typename T>
 int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride,
                     int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
                     void* grid, void* stream, const void* sigma = nullptr, int32_t sigma_stride = 0, uint64_t seed = 0,
-                    uint64_t stream_id = 0, int64_t batch_offset = 0) {
+                    uint64_t stream_id = 0, int64_t batch_offset = 0, const int64_t* item_ids = nullptr) {
   NRX_REQUIRE(!sigma || wave_stride == wave_len, NRX_E_SHAPE,
               "nrx_ofdm_demodulate_awgn: rows must be contiguous (element numbering of nrx_awgn)");
   NRX_REQUIRE(wave && grid, NRX_E_ARG, "nrx_ofdm_demodulate: NULL buffer");
@@ -303,15 +305,15 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
   const int grid_dim = n_tasks < 4096 ? n_tasks : 4096;
   hipLaunchKernelGGL(kern, dim3(grid_dim), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)wave, wave_stride, wave_len,
                      t_off, t_off_stride, n_ant, K, nfft, ilog2(nfft), g, (cx<T>*)grid, n_tasks, tw, (const T*)sigma,
-                     sigma_stride, seed, stream_id, batch_offset);
+                     sigma_stride, seed, stream_id, batch_offset, item_ids);
   NRX_CHECK_LAUNCH("nrx_ofdm_demodulate");
   return NRX_OK;
 }
 
 }  // namespace
 
-extern "C" int32_t nrx_ofdm_demodulate_awgn_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset); }
-extern "C" int32_t nrx_ofdm_demodulate_awgn_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset); }
+extern "C" int32_t nrx_ofdm_demodulate_awgn_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset, item_ids); }
+extern "C" int32_t nrx_ofdm_demodulate_awgn_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset, item_ids); }
 extern "C" int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<float>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
 extern "C" int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
 extern "C" int32_t nrx_ofdm_modulate_precoded_f32(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); NRX_REQUIRE(tails_ws || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_precoded: windowing needs the tails workspace"); return mod_entry<float>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports, tails_ws); }

@@ -73,7 +73,8 @@ class PdschLink:
                 self.tbs = tbs_all[0]
                 self.port_ks, self.dmrs_syms = ks, [int(v) for v in ds]
             else:
-                assert all(np.array_equal(a, b) for a, b in zip(idx0, pdsch.dataIndices))
+                if not all(np.array_equal(a, b) for a, b in zip(idx0, pdsch.dataIndices)):
+                    raise ValueError("PdschLink: the data RE indices must be the same in every slot of the frame")
         self.carrier.slotNo = saved
         self.templates = D(np.stack(templ))                    # (S, Nl, L, K) complex128
         self.pilots = D(np.stack(pil))                         # (S, P, nDs, nK)
@@ -213,6 +214,9 @@ class PdschLink:
         n = len(slots)
         sis = int(slots[0]) % self.bwp.slotsPerSubFrame
         sif = torch.as_tensor(slots % self.bwp.slotsPerFrame, dtype=torch.int64, device=dev)
+        # device generator keys = the ABSOLUTE slot numbers (a geometry group at mu >= 2 is not a contiguous slot range)
+        contiguous = bool(np.all(np.diff(slots) == 1))
+        ids = None if contiguous else torch.as_tensor(np.asarray(slots, dtype=np.int64), device=dev)
         snr_lin = torch.full((n,), 10.0 ** (float(snr_db) / 10.0), dtype=torch.float64, device=dev) \
             if np.isscalar(snr_db) else D(10.0 ** (np.float64(snr_db) / 10.0))
 
@@ -223,7 +227,7 @@ class PdschLink:
         tbs_in = []
         for q, cw in enumerate(self.cw):
             if tb_bits is None:     # stream ids: 1 = first codeword (as before), 3 = second; 2 is the noise
-                tb = ops.random_bits(n, cw['tbs'], seed, dev, stream_id=1 + 2 * q, batch_offset=int(slots[0]))
+                tb = ops.random_bits(n, cw['tbs'], seed, dev, stream_id=1 + 2 * q, batch_offset=int(slots[0]), item_ids=ids)
             else:
                 tb = (tb_bits[q] if self.numCW > 1 else tb_bits).to(dev).to(torch.uint8).contiguous()
             tbs_in.append(tb)
@@ -252,7 +256,7 @@ class PdschLink:
             rx = ops.apply_channel_fd(grid if self.prg else ops.precode(grid, F), H)
             _, sigma, nv = ops.noise_level(rx, snr_lin=snr_lin)                 # grid.py:1040-1046
             rxg = ops.add_noise(rx, noise.to(dev), sigma) if noise is not None else \
-                ops.awgn(rx, sigma, seed, stream_id=2, batch_offset=int(slots[0]))
+                ops.awgn(rx, sigma, seed, stream_id=2, batch_offset=int(slots[0]), item_ids=ids)
         else:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
@@ -266,7 +270,7 @@ class PdschLink:
             if noise is not None:
                 rxg = ops.ofdm_demodulate(ops.add_noise(ry, noise.to(dev), sigma), self.nfft, cps, self.K, t_off=off)
             else:       # the noise is generated while the demodulator loads its samples (= ops.awgn, then demodulate)
-                rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off, awgn=(sigma, seed, 2, int(slots[0])))
+                rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off, awgn=(sigma, seed, 2, int(slots[0]), ids))
 
         # ---- Rx
         hest = None
@@ -353,7 +357,9 @@ class PdschLink:
             new = tries == 0
             fresh = ops.random_bits(n_proc, self.tbs, seed, dev, stream_id=1, batch_offset=s0)
             state['tb'] = torch.where(new[:, None], fresh, state['tb'])
-            rv = rvs[tries % rvs.numel()].contiguous()
+            # a new block always starts at rv 0 (HarqCW.reset, harq.py:119); rvSequence is consulted for retransmissions only
+            # (harq.py:199, 580-583)
+            rv = torch.where(new, torch.zeros_like(rvs[0]), rvs[tries % rvs.numel()]).contiguous()
             out = self._run_group(slots, snr_db, seed, state['tb'], None, None, False,
                                   harq=(rv, state['circ'], new.to(torch.uint8)))
             ok = out['cb_ok'].reshape(n_proc, cfg.C).to(torch.bool).all(1)

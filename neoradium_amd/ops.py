@@ -19,6 +19,10 @@ _FT = {torch.float32: 'f32', torch.float64: 'f64'}
 def _dev(t):
     if not t.is_cuda:
         raise ValueError("nrx ops need tensors on the GPU (no CPU fallback)")
+    # one process per GPU: launches go to the CURRENT device's stream and libnrx's per-device tables are resolved for the
+    # current device, so a tensor living elsewhere must be refused (torch.cuda.set_device / torch.cuda.device(...) first)
+    if t.device.index != torch.cuda.current_device():
+        raise ValueError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}")
     return t.device
 
 
@@ -383,8 +387,18 @@ def add_noise(x, z, sigma):
     return out
 
 
-def awgn(x, sigma, seed, stream_id=0, batch_offset=0):
-    """x + complex AWGN of std sigma[b] from the counter-based device generator (throughput mode)."""
+def _item_ids(item_ids, n, dev):
+    """Per-item generator keys (absolute slot numbers of a non-contiguous selection): int64 device tensor of n entries."""
+    if item_ids is None:
+        return None
+    if item_ids.dtype != torch.int64 or item_ids.numel() != n or item_ids.device != dev:
+        raise ValueError("item_ids must be an int64 device tensor with one entry per batch item")
+    return item_ids.contiguous()
+
+
+def awgn(x, sigma, seed, stream_id=0, batch_offset=0, item_ids=None):
+    """x + complex AWGN of std sigma[b] from the counter-based device generator (throughput mode), keyed by
+    (seed, stream_id, item, element) with item = item_ids[b] if given else batch_offset + b."""
     x = x.contiguous()
     sfx, rt = _ct(x)
     n = x.shape[0]
@@ -392,7 +406,7 @@ def awgn(x, sigma, seed, stream_id=0, batch_offset=0):
     out = torch.empty_like(x)
     fn = getattr(lib(), 'nrx_awgn_' + sfx)
     check(fn(ptr(x), ptr(sg), 0 if sg.numel() == 1 else 1, x[0].numel(), ptr(out), n, int(seed), int(stream_id),
-             int(batch_offset), stream()))
+             int(batch_offset), ptr(_item_ids(item_ids, n, _dev(x))), stream()))
     return out
 
 
@@ -434,7 +448,7 @@ def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0, f=None):
 def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None):
     """Waveform.sync(t_off).ofdmDemodulate: (n,Nr,S_in) -> (n,Nr,L,K).
 
-    ``awgn`` = (sigma, seed, stream_id, batch_offset): add the noise of :func:`awgn` while loading (same values)."""
+    ``awgn`` = (sigma, seed, stream_id, batch_offset[, item_ids]): add the noise of :func:`awgn` while loading (same values)."""
     wave = wave.contiguous()
     sfx, _ = _ct(wave)
     n, nr, S_in = wave.shape
@@ -447,13 +461,14 @@ def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None):
             raise ValueError("one timing offset per batch item expected")
     grid = torch.empty((n, nr, L, K), dtype=wave.dtype, device=dev)
     if awgn is not None:
-        sigma, seed, stream_id, batch_offset = awgn
+        sigma, seed, stream_id, batch_offset = awgn[:4]
+        ids = _item_ids(awgn[4] if len(awgn) > 4 else None, n, dev)
         _, rt = _ct(wave)
         sg = torch.as_tensor(sigma, dtype=rt, device=dev).reshape(-1).contiguous()
         fn = getattr(lib(), 'nrx_ofdm_demodulate_awgn_' + sfx)
         check(fn(ptr(wave), S_in, S_in, ptr(to), 0 if to is None or to.numel() == 1 else 1, n, nr, K, nfft,
                  _host_i32(cp_lens), L, ptr(sg), 0 if sg.numel() == 1 else 1, int(seed), int(stream_id), int(batch_offset),
-                 ptr(grid), stream()))
+                 ptr(ids), ptr(grid), stream()))
         return grid
     fn = getattr(lib(), 'nrx_ofdm_demodulate_' + sfx)
     check(fn(ptr(wave), S_in, S_in, ptr(to), 0 if to is None or to.numel() == 1 else 1, n, nr, K, nfft,
@@ -711,10 +726,11 @@ def effective_channel_prg(H, F, k2g):
     return out
 
 
-def random_bits(n_batch, n_per, seed, device, stream_id=0, batch_offset=0):
-    """(n_batch, n_per) uniform random bits from the counter-based device generator."""
+def random_bits(n_batch, n_per, seed, device, stream_id=0, batch_offset=0, item_ids=None):
+    """(n_batch, n_per) uniform random bits from the counter-based device generator (keyed like :func:`awgn`)."""
     out = torch.empty((n_batch, n_per), dtype=torch.uint8, device=device)
-    check(lib().nrx_random_bits(ptr(out), n_per, n_batch, int(seed), int(stream_id), int(batch_offset), stream()))
+    check(lib().nrx_random_bits(ptr(out), n_per, n_batch, int(seed), int(stream_id), int(batch_offset),
+                                ptr(_item_ids(item_ids, n_batch, out.device)), stream()))
     return out
 
 

@@ -12,8 +12,19 @@ from . import coding as oc
 from . import phy as op
 
 
-def static_from_link(link):
-    """Plain-array description of a configured neoradium_amd.engine.PdschLink (host data only, no GPU results)."""
+class _GainTimes:
+    """Picklable slot -> (L+1,) gain instants table (the sharded CPU baseline ships `static` to worker processes)."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, slot):
+        return self.table[int(slot)]
+
+
+def static_from_link(link, slots=None):
+    """Plain-array description of a configured neoradium_amd.engine.PdschLink (host data only, no GPU results).
+    ``slots``: tabulate the gain instants of these slots, so that the result holds no reference to the link."""
     ch = link.channel
     A, nu, Alos, nulos = ch.staticCoefficients()
     s = ch._normalisation()
@@ -26,7 +37,31 @@ def static_from_link(link):
         A=A * s, nu=nu, Alos=None if Alos is None else Alos * s, nulos=nulos, coeff=ch.getCoeffMatrix(),
         max_delay=link.max_delay, first_prb=link.first_prb, num_iter=link.numIter, freq_domain=link.freqDomain,
         perfect=link.chanEst == "Perfect", window=link.window != "NONE",
-        gain_times=lambda slot: link.gain_times([slot])[0])
+        gain_times=(lambda slot: link.gain_times([slot])[0]) if slots is None else
+        _GainTimes({int(s): link.gain_times([int(s)])[0] for s in slots}))
+
+
+def _job(args):
+    st, slot, snr_db, tb, z, F = args
+    return run_slot(st, slot, snr_db, tb, z, F=F)
+
+
+def run_slots_parallel(jobs, n_procs):
+    """bench.py's sharded CPU baseline (SURVEY 8d leg b): one job = the argument tuple of :func:`run_slot`, one
+    single-threaded process per host core.  The workers are started with "spawn" and import NumPy + oracle/ only."""
+    import multiprocessing as mp
+    import os
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+    os.environ.update({k: '1' for k in saved})            # inherited by the children: one thread per process
+    try:
+        with mp.get_context('spawn').Pool(n_procs) as pool:
+            return pool.map(_job, jobs, chunksize=1)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def run_slot(st, slot, snr_db, tb, z, F=None):

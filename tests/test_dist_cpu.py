@@ -99,3 +99,31 @@ def test_sharded_sweep_world2_equals_single_process():
     assert [r[2] for r in res] == [(100, 19), (119, 18)]
     for _, table, _ in res:
         assert table == want
+
+
+def test_bench_gpus2_self_launch_gloo():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (torch.distributed.run children), each rank
+    takes its own slot range, the counters are all-reduced and rank 0 prints ONE JSON line with n_gpus == 2.  Runs the
+    real bench.py code path (launcher, rank bookkeeping, timed_steps, collectives) on the host: gloo backend + the
+    --stub link (no GPU here)."""
+    import json
+    import subprocess
+    env = dict(os.environ, NRX_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '8',
+                        '--stub', '--no-cpu'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    # both ranks' slot ranges counted: 2 ranks x 3 steps x 8 slots x 72 code blocks
+    assert out['bler']['blocks'] == 2 * 3 * 8 * 72
+    slots = np.concatenate([np.arange(r_ * 4 * 8 + 8, (r_ + 1) * 4 * 8) for r_ in range(2)])      # timed slots of each rank
+    assert out['bler']['block_errors'] == int(((slots * 2654435761 + 123) % 97 < 13).sum() * 3)
+    # a launcher whose world size contradicts --gpus is an error, not a silent single-GPU run
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub', '--no-cpu'], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and 'WORLD_SIZE' in r2.stderr

@@ -239,6 +239,28 @@ def test_engine_throughput_mode_properties(dev):
     assert np.array_equal(mid_all, mid_split)
 
 
+def test_engine_batch_split_invariance_at_60khz(dev):
+    """mu = 2: the slots of a batch fall into two geometry groups that interleave ({0,2,..} carry the long-CP symbol,
+    {1,3,..} do not).  The device generator is keyed by the ABSOLUTE slot number of every item, so every slot gets its own
+    transport block and noise, and the counters do not depend on how the range is batched or sharded."""
+    import neoradium_amd as nr
+    cfg = dict(seed=5, numRbs=20, spacing=60, mod='16QAM', layers=1, dm=dict(configType=1, additionalPos=1),
+               chan=('cdl', 'C', 30, 5, [1, 1], [1, 1]), slot0=0)
+    car, bwp, p, ch = _slot(nr, cfg)
+    link = nr.PdschLink(p, ch, 0.5, numIter=8, decoder="f64")
+    assert len({tuple(v) for v in link.sym_lens}) == 2                 # two slot geometries per subframe
+    _, det = link.run(2, 8, 9.0, seed=3, details=True)
+    tbs = np.empty((8, link.tbs), dtype=np.uint8)
+    for sel, d in det:
+        tbs[sel] = d['tb'].cpu().numpy()
+    assert len({t.tobytes() for t in tbs}) == 8                        # eight slots, eight different transport blocks
+    whole = link.run(2, 8, 9.0, seed=3).cpu().numpy()
+    split = (link.run(2, 3, 9.0, seed=3) + link.run(5, 1, 9.0, seed=3) + link.run(6, 4, 9.0, seed=3)).cpu().numpy()
+    assert np.array_equal(whole, split) and 0 < whole[0] < whole[1]    # a point on the waterfall: both outcomes occur
+    one = link.run(7, 1, 9.0, seed=3, details=True)[1][0][1]['tb'].cpu().numpy()[0]
+    assert np.array_equal(one, tbs[5])                                 # slot 7 alone = slot 7 inside the batch
+
+
 def test_engine_batched_harq(dev):
     """PdschLink.run_harq (BASELINE cfg5: HARQ-IR, 4 redundancy versions, soft buffers resident on the GPU): the
     HarqEntity bookkeeping identities hold, combining helps (blocks that fail the first try decode on a later one),
