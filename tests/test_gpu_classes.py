@@ -254,9 +254,13 @@ def test_engine_batch_split_invariance_at_60khz(dev):
     for sel, d in det:
         tbs[sel] = d['tb'].cpu().numpy()
     assert len({t.tobytes() for t in tbs}) == 8                        # eight slots, eight different transport blocks
-    whole = link.run(2, 8, 9.0, seed=3).cpu().numpy()
-    split = (link.run(2, 3, 9.0, seed=3) + link.run(5, 1, 9.0, seed=3) + link.run(6, 4, 9.0, seed=3)).cpu().numpy()
-    assert np.array_equal(whole, split) and 0 < whole[0] < whole[1]    # a point on the waterfall: both outcomes occur
+    errs = []
+    for snr in (-2.0, 2.0, 5.0, 9.0):                                  # across the waterfall: the noise draws matter
+        whole = link.run(2, 8, snr, seed=3).cpu().numpy()
+        split = (link.run(2, 3, snr, seed=3) + link.run(5, 1, snr, seed=3) + link.run(6, 4, snr, seed=3)).cpu().numpy()
+        assert np.array_equal(whole, split) and whole[1] == 8 * link.cfg.C
+        errs.append(int(whole[2]))
+    assert errs[0] > 0 and errs[-1] == 0
     one = link.run(7, 1, 9.0, seed=3, details=True)[1][0][1]['tb'].cpu().numpy()[0]
     assert np.array_equal(one, tbs[5])                                 # slot 7 alone = slot 7 inside the batch
 
