@@ -137,6 +137,19 @@ int32_t nrx_ldpc_decode_rows_f32(const float* llr, int32_t n_cb, const nrx_ldpc_
 int32_t nrx_ldpc_decode_rows_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
                                  uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ldpc.py:1330-1418 recoverRate (first transmission: rv 0, no HARQ soft buffer, no LBRM, no wrap-around repetition)
+ * + ldpc.py:1495-1581 decode + ldpc.py:1584-1619 checkCrcAndMerge (C > 1: CRC24B per code block) in ONE launch (SURVEY 7
+ * step 4): the decoder's initial fill gathers the de-interleaved LLRs straight from the demapper output
+ * llr (n_tb, llr_len = G), fillers become the clipped LARGE_LLR in-register, and its tail writes the merged hard bits
+ * tb_out (n_tb, C*(cb_len-24)) and the per-code-block CRC verdicts cb_ok (n_tb*C); the (n_tb*C, N) rate-recovered LLRs and
+ * the (n_tb*C, K) hard-bit matrix never exist in HBM.  Results are bit-identical to nrx_ldpc_rate_recover_f64 ->
+ * nrx_ldpc_decode_rows_f64 -> nrx_ldpc_crc_merge.  n_rows: rows of the base graph to run (0 = as many as the received
+ * bits reach; raised to that number when smaller).  Returns NRX_E_UNSUPPORTED when (bg, Zc, C, rows) has no fused
+ * instantiation (today: BG1, Zc 384, C > 1, <= 15 rows): the caller then uses the three separate entries. */
+int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                          int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                          uint8_t* cb_ok, void* stream);
+
 /* ldpc.py:1584-1619 checkCrcAndMerge (+ the TB-level checkCrc('24A') the harness applies).
  * dec: (n_tb*C) x K hard bits.  tb_out (nullable): n_tb x M bits, M = C*(cb_len - 24) for C>1 (>= B: the TB incl.
  * its CRC24A followed by the segmentation zero padding, exactly what the reference returns), M = B for C==1.

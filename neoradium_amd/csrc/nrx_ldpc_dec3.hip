@@ -17,6 +17,7 @@
 //     load fetches from a constant table.
 // No HBM traffic between the initial fill and the hard decisions.  Arithmetic and its order are those of
 // ldpc_dec_kernel<double, BG, true> (which stays the path for every other lifting size / row count and for soft output).
+#include <stddef.h>
 #include <stdlib.h>
 #include <mutex>
 #include "nrx_ldpc_graph.h"
@@ -66,10 +67,69 @@ template <int BG> constexpr bool ext_shifts_are_zero() {
   return true;
 }
 
+// ---- CRC24B over GF(2) (chancodebase.py:37-44, 83-128), usable at compile time
+constexpr uint32_t CRC24B_LOW = 0x800063u;
+constexpr uint32_t gf2_mulmod24(uint32_t a, uint32_t b) {      // (a * b) mod g, degrees < 24
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; --i) {
+    const uint32_t top = (r >> 23) & 1u;
+    r = ((r << 1) & 0xFFFFFFu) ^ (top ? CRC24B_LOW : 0u);
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r;
+}
+constexpr uint32_t gf2_xpow24(uint32_t e) {                    // x^e mod g
+  uint32_t result = 1u, base = 2u;
+  while (e) {
+    if (e & 1u) result = gf2_mulmod24(result, base);
+    base = gf2_mulmod24(base, base);
+    e >>= 1;
+  }
+  return result;
+}
+// a * K mod g for a compile-time K: xor of the precomputed K * x^i mod g over the set bits of a
+template <uint32_t K> __device__ __forceinline__ uint32_t gf2_mulc24(uint32_t a) {
+  uint32_t r = 0;
+  static_for<24>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr uint32_t ki = gf2_mulmod24(K, gf2_xpow24(i));
+    r ^= (0u - ((a >> i) & 1u)) & ki;
+  });
+  return r;
+}
+
+// Fused front and back: rate recovery (ldpc.py:1330-1418, first transmission: rv 0, empty soft buffer,
+// no wrap-around repetition) is done by the initial fill, which gathers the de-interleaved LLRs straight from the
+// demapper's (n_tb, llr_len) output; the code-block CRC24B check and the merge into the transport block
+// (ldpc.py:1584-1619) are done by the tail.  Geometry as nrx_ldpc_enc.hip's RmGeom.
+struct FuseGeom {
+  int C, e_small, n_small, f, qm, sys_len, F, llr_len, cb_len, payload;
+};
+struct FuseArgs {
+  FuseGeom g;
+  uint8_t* tb_out;
+  uint8_t* cb_ok;
+};
+// The kernel reads FuseArgs through the kernarg segment pointer at the two places that need it (initial fill, tail)
+// instead of through its parameter: as a parameter its ten scalars and two pointers stay live across the whole layer
+// loop, and at 168 VGPRs / 106 SGPRs that pushed 99 scratch accesses INTO the loop.
+struct KernArgs {
+  const double* llr; int n_cb; int n_iter; uint8_t* hard; const uint64_t* wtab; FuseArgs fa;
+};
+typedef const FuseArgs __attribute__((address_space(4))) * fargs_t;
+__device__ __forceinline__ fargs_t fuse_args() {
+  const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  return (fargs_t)(ka + offsetof(KernArgs, fa));
+}
+
 // NS = 2 code blocks per workgroup (2 x Zc/64 waves).  Lane z of a code block's waves = check row z of every layer.
-template <int BG, int ZI, int RA>
+// FUSED = false: llr = rate-recovered LLRs (n_cb, N), hard = (n_cb, K) hard decisions.
+// FUSED = true:  llr = demapper output (n_tb, llr_len), tb_out = (n_tb, C*payload) merged hard bits, cb_ok = (n_cb,).
+template <int BG, int ZI, int RA, bool FUSED>
 __global__ void __launch_bounds__(2 * kZ.z[ZI], 3)
-ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint8_t* __restrict__ hard, mtab_t wtab) {
+ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint8_t* __restrict__ hard, mtab_t wtab,
+                       FuseArgs /* read through fuse_args() */) {
   static_assert(ext_shifts_are_zero<BG>(), "extension columns are expected to be unshifted");
   using B = GR<BG, RA>;
   using Y = Lay<BG, RA>;
@@ -106,17 +166,44 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     int one = 1;
     asm volatile("" : "+s"(one));                          // keeps the per-layer `if (live)` a real branch (see dec2)
     const bool live = cb < n_cb && one != 0;
-    const double* in = llr + (size_t)(live ? cb : n_cb - 1) * N;
-    // ---- load: clip, prepend the two punctured columns as zeros (ldpc.py:1536-1538); + 0.0 turns -0.0 into +0.0
+    const int cbq = live ? cb : n_cb - 1;                   // (a wave without a code block loads an existing one)
+    const double* in = FUSED ? llr : llr + (size_t)cbq * N;
+    int fE = 0, feq = 1, foff = 0;                         // FUSED: E_r, E_r / Qm, offset of the block in the LLR stream
+    FuseGeom fg{};
+    if constexpr (FUSED) {
+      const fargs_t fa = fuse_args();
+      fg.C = fa->g.C; fg.e_small = fa->g.e_small; fg.n_small = fa->g.n_small; fg.f = fa->g.f; fg.qm = fa->g.qm;
+      fg.sys_len = fa->g.sys_len; fg.F = fa->g.F; fg.llr_len = fa->g.llr_len;
+      const int t = cbq / fg.C, r = cbq - t * fg.C;
+      if (r < fg.n_small) { fE = fg.e_small; foff = r * fg.e_small; }
+      else { fE = fg.e_small + fg.f; foff = fg.n_small * fg.e_small + (r - fg.n_small) * fE; }
+      feq = fE / fg.qm;
+      in = llr + (size_t)t * fg.llr_len;
+    }
+    // element p of the rate-recovered (punctured) code word, clipped like ldpc.py:1536; + 0.0 turns -0.0 into +0.0
+    auto fetch = [&](int p) __attribute__((always_inline)) -> double {
+      if constexpr (!FUSED) {
+        return clip10(in[p]) + 0.0;
+      } else {
+        if (p >= fg.sys_len && p < fg.sys_len + fg.F) return 1e10;        // filler: LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
+        const int ci = p < fg.sys_len ? p : p - fg.F;                     // position in the circular buffer (no fillers)
+        if (ci >= fE) return 0.0;                                         // not transmitted
+        const int q = ci / feq;
+        const int src = foff + (ci - q * feq) * fg.qm + q;                // de-interleave: x[e] = rx[(e mod E/Qm)*Qm + e div (E/Qm)]
+        return src < fg.llr_len ? clip10(in[src]) + 0.0 : 0.0;            // short input is zero padded (ldpc.py:1401-1402)
+      }
+    };
+    // ---- load: prepend the two punctured columns as zeros (ldpc.py:1536-1538)
     static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value;
-      Ps[c * ZS + z] = (c < 2) ? 0.0 : clip10(in[(c - 2) * ZC + z]) + 0.0;
+      if constexpr (c < 2) Ps[c * ZS + z] = 0.0;
+      else Ps[c * ZS + z] = fetch((c - 2) * ZC + z);
     });
     static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
       constexpr int L = decltype(lc)::value;
       m1[L] = 0.0;
       m2[L] = 0.0;
-      if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = clip10(in[(Y::ext_col(L) - 2) * ZC + z]) + 0.0;
+      if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC + z);
     });
     static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
     static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
@@ -257,11 +344,47 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     __syncthreads();
 
     // ---- hard decisions of the information columns (ldpc.py:1578-1581)
-    if (live) {
+    if constexpr (!FUSED) {
+      if (live) {
+        static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
+          constexpr int c = decltype(cc)::value;
+          hard[(size_t)cb * K + c * ZC + z] = Ps[c * ZS + z] < 0.0 ? 1 : 0;
+        });
+      }
+    } else {
+      // ... merged into the transport block (fillers and the code-block CRC stripped, ldpc.py:1600-1619), and the CRC24B
+      // check of the block: bit n = c*Zc + z contributes x^((KB-1-c)*Zc + (Zc-1-z)) mod g, i.e. lane z xors the
+      // compile-time constants x^((KB-1-c)*Zc) of its set bits and the lanes are then joined as a polynomial in x
+      // (lane z weighs x^(Zc-1-z)).  The common factor x^(...) against the reference's long division (chancodebase.py:
+      // 119-128) is invertible mod g, so the remainder is zero for exactly the same bit strings.
+      uint32_t v = 0;
+      const int cbm = live ? cb : 0;
+      const fargs_t fa = fuse_args();
+      const int payload = fa->g.payload, cb_len = fa->g.cb_len;
+      uint8_t* dst = fa->tb_out + (size_t)cbm * payload;   // (t*C + r) * payload
       static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        hard[(size_t)cb * K + c * ZC + z] = Ps[c * ZS + z] < 0.0 ? 1 : 0;
+        constexpr uint32_t w = gf2_xpow24((uint32_t)((B::KB - 1 - c) * ZC));
+        const int n = c * ZC + z;
+        const uint32_t bit = Ps[c * ZS + z] < 0.0 ? 1u : 0u;
+        if (live && n < payload) dst[n] = (uint8_t)bit;
+        v ^= (n < cb_len && bit) ? w : 0u;
       });
+      // join inside the wave: level k pairs blocks of 2^k lanes, left * x^(2^k) + right
+      static_for<6>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const uint32_t other = (uint32_t)__shfl_xor((int)v, 1 << k, 64);
+        const bool upper = (z >> k) & 1;
+        v = gf2_mulc24<gf2_xpow24(1u << k)>(upper ? other : v) ^ (upper ? v : other);
+      });
+      uint32_t* red = (uint32_t*)Praw;                      // the padding in front of the columns is never addressed
+      if ((z & 63) == 0) red[slot * (ZC / 64) + (z >> 6)] = v;
+      __syncthreads();
+      if (z == 0 && live) {
+        uint32_t tot = 0;
+        for (int w = 0; w < ZC / 64; ++w) tot = gf2_mulc24<gf2_xpow24(64)>(tot) ^ red[slot * (ZC / 64) + w];
+        fa->cb_ok[cb] = tot == 0 ? 1 : 0;
+      }
     }
     __syncthreads();
   }
@@ -272,16 +395,8 @@ __constant__ WrapTab kWrap1_384_r15 = make_wrap<1, zindex_c(384), 15>();
 
 struct DevTab { const uint64_t* p[2]; bool ok; };
 
-}  // namespace nrx_dec3
-
-// Called by nrx_ldpc_decode_rows_f64 (nrx_ldpc_dec.hip) for hard decisions of the K information bits.
-// Returns 1 when no on-chip instantiation covers (bg, Zc, n_rows): the caller then runs the workspace kernel.
-int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                      int32_t n_rows, uint8_t* hard, hipStream_t st) {
-  using namespace nrx_dec3;
-  static const bool off = getenv("NRX_LDPC_NOCHIP64") != nullptr;      // developer switch: always the workspace kernel
-  if (off || cfg->bg != 1 || cfg->Zc != 384 || cfg->iLS != 1 || n_rows > 15) return 1;
-  // device addresses of the wrap-mask tables: per device (a __constant__ symbol has one address per device)
+// wrap-mask table of the instantiation that serves n_rows (13 or 15 rows), resolved per device
+int32_t wrap_table(int n_rows, const uint64_t** out) {
   static DevTab tabs[16] = {};
   static std::mutex mu;
   int dev = 0;
@@ -296,13 +411,80 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
     for (int i = 0; i < 2; ++i) dt.p[i] = (const uint64_t*)p[i];
     dt.ok = true;
   }
+  *out = dt.p[n_rows <= 13 ? 0 : 1];
+  return NRX_OK;
+}
+
+bool chip64_covers(const nrx_ldpc_cfg* cfg, int n_rows) {
+  static const bool off = getenv("NRX_LDPC_NOCHIP64") != nullptr;      // developer switch: always the workspace kernel
+  return !off && cfg->bg == 1 && cfg->Zc == 384 && cfg->iLS == 1 && n_rows <= 15;
+}
+
+}  // namespace nrx_dec3
+
+// Called by nrx_ldpc_decode_rows_f64 (nrx_ldpc_dec.hip) for hard decisions of the K information bits.
+// Returns 1 when no on-chip instantiation covers (bg, Zc, n_rows): the caller then runs the workspace kernel.
+int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                      int32_t n_rows, uint8_t* hard, hipStream_t st) {
+  using namespace nrx_dec3;
+  if (!chip64_covers(cfg, n_rows)) return 1;
+  const uint64_t* wt = nullptr;
+  const int32_t rc = wrap_table(n_rows, &wt);
+  if (rc) return rc;
   const int n_wg = (n_cb + 1) / 2;
   const int grid = n_wg < 1024 ? n_wg : 1024;
   constexpr int ZI384 = zindex_c(384);
+  const FuseArgs fa{};
   if (n_rows <= 13)
-    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 13>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard, (mtab_t)dt.p[0]);
+    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 13, false>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard, (mtab_t)wt, fa);
   else
-    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 15>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard, (mtab_t)dt.p[1]);
+    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 15, false>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard, (mtab_t)wt, fa);
   NRX_CHECK_LAUNCH("nrx_ldpc_decode_f64(on-chip)");
+  return NRX_OK;
+}
+
+// ldpc.py:1330-1418 recoverRate (first transmission) + :1495-1581 decode + :1584-1619 checkCrcAndMerge in ONE launch.
+// NRX_E_UNSUPPORTED when the configuration has no fused instantiation: the caller runs the three separate entries.
+extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                                     int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                                     uint8_t* cb_ok, void* stream) {
+  using namespace nrx_dec3;
+  NRX_REQUIRE(llr && cfg && tb_out && cb_ok, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: NULL buffer");
+  NRX_REQUIRE(nl >= 1 && qm >= 1 && llr_len > 0 && n_tb >= 0 && n_iter >= 0, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: bad argument");
+  const int f = nl * qm, gb = (llr_len + f - 1) / f;
+  NRX_REQUIRE(cfg->C >= 1 && gb / cfg->C > 0, NRX_E_SHAPE, "nrx_ldpc_recover_decode_merge: G=%d too small for %d code blocks", llr_len, cfg->C);
+  FuseArgs fa;
+  fa.tb_out = tb_out;
+  fa.cb_ok = cb_ok;
+  FuseGeom& fg = fa.g;
+  fg.C = cfg->C; fg.f = f; fg.qm = qm; fg.F = cfg->F; fg.llr_len = llr_len; fg.cb_len = cfg->cb_len;
+  fg.e_small = (gb / cfg->C) * f;
+  fg.n_small = cfg->C - gb % cfg->C;
+  fg.sys_len = cfg->K - 2 * cfg->Zc - cfg->F;
+  fg.payload = cfg->cb_len - 24;
+  const int e_max = fg.e_small + (fg.n_small < cfg->C ? f : 0);
+  // the rows that can matter for e_max received bits (as ops.ldpc_active_rows): never fewer than the caller asks for
+  const int last = e_max - 1 + (e_max > fg.sys_len ? cfg->F : 0);
+  int need = last / cfg->Zc + 2 - 26 + 1 + 4;
+  if (need < 4) need = 4;
+  if (n_rows < need) n_rows = need;
+  if (cfg->C < 2 || cfg->cb_len <= 24 || e_max > cfg->N - cfg->F || fg.e_small % qm || (fg.e_small + f) % qm || !chip64_covers(cfg, n_rows)) {
+    ::nrx::set_error("nrx_ldpc_recover_decode_merge: no fused instantiation for bg %d Zc %d C %d rows %d", cfg->bg, cfg->Zc, cfg->C, n_rows);
+    return NRX_E_UNSUPPORTED;
+  }
+  if (n_tb == 0) return NRX_OK;
+  const uint64_t* wt = nullptr;
+  const int32_t rc = wrap_table(n_rows, &wt);
+  if (rc) return rc;
+  const int n_cb = n_tb * cfg->C;
+  const int n_wg = (n_cb + 1) / 2;
+  const int grid = n_wg < 1024 ? n_wg : 1024;
+  constexpr int ZI384 = zindex_c(384);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows <= 13)
+    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 13, true>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa);
+  else
+    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 15, true>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa);
+  NRX_CHECK_LAUNCH("nrx_ldpc_recover_decode_merge_f64");
   return NRX_OK;
 }

@@ -293,6 +293,16 @@ class PdschLink:
             ccfg = cw['cfg']
             llr = ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
                                 exact=not self.useMax, llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64)
+            fused = None
+            if harq is None and self.firstPassIter is None and self.decoder == "f64" and cw['rows'] is not None:
+                # rate recovery + decode + CRC/merge in one launch where an instantiation exists (same bits)
+                fused = ops.ldpc_recover_decode_merge(llr, ccfg, cw['nl'], cw['qm'], self.numIter, rows=cw['rows'])
+            if fused is not None:
+                tb_out, cb_ok = fused
+                if counters is not None:
+                    ops.count_errors(cb_ok, tb_out, tbs_in[q], counters)
+                per_cw.append(dict(tb=tbs_in[q], cb_ok=cb_ok, tb_out=tb_out, llr=llr))
+                continue
             if harq is None:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'])
             else:

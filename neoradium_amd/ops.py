@@ -186,6 +186,28 @@ def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False, rows=None):
     return bel if belief else hard
 
 
+def ldpc_recover_decode_merge(llr, cfg, nl, qm, n_iter, rows=0):
+    """recoverRate (first transmission) + decode + checkCrcAndMerge in one launch (nrx_ldpc_recover_decode_merge_f64):
+    (n_tb, G) float64 demapper LLRs -> (tb_out (n_tb, C*(cb_len-24)), cb_ok (n_tb, C)), bit-identical to
+    ldpc_rate_recover -> ldpc_decode(rows=...) -> ldpc_crc_merge.  Returns None when this configuration has no fused
+    instantiation (the caller then runs the three separate stages)."""
+    if llr.dtype != torch.float64 or llr.dim() != 2:
+        return None
+    if not (cfg.bg == 1 and cfg.Zc == 384 and cfg.C > 1):          # (cheap pre-check; the library decides)
+        return None
+    llr = llr.contiguous()
+    n_tb, G = llr.shape
+    dev = _dev(llr)
+    tb_out = torch.empty((n_tb, cfg.C * (cfg.cb_len - 24)), dtype=torch.uint8, device=dev)
+    cb_ok = torch.empty((n_tb, cfg.C), dtype=torch.uint8, device=dev)
+    rc = lib().nrx_ldpc_recover_decode_merge_f64(ptr(llr), n_tb, G, C.byref(cfg), nl, qm, int(n_iter), int(rows or 0),
+                                                 ptr(tb_out), ptr(cb_ok), stream())
+    if rc == -3:                                                   # NRX_E_UNSUPPORTED
+        return None
+    check(rc)
+    return tb_out, cb_ok
+
+
 def ldpc_crc_merge(dec, cfg, want_tb=True, want_tb_crc=True):
     """ldpc.py:1584-1619 checkCrcAndMerge (+ TB CRC24A check): (n_tb*C, K) -> tb_out (n_tb,M>=B), cb_ok (n_tb,C), tb_ok."""
     dec = _u8(dec)

@@ -292,3 +292,46 @@ def test_punctured_rows_are_exact_no_ops(dev, bg, zc, n_tx_cols):
         ops.ldpc_decode(torch.from_numpy(llr).to(dev), cfg, 5, rows=3)
     with pytest.raises(ValueError):
         ops.ldpc_decode(torch.from_numpy(llr).to(dev), cfg, 5, rows=rows, belief=True)
+
+
+@pytest.mark.parametrize("tbs,qm,nl,g_extra", [(25000, 6, 4, 0), (25000, 6, 4, 7), (33000, 4, 2, 3), (16700, 8, 1, 0)])
+def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_extra):
+    """nrx_ldpc_recover_decode_merge_f64 (initial fill = rate recovery gathering straight from the demapper LLRs, tail =
+    CRC24B check + merge) against the three separate entries on the same LLRs: transport block bits and CRC verdicts
+    identical -- with unequal E_r across the code blocks (g_extra), filler bits (F > 0), partly filled last columns,
+    blocks that converge and blocks that do not, and a slot batch that leaves a lone code block in the last workgroup."""
+    import torch
+    from neoradium_amd import ops, _lib
+    cfg = _lib.ldpc_config(1, tbs + 24)
+    assert cfg.Zc == 384 and cfg.C > 1 and cfg.F > 0
+    n_tb = 3
+    rng = np.random.default_rng(tbs + qm)
+    # about 15 rows' worth of bits per code block, E_r = multiples of nl*qm, the last g_extra blocks one step longer
+    e_small = (13000 // (nl * qm)) * (nl * qm)
+    G = cfg.C * e_small + g_extra * nl * qm
+    lens = _lib.ldpc_cb_lens(G, cfg.C, nl, qm)
+    assert sum(lens) == G and (g_extra == 0 or len(set(lens)) == 2)
+    tb = torch.from_numpy(rng.integers(0, 2, (n_tb, tbs)).astype(np.uint8)).to(dev)
+    coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+    bits = ops.ldpc_rate_match(coded, cfg, G, nl, qm).cpu().numpy().astype(np.float64)
+    sig = np.array([0.5, 0.78, 1.1])[:, None]               # one clean, one marginal, one hopeless transport block
+    llr = (2 / sig ** 2) * ((1 - 2 * bits) + sig * rng.standard_normal(bits.shape))
+    llr[rng.random(llr.shape) < 0.001] = 0.0
+    x = torch.from_numpy(llr).to(dev)
+    rows = ops.ldpc_active_rows(cfg, max(lens))
+    assert rows <= 15
+    rr = ops.ldpc_rate_recover(x, cfg, nl, qm)
+    dec = ops.ldpc_decode(rr, cfg, 12, rows=rows)
+    tb_ref, ok_ref, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
+    got = ops.ldpc_recover_decode_merge(x, cfg, nl, qm, 12, rows=rows)
+    assert got is not None, "no fused instantiation for BG1 / Zc 384 / <= 15 rows"
+    tb_out, ok = got
+    assert torch.equal(ok, ok_ref) and torch.equal(tb_out, tb_ref)
+    n_ok = int(ok.sum())
+    assert 0 < n_ok < ok.numel(), f"want both outcomes, got {n_ok}/{ok.numel()} passing"
+    # rows = 0: the library works the row count out itself
+    tb2, ok2 = ops.ldpc_recover_decode_merge(x, cfg, nl, qm, 12, rows=0)
+    assert torch.equal(ok2, ok_ref) and torch.equal(tb2, tb_ref)
+    # unsupported configurations are reported, not approximated: Zc 352
+    cfg2 = _lib.ldpc_config(1, 7500 * 3)
+    assert cfg2.Zc != 384 and ops.ldpc_recover_decode_merge(x[:, :cfg2.C * 1200], cfg2, nl, qm, 5) is None
