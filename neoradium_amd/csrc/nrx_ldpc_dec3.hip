@@ -104,6 +104,7 @@ template <uint32_t K> __device__ __forceinline__ uint32_t gf2_mulc24(uint32_t a)
 // (ldpc.py:1584-1619) are done by the tail.  Geometry as nrx_ldpc_enc.hip's RmGeom.
 struct FuseGeom {
   int C, e_small, n_small, f, qm, sys_len, F, llr_len, cb_len, payload;
+  uint32_t qm_magic;   // ceil(2^32 / qm)
 };
 struct FuseArgs {
   FuseGeom g;
@@ -185,25 +186,69 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       if constexpr (!FUSED) {
         return clip10(in[p]) + 0.0;
       } else {
-        if (p >= fg.sys_len && p < fg.sys_len + fg.F) return 1e10;        // filler: LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
+        // branch-free: every lane issues its load (clamped address), the cases are selected afterwards
+        const bool filler = p >= fg.sys_len && p < fg.sys_len + fg.F;     // LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
         const int ci = p < fg.sys_len ? p : p - fg.F;                     // position in the circular buffer (no fillers)
-        if (ci >= fE) return 0.0;                                         // not transmitted
-        const int q = ci / feq;
-        const int src = foff + (ci - q * feq) * fg.qm + q;                // de-interleave: x[e] = rx[(e mod E/Qm)*Qm + e div (E/Qm)]
-        return src < fg.llr_len ? clip10(in[src]) + 0.0 : 0.0;            // short input is zero padded (ldpc.py:1401-1402)
+        const bool sent = ci < fE;
+        const int cic = sent ? ci : 0;
+        const int q = cic / feq;
+        const int src = foff + (cic - q * feq) * fg.qm + q;               // de-interleave: x[e] = rx[(e mod E/Qm)*Qm + e div (E/Qm)]
+        const double x = in[src < fg.llr_len ? src : fg.llr_len - 1];
+        const double v = (sent && src < fg.llr_len) ? clip10(x) + 0.0 : 0.0;   // short input is zero padded (ldpc.py:1401-1402)
+        return filler ? 1e10 : v;
       }
     };
     // ---- load: prepend the two punctured columns as zeros (ldpc.py:1536-1538)
-    static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
-      constexpr int c = decltype(cc)::value;
-      if constexpr (c < 2) Ps[c * ZS + z] = 0.0;
-      else Ps[c * ZS + z] = fetch((c - 2) * ZC + z);
-    });
+    if constexpr (!FUSED) {
+      static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c < 2) Ps[c * ZS + z] = 0.0;
+        else Ps[c * ZS + z] = fetch((c - 2) * ZC + z);
+      });
+    } else {
+      // The core columns are linear in the code-word position (column stride = Zc): element p sits at Ps[2*Zc + p].
+      // (a) what no received LLR reaches: the punctured columns, the fillers, the untransmitted tail
+      static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c < 2) {
+          Ps[c * ZS + z] = 0.0;
+        } else {
+          const int p = (c - 2) * ZC + z;
+          if (p >= fg.sys_len && p < fg.sys_len + fg.F) Ps[c * ZS + z] = 1e10;   // LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
+          else if ((p < fg.sys_len ? p : p - fg.F) >= fE) Ps[c * ZS + z] = 0.0;
+        }
+      });
+      // (b) one coalesced sweep over the block's E_r LLRs in the order the demapper wrote them (symbol-major, Qm bits
+      // per symbol): LLR i = (symbol s, bit q) de-interleaves to buffer position q*(E/Qm) + s (ldpc.py:1390-1397); core
+      // positions are scattered into LDS, the extension columns are fetched in (c)
+      const uint32_t magic = fuse_args()->g.qm_magic;        // ceil(2^32 / Qm): i / Qm = umulhi(i, magic) for i < 2^16
+      constexpr int UN = 12;                                 // loads in flight per lane (one round trip per UN*Zc LLRs)
+      for (int i0 = 0; i0 < fE; i0 += UN * ZC) {
+        double v[UN];
+        int pp[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = i0 + u * ZC + z;
+          const int sidx = (int)__umulhi((uint32_t)i, magic), q = i - sidx * fg.qm;
+          const int ci = q * feq + sidx;
+          const int p = ci < fg.sys_len ? ci : ci + fg.F;
+          const int src = foff + i;
+          pp[u] = (i < fE && p < 24 * ZC) ? p : -1;
+          // unconditional load from a clamped address (every lane issues it, nothing branches around it); short input is
+          // zero padded (ldpc.py:1401-1402)
+          const double x = in[src < fg.llr_len ? src : fg.llr_len - 1];
+          v[u] = src < fg.llr_len ? x : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+          if (pp[u] >= 0) Ps[2 * ZC + pp[u]] = clip10(v[u]) + 0.0;
+      }
+    }
     static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
       constexpr int L = decltype(lc)::value;
       m1[L] = 0.0;
       m2[L] = 0.0;
-      if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC + z);
+      if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC + z);   // (c)
     });
     static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
     static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
@@ -257,19 +302,26 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           }
           // ---- pass 1b: t_j = r_j - msg_old_j  (ldpc.py:1550-1553); the extension column's r comes from its register
           if constexpr (EXT) t[D - 1] = rext[Y::ext_idx(L)];
-          bool was_min[D];
-          static_for<D>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            was_min[j] = oidx == (uint32_t)j;
-          });
+          // (the "was edge j the minimum" tests go into SGPR pairs a few edges ahead of their use: a VALU-written mask
+          //  needs wait states before v_cndmask may read it; all D at once would hold 19 SGPR pairs and the allocator
+          //  then re-issues compares instead)
+          constexpr int CH = 5;
           uint32_t wrun = word << (top - (D - 1));           // sign of edge D-1 at bit 31; doubled per edge
-          static_for<D>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = D - 1 - decltype(jc)::value;
-            uint32_t wnext = 0;
-            if constexpr (j > 0) wnext = dbl(wrun);
-            const double mag = was_min[j] ? om2 : om1;
-            t[j] = t[j] - sign_from(wrun, mag);
-            wrun = wnext;
+          static_for<(D + CH - 1) / CH>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int hi = D - 1 - decltype(kc)::value * CH;            // edges hi, hi-1, ... of this chunk
+            constexpr int n = hi + 1 < CH ? hi + 1 : CH;
+            bool was_min[CH];
+            static_for<n>([&](auto jc) __attribute__((always_inline)) {
+              was_min[decltype(jc)::value] = oidx == (uint32_t)(hi - decltype(jc)::value);
+            });
+            static_for<n>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = hi - decltype(jc)::value;
+              uint32_t wnext = 0;
+              if constexpr (j > 0) wnext = dbl(wrun);
+              const double mag = was_min[decltype(jc)::value] ? om2 : om1;
+              t[j] = t[j] - sign_from(wrun, mag);
+              wrun = wnext;
+            });
           });
           // ---- min-sum (ldpc.py:1556-1564): two smallest magnitudes by min/max, sign parity by XOR of the sign words
           double a1 = __builtin_fabs(t[0]);
@@ -288,7 +340,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             double v = t[D - 1];
             static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
               constexpr int j = D - 2 - decltype(jc)::value;
-              v = __builtin_fabs(t[j]) == a1 ? t[j] : v;     // ends at the first index holding the minimum
+              // (compared as bit patterns: the same test as pass 2's |t_j| == min1 for these finite values, but a different
+              //  instruction -- written as the same float compare, the compiler hoists all D of them above this branch to
+              //  share them with pass 2 and then cannot keep that many SGPR pairs alive)
+              v = (__double_as_longlong(t[j]) & 0x7fffffffffffffffll) == __double_as_longlong(a1) ? t[j] : v;   // ends at the first index holding the minimum
             });
             const double q = __builtin_fabs(v + 100000.0);
             a2 = q < a2 ? q : a2;
@@ -298,28 +353,32 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           m2[L] = nm2;
           // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written back to the element it was read from.  An entry
           // equal to min1 gets min2 (with ties min2 == min1, so every tied entry may take it); first such index = argmin.
-          bool is_min[D];
-          static_for<D>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            is_min[j] = __builtin_fabs(t[j]) == a1;
-          });
           uint32_t nsg = 0, idx = 0;
-          static_for<D>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = D - 1 - decltype(jc)::value;
-            constexpr int col = B::col(E0 + j);
-            const uint32_t sx = px ^ hi32(t[j]);              // bit 31 = parity ^ sign(t_j)
-            nsg = __builtin_amdgcn_alignbit(nsg, sx, 31);     // (nsg << 1) | (sx >> 31): edge j ends at bit j
-            idx = is_min[j] ? (uint32_t)j : idx;
-            const double mag = is_min[j] ? nm2 : nm1;
-            const double r = t[j] + sign_from(sx, mag);
-            if constexpr (col < B::CORE) {
-              constexpr uint32_t off = 8u * (uint32_t)(col * ZS + B::shift(ILS, E0 + j) % ZC);
-              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
-              if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = r;
-              else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = r;
-            } else {
-              rext[Y::ext_idx(L)] = r;
-            }
+          static_for<(D + CH - 1) / CH>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int hi = D - 1 - decltype(kc)::value * CH;
+            constexpr int n = hi + 1 < CH ? hi + 1 : CH;
+            bool is_min[CH];
+            static_for<n>([&](auto jc) __attribute__((always_inline)) {
+              is_min[decltype(jc)::value] = __builtin_fabs(t[hi - decltype(jc)::value]) == a1;
+            });
+            static_for<n>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = hi - decltype(jc)::value;
+              constexpr int col = B::col(E0 + j);
+              const bool im = is_min[decltype(jc)::value];
+              const uint32_t sx = px ^ hi32(t[j]);              // bit 31 = parity ^ sign(t_j)
+              nsg = __builtin_amdgcn_alignbit(nsg, sx, 31);     // (nsg << 1) | (sx >> 31): edge j ends at bit j
+              idx = im ? (uint32_t)j : idx;
+              const double mag = im ? nm2 : nm1;
+              const double r = t[j] + sign_from(sx, mag);
+              if constexpr (col < B::CORE) {
+                constexpr uint32_t off = 8u * (uint32_t)(col * ZS + B::shift(ILS, E0 + j) % ZC);
+                const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
+                if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = r;
+                else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = r;
+              } else {
+                rext[Y::ext_idx(L)] = r;
+              }
+            });
           });
           if constexpr (WIDE) {
             sgw[Y::wide_idx(L)] = idx | (nsg << 5);           // argmin [4:0], signs [5+D-1:5]
@@ -462,13 +521,14 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t 
   fg.n_small = cfg->C - gb % cfg->C;
   fg.sys_len = cfg->K - 2 * cfg->Zc - cfg->F;
   fg.payload = cfg->cb_len - 24;
+  fg.qm_magic = (uint32_t)((0x100000000ull + (uint64_t)qm - 1) / (uint64_t)qm);
   const int e_max = fg.e_small + (fg.n_small < cfg->C ? f : 0);
   // the rows that can matter for e_max received bits (as ops.ldpc_active_rows): never fewer than the caller asks for
   const int last = e_max - 1 + (e_max > fg.sys_len ? cfg->F : 0);
   int need = last / cfg->Zc + 2 - 26 + 1 + 4;
   if (need < 4) need = 4;
   if (n_rows < need) n_rows = need;
-  if (cfg->C < 2 || cfg->cb_len <= 24 || e_max > cfg->N - cfg->F || fg.e_small % qm || (fg.e_small + f) % qm || !chip64_covers(cfg, n_rows)) {
+  if (cfg->C < 2 || cfg->cb_len <= 24 || e_max > cfg->N - cfg->F || e_max >= 65536 || fg.e_small % qm || (fg.e_small + f) % qm || !chip64_covers(cfg, n_rows)) {
     ::nrx::set_error("nrx_ldpc_recover_decode_merge: no fused instantiation for bg %d Zc %d C %d rows %d", cfg->bg, cfg->Zc, cfg->C, n_rows);
     return NRX_E_UNSUPPORTED;
   }
