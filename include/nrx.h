@@ -178,6 +178,19 @@ int32_t nrx_qam_map_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t*
                         const int32_t* re_index, int32_t n_sym, void* out, int64_t out_stride, int32_t n_batch,
                         void* stream);
 
+/* pdsch.py:670-695 PDSCH.getGrid (DMRS-filled template of the slot) + pdsch.py:855-932 populateGrid in one pass: out
+ * (n_batch, elems) is written once per element -- re_inv[e] >= 0: the scrambled + modulated symbol number re_inv[e] of the
+ * item's bit stream (the INVERSE of the layer/RE map nrx_qam_map_* scatters through; requires every data RE of the
+ * allocation to be covered by this one bit stream, i.e. one codeword); re_inv[e] < 0: templ[templ_sel[b]][e] (DMRS, empty
+ * REs; templ (n_templ, elems), templ_sel (n_batch,) int64 = slot number in frame).  Same values as copying the template
+ * and calling nrx_qam_map_*. */
+int32_t nrx_pdsch_populate_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv,
+                               const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch,
+                               void* stream);
+int32_t nrx_pdsch_populate_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv,
+                               const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch,
+                               void* stream);
+
 /* modulation.py:159-204 getLLRsFromSymbols fused with pdsch.py:935-1005 getLLRsFromGrid (gather at re_index,
  * noise floor, descrambling pdsch.py:611-616, llrScale weighting).  exact=0: max-log (useMax=True), 1: log-sum-exp.
  * syms/scales: n_batch items of sym_stride elements (scales nullable, same offsets as syms).

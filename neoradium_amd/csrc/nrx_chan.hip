@@ -229,7 +229,11 @@ apply_td_paths_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __
 // loads); arithmetic is explicit fma (the summation order already differs from SciPy's lfilter).
 constexpr int TDP_R = 4;
 constexpr int TDP_TILE = 128;  // threads per antenna group -> 512 output samples per workgroup
-constexpr int TDP_GROUPS = 2;  // antenna groups per workgroup (more waves on the same staged tile)
+// Antenna groups per workgroup (more waves on the same staged tile).  The float64 FMA pipe issues at its full rate only
+// with >= 3 waves per SIMD (profiles/r2_f64_issue_rates.txt: 4.4 cycles per wave instruction with two waves, 2.9-3.2
+// with three or four), and the 54 KB tile allows two workgroups per CU: four groups = 8 waves per workgroup = 4 per SIMD.
+// (6-wave workgroups do not work: the first lands 2,2,1,1 on the SIMDs and a second one is never co-scheduled.)
+constexpr int TDP_GROUPS = 4;
 constexpr int TDP_FLEN = 16;   // channelmodel.py:249-289: 16-tap fractional-delay filters
 
 // One (tx antenna, path) term for the 4 samples of a thread.  U0 = (first window sample) mod 4 is a template
@@ -274,7 +278,7 @@ __device__ __forceinline__ void tdp4_term(const cd* __restrict__ p0, const cd* _
 }
 
 template <int NR>
-__global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS)
+__global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS, 4)   // four waves per SIMD (two workgroups per CU): <= 128 VGPRs
 apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ gains1, int n_paths,
                        const double* __restrict__ taps, const int32_t* __restrict__ tap_off, int hist, TdGeom g,
                        cd* __restrict__ y) {
@@ -320,28 +324,37 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
       }
     }
   }
-  // sum the groups' partial results through LDS (the staged tile is dead now)
-  __syncthreads();
-  double* part = (double*)smem;   // [2 * NR * R][TDP_TILE]
-  if (grp == 1) {
+  // sum the groups' partial results through LDS (the staged tile is dead now): real parts, then imaginary parts, so that
+  // the (GROUPS-1) x NR x R x TILE doubles of a phase fit the tile's space
+  double* part = (double*)smem;   // [GROUPS - 1][NR * R][TDP_TILE]
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
+  for (int ph = 0; ph < 2; ++ph) {
+    __syncthreads();
+    if (grp > 0) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        part[((r * R + j) * 2 + 0) * TDP_TILE + ts] = ar[r][j];
-        part[((r * R + j) * 2 + 1) * TDP_TILE + ts] = ai[r][j];
-      }
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < R; ++j) part[((grp - 1) * NR * R + r * R + j) * TDP_TILE + ts] = ph == 0 ? ar[r][j] : ai[r][j];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          double a = ph == 0 ? ar[r][j] : ai[r][j];
+#pragma unroll
+          for (int q = 0; q < TDP_GROUPS - 1; ++q) a += part[(q * NR * R + r * R + j) * TDP_TILE + ts];
+          if (ph == 0) ar[r][j] = a; else ai[r][j] = a;
+        }
+    }
   }
-  __syncthreads();
   if (grp == 0 && n < n_end) {
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const double re = ar[r][j] + part[((r * R + j) * 2 + 0) * TDP_TILE + ts];
-        const double im = ai[r][j] + part[((r * R + j) * 2 + 1) * TDP_TILE + ts];
-        if (n + j < n_end) y[((size_t)b * NR + r) * ns + n + j] = cd(re, im);
-      }
+      for (int j = 0; j < R; ++j)
+        if (n + j < n_end) y[((size_t)b * NR + r) * ns + n + j] = cd(ar[r][j], ai[r][j]);
   }
 }
 
@@ -791,7 +804,7 @@ extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_
     // register-tiled kernel: 4 output samples per thread
     const int hist4 = (hist + TDP_R - 1) / TDP_R * TDP_R;
     size_t lds4 = sizeof(cd) * (size_t)n_tx * (TDP_TILE * TDP_R + hist4);
-    const size_t part4 = sizeof(double) * 2 * (size_t)n_rx * TDP_R * TDP_TILE;   // group partial sums reuse the tile
+    const size_t part4 = sizeof(double) * (TDP_GROUPS - 1) * (size_t)n_rx * TDP_R * TDP_TILE;   // group partial sums (one phase) reuse the tile
     if (lds4 < part4) lds4 = part4;
     if (flen == TDP_FLEN && lds4 <= 80 * 1024 && n_rx <= 4) {
       int maxlen = 0;

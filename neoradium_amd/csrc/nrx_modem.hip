@@ -38,9 +38,9 @@ __global__ void __launch_bounds__(256)
 qam_map_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, const uint8_t* __restrict__ scr, int qm,
                double scale, const int32_t* __restrict__ re_index, int n_sym, cx<T>* __restrict__ out,
                int64_t out_stride, int n_batch) {
-  const int64_t total = (int64_t)n_batch * n_sym;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(g / n_sym), i = (int)(g - (int64_t)b * n_sym);
+  // grid: (x-blocks over the symbols, batch items): 32-bit indices, no 64-bit division per element
+  for (int b = blockIdx.y; b < n_batch; b += gridDim.y)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sym; i += gridDim.x * blockDim.x) {
     const uint8_t* src = bits + (size_t)b * bits_stride + (size_t)i * qm;
     uint32_t v = 0;
     for (int q = 0; q < qm; ++q) {
@@ -62,6 +62,45 @@ qam_map_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, const uint
   }
 }
 
+// PDSCH.getGrid + populateGrid in one pass (pdsch.py:670-695, 855-932): every grid element is written exactly once --
+// a data RE gets its scrambled + modulated symbol (gather through the INVERSE layer/RE map: element -> symbol number),
+// everything else (DMRS, empty REs) is copied from the slot-number-in-frame template selected per batch item.  Replaces
+// "copy the template, then scatter the symbols" (one 16-byte write per element instead of write + read-modify-write).
+template <typename T>
+__global__ void __launch_bounds__(256)
+pdsch_populate_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, const uint8_t* __restrict__ scr, int qm,
+                      double scale, const int32_t* __restrict__ re_inv, const cx<T>* __restrict__ templ,
+                      const int64_t* __restrict__ templ_sel, int64_t elems, cx<T>* __restrict__ out, int n_batch) {
+  // grid: (x-blocks, n_batch): no 64-bit division per element
+  const int b = blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)elems; e += gridDim.x * blockDim.x) {
+    const int i = re_inv[e];
+    cx<T> o;
+    if (i < 0) {
+      o = templ[(size_t)templ_sel[b] * elems + e];
+    } else {
+      const uint8_t* src = bits + (size_t)b * bits_stride + (size_t)i * qm;
+      uint32_t v = 0;
+      for (int q = 0; q < qm; ++q) {
+        uint32_t bit = src[q] & 1;
+        if (scr) bit ^= scr[(size_t)i * qm + q] & 1;  // pdsch.py:603-608
+        v = (v << 1) | bit;
+      }
+      double re, im;
+      if (qm == 1) {
+        re = im = (double)(1 - 2 * (int)v) * scale;
+      } else {
+        uint32_t rb, ib;
+        split_axes(v, qm, rb, ib);
+        re = (double)pam_level(rb, qm / 2) * scale;
+        im = (double)pam_level(ib, qm / 2) * scale;
+      }
+      o = cx<T>((T)re, (T)im);
+    }
+    out[(size_t)b * elems + e] = o;
+  }
+}
+
 // Max-log LLRs (useMax=True, the reference default).  The exhaustive max over the 2^qm points of
 // -|y-s|^2/s2 separates per axis for square QAM: bits on the real axis only see (Re y - a)^2 because the
 // imaginary-axis minimum is common to both hypotheses and cancels in the difference.
@@ -79,9 +118,9 @@ qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __
   double lev[h > 0 ? (1 << h) : 1];
 #pragma unroll
   for (int a = 0; a < (1 << h); ++a) lev[a] = (double)pam_level(a, h) * scale;
-  const int64_t total = (int64_t)n_batch * n_sym;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(g / n_sym), i = (int)(g - (int64_t)b * n_sym);
+  // grid: (x-blocks over the symbols, batch items): 32-bit indices, no 64-bit division per element
+  for (int b = blockIdx.y; b < n_batch; b += gridDim.y)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sym; i += gridDim.x * blockDim.x) {
     const int64_t src = re_index ? (int64_t)re_index[i] : (int64_t)i;
     const cx<T> y = syms[(size_t)b * sym_stride + src];
     double nv = (double)noise_var[(size_t)b * nv_stride];
@@ -142,9 +181,9 @@ qam_demap_exact_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const
                        const T* __restrict__ noise_var, int nv_stride, const uint8_t* __restrict__ scr, int qm,
                        double scale, const int32_t* __restrict__ re_index, int n_sym, TL* __restrict__ llr,
                        int64_t llr_stride, int n_batch, double nv_floor) {
-  const int64_t total = (int64_t)n_batch * n_sym;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(g / n_sym), i = (int)(g - (int64_t)b * n_sym);
+  // grid: (x-blocks over the symbols, batch items): 32-bit indices, no 64-bit division per element
+  for (int b = blockIdx.y; b < n_batch; b += gridDim.y)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sym; i += gridDim.x * blockDim.x) {
     const int64_t src = re_index ? (int64_t)re_index[i] : (int64_t)i;
     const cx<T> y = syms[(size_t)b * sym_stride + src];
     double nv = (double)noise_var[(size_t)b * nv_stride];
@@ -183,6 +222,12 @@ double qam_scale(int qm) {
   static const int norm[11] = {0, 2, 2, 0, 10, 0, 42, 0, 170, 0, 682};  // modulation.py:58
   return 1.0 / sqrt((double)norm[qm]);
 }
+// launch shape of the per-symbol kernels: x = blocks over the symbols of an item, y = batch items
+dim3 sym_batch_grid(int n_sym, int n_batch) {
+  int gx = (n_sym + 255) / 256;
+  if (n_batch >= 64 && gx > 64) gx = 64;
+  return dim3(gx < 1 ? 1 : gx, n_batch < 65535 ? (n_batch < 1 ? 1 : n_batch) : 65535);
+}
 bool qm_ok(int qm) { return qm == 1 || qm == 2 || qm == 4 || qm == 6 || qm == 8 || qm == 10; }
 
 template <typename T>
@@ -192,10 +237,26 @@ int32_t map_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, 
   NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_qam_map: unsupported modulation order %d", qm);
   NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && bits_stride >= (int64_t)n_sym * qm, NRX_E_SHAPE, "nrx_qam_map: bad sizes");
   if (n_sym == 0 || n_batch == 0) return NRX_OK;
-  hipLaunchKernelGGL(qam_map_kernel<T>, dim3(nrx::stream_grid((long)n_sym * n_batch, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(qam_map_kernel<T>, sym_batch_grid(n_sym, n_batch), dim3(256), 0,
                      (hipStream_t)stream, bits, bits_stride, scr, qm, qam_scale(qm), re_index, n_sym, (cx<T>*)out,
                      out_stride, n_batch);
   NRX_CHECK_LAUNCH("nrx_qam_map");
+  return NRX_OK;
+}
+
+template <typename T>
+int32_t populate_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv,
+                       const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) {
+  NRX_REQUIRE(bits && re_inv && templ && templ_sel && out, NRX_E_ARG, "nrx_pdsch_populate: NULL buffer");
+  NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_pdsch_populate: unsupported modulation order %d", qm);
+  NRX_REQUIRE(elems >= 0 && elems < (1ll << 31) && n_batch >= 0 && n_batch < 65536 && bits_stride >= 0, NRX_E_SHAPE, "nrx_pdsch_populate: bad sizes");
+  if (elems == 0 || n_batch == 0) return NRX_OK;
+  int gx = (int)((elems + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(pdsch_populate_kernel<T>, dim3(gx, n_batch), dim3(256), 0,
+                     (hipStream_t)stream, bits, bits_stride, scr, qm, qam_scale(qm), re_inv, (const cx<T>*)templ, templ_sel,
+                     elems, (cx<T>*)out, n_batch);
+  NRX_CHECK_LAUNCH("nrx_pdsch_populate");
   return NRX_OK;
 }
 
@@ -207,7 +268,7 @@ int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, co
   NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_qam_demap: unsupported modulation order %d", qm);
   NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && llr_stride >= (int64_t)n_sym * qm, NRX_E_SHAPE, "nrx_qam_demap: bad sizes");
   if (n_sym == 0 || n_batch == 0) return NRX_OK;
-  const dim3 grid(nrx::stream_grid((long)n_sym * n_batch, 256));
+  const dim3 grid = sym_batch_grid(n_sym, n_batch);
   if (exact)
     hipLaunchKernelGGL((qam_demap_exact_kernel<T, TL>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,
                        sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qm, qam_scale(qm), re_index,
@@ -257,3 +318,6 @@ extern "C" int32_t nrx_qam_map_f64(const uint8_t* bits, int64_t bits_stride, con
 NRX_DEMAP(nrx_qam_demap_f32, float, float)
 NRX_DEMAP(nrx_qam_demap_f64, double, double)
 NRX_DEMAP(nrx_qam_demap_f64o32, double, float)
+
+extern "C" int32_t nrx_pdsch_populate_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) { return populate_entry<float>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, stream); }
+extern "C" int32_t nrx_pdsch_populate_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) { return populate_entry<double>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, stream); }

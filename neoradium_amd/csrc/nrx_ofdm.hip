@@ -146,11 +146,23 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
                     cx<T>* __restrict__ wave, int64_t wave_stride, const cx<T>* __restrict__ f, int64_t f_stride, int nl,
-                    int ports, const cx<double>* __restrict__ tw, cx<T>* __restrict__ tails) {
+                    int ports, const cx<double>* __restrict__ tw, cx<T>* __restrict__ tails, int xcd_pairs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
-  const int l = blockIdx.x % g.n_sym;
-  const int row = blockIdx.x / g.n_sym;   // item * ports + port
+  // Workgroup -> (item, port, symbol).  With a precoder every port of an (item, symbol) pair reads the same nl layer rows:
+  // consecutive workgroups go to the 8 XCDs round-robin (each XCD has its own L2), so the ports of a pair are placed 8
+  // workgroups apart -- same XCD, dispatched together -- and the layer rows come from HBM once instead of once per port.
+  int l, row;
+  if (f && xcd_pairs) {
+    const int b = blockIdx.x, x = b & 7, pt = (b >> 3) % ports, q = (b >> 3) / ports;
+    const int pair = q * 8 + x;              // (item, symbol) pair; the host pads the grid to whole groups of 8 pairs
+    if (pair >= xcd_pairs) return;
+    l = pair % g.n_sym;
+    row = (pair / g.n_sym) * ports + pt;
+  } else {
+    l = blockIdx.x % g.n_sym;
+    row = blockIdx.x / g.n_sym;             // item * ports + port
+  }
   const int item = f ? row / ports : 0, port = f ? row % ports : 0;
   const cx<T>* src = f ? grid + (size_t)item * nl * g.n_sym * K : grid + (size_t)row * g.n_sym * K;
   cx<double> fw[8];
@@ -260,9 +272,12 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
     const size_t lds = sizeof(cx<T>) * nrx::fft_lds_elems((size_t)nfft);
     auto kern = ofdm_mod_sym_kernel<T>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(n_rows * n_sym), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
+    // precoded: XCD-aware placement of the ports of an (item, symbol) pair (see the kernel)
+    const int pairs = f ? (n_rows / ports) * n_sym : 0;
+    const int n_wg = f ? ((pairs + 7) / 8) * 8 * ports : n_rows * n_sym;
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
                        ilog2(nfft), g, window_len, slot_len, (cx<T>*)wave, wave_stride, (const cx<T>*)f, f_stride, nl,
-                       ports, tw, (cx<T>*)tails);
+                       ports, tw, (cx<T>*)tails, pairs);
     if (window_len > 0) {
       const int64_t total = (int64_t)n_rows * n_sym * window_len;
       hipLaunchKernelGGL(ofdm_tail_add_kernel<T>, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,

@@ -100,6 +100,13 @@ class PdschLink:
                                 rows=ops.ldpc_active_rows(ccfg, e_max) if skipPuncturedRows else None,
                                 re_index=D(np.int32((np.int64(lm[0]) * self.L + lm[1]) * self.K + lm[2])),
                                 scr=D(pdsch._scrambling(q, G))))
+        if self.numCW == 1:     # inverse RE map (grid element -> symbol number, -1 = no data): getGrid + populateGrid in one pass
+            ri = np.int64(lms[0][0]) * self.L * self.K + np.int64(lms[0][1]) * self.K + np.int64(lms[0][2])
+            inv = np.full(self.nl * self.L * self.K, -1, dtype=np.int32)
+            if len(np.unique(ri)) != len(ri) or int(ri.min()) < 0 or int(ri.max()) >= len(inv) or len(ri) * self.cw[0]['qm'] != self.cw[0]['G']:
+                raise ValueError("PdschLink: the layer/RE map must address distinct grid elements, one per modulated symbol")
+            inv[ri] = np.arange(len(ri), dtype=np.int32)
+            self.re_inv = D(inv)
         c0 = self.cw[0]     # (single-codeword attribute names kept: bench.py, the oracle harness and the tests use them)
         self.G, self.re_index, self.scr, self.cfg = c0['G'], c0['re_index'], c0['scr'], c0['cfg']
         self.first_prb = int(pdsch.prbSet[0])
@@ -179,6 +186,8 @@ class PdschLink:
     def run(self, slot0, n_slots, snr_db, seed=0, tb_bits=None, noise=None, counters=None, details=False):
         """Simulate absolute slots [slot0, slot0+n_slots).  Returns the int64[4] device counters
         (blockErrors, totalBlocks, bitErrors, totalBits) -- accumulated into ``counters`` when given.
+        ``details=True`` also returns every intermediate of each geometry group, ``details="verdicts"`` only the
+        per-code-block CRC verdicts.
 
         Throughput mode (default): transport blocks and noise come from the counter-based device generator keyed by
         (seed, slot index), so results do not depend on batch size or on how slots are sharded over GPUs.
@@ -223,7 +232,7 @@ class PdschLink:
         # ---- Tx
         if self.numCW > 1 and harq is not None:
             raise NotImplementedError("run_harq: two-codeword PDSCH is not built")
-        grid = self.templates.index_select(0, sif)                              # DMRS-filled (n, Nl, L, K)
+        grid = None if self.numCW == 1 else self.templates.index_select(0, sif)   # DMRS-filled (n, Nl, L, K)
         tbs_in = []
         for q, cw in enumerate(self.cw):
             if tb_bits is None:     # stream ids: 1 = first codeword (as before), 3 = second; 2 is the noise
@@ -233,7 +242,10 @@ class PdschLink:
             tbs_in.append(tb)
             coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'])
             bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[0])
-            ops.qam_map(bits, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], out=grid)
+            if grid is None:    # one codeword: template + scramble + modulate + layer/RE map in one pass over the grid
+                grid = ops.pdsch_populate(bits, cw['qm'], cw['scr'], self.re_inv, self.templates, sif)
+            else:
+                ops.qam_map(bits, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], out=grid)
         tb = tbs_in[0]
 
         # ---- channel state of each slot
@@ -281,7 +293,7 @@ class PdschLink:
             hest = ops.chest_ls_ex(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,
                                    pil_set=sif.to(torch.int32), polar=True)
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
-        elif details or self.n_tg > 2 or self.nl > 4:
+        elif details is True or self.n_tg > 2 or self.nl > 4:
             hest = ops.chest_ls(rxg, self.pilots, self.port_ks, self.dmrs_syms, l_cdm=self.l_cdm, k_cdm=self.k_cdm,
                                 pil_set=sif.to(torch.int32))
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
@@ -322,6 +334,8 @@ class PdschLink:
                 ops.count_errors(cb_ok, tb_out, tbs_in[q], counters)
             per_cw.append(dict(tb=tbs_in[q], cb_ok=cb_ok, tb_out=tb_out, llr=llr))
         cb_ok = per_cw[0]['cb_ok']
+        if details == "verdicts":       # per-code-block CRC verdicts only (nothing extra is materialised)
+            return dict(cb_ok=cb_ok) if self.numCW == 1 else dict(cb_ok=cb_ok, cw=[dict(cb_ok=c['cb_ok']) for c in per_cw])
         if details:
             d = dict(per_cw[0], eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv, sigma=sigma, grid=grid)
             if self.numCW > 1:

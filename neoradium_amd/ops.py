@@ -285,6 +285,30 @@ def qam_map(bits, qm, scr=None, re_index=None, out=None, out_elems=None, dtype=t
     return out
 
 
+def pdsch_populate(bits, qm, scr, re_inv, templates, templ_sel):
+    """getGrid + populateGrid in one pass (nrx_pdsch_populate_*): (n, G) bits -> (n, *templates.shape[1:]) grid; data REs
+    from the bit stream through the inverse RE map ``re_inv`` (int32, one entry per grid element, -1 = not a data RE),
+    everything else from ``templates[templ_sel[b]]``."""
+    bits = _u8(bits)
+    n, nb = bits.shape
+    dev = _dev(bits)
+    templates = templates.contiguous()
+    elems = templates[0].numel()
+    sfx, _ = _ct(templates)
+    if re_inv.dtype != torch.int32 or re_inv.numel() != elems:
+        raise ValueError("re_inv must be an int32 tensor with one entry per grid element")
+    if templ_sel.dtype != torch.int64 or templ_sel.numel() != n:
+        raise ValueError("templ_sel must be an int64 tensor with one entry per batch item")
+    scr_t = None if scr is None else _u8(scr.to(dev))
+    if scr_t is not None and scr_t.numel() < nb:
+        raise ValueError("scrambling sequence shorter than the bit stream")
+    out = torch.empty((n,) + tuple(templates.shape[1:]), dtype=templates.dtype, device=dev)
+    fn = getattr(lib(), 'nrx_pdsch_populate_' + sfx)
+    check(fn(ptr(bits), nb, ptr(scr_t), qm, ptr(re_inv.contiguous()), ptr(templates), ptr(templ_sel.contiguous()), elems,
+             ptr(out), n, stream()))
+    return out
+
+
 def qam_demap(syms, noise_var, qm, n_sym=None, scr=None, re_index=None, scales=None, exact=False, nv_floor=0.0,
               llr_dtype=None):
     """Modem.getLLRsFromSymbols / PDSCH.getLLRsFromGrid: (n, E) complex -> (n, n_sym*qm) LLRs."""

@@ -97,6 +97,9 @@ def test_engine_counters_at_metric_size(link, dev):
     _, d32 = link.run(3, 2, 36.0, seed=11, details=True)
     _, d64 = l64.run(3, 2, 36.0, seed=11, details=True)
     a, b = d32[0][1]['cb_ok'].cpu().numpy(), d64[0][1]['cb_ok'].cpu().numpy()
-    assert (a != b).mean() <= 0.02           # verdicts may differ on a block sitting exactly on the decoding threshold
+    # float32 fast mode against the float64 chain: measured verdict disagreement 1.1e-3 over 147 168 code blocks across the
+    # waterfall of this configuration, worst SNR point 2.4e-3 (profiles/r2_f32_vs_f64_verdicts_metric.json, tools/
+    # verdict_compare.py); on these 144 blocks that is an expectation of 0.2 -- more than 2 differing verdicts is a regression
+    assert int((a != b).sum()) <= 2
     rel = float((d32[0][1]['llr'].double() - d64[0][1]['llr']).abs().max() / d64[0][1]['llr'].abs().max())
     assert rel <= 1e-5                        # north-star tolerance on float LLRs
