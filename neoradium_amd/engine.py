@@ -24,6 +24,74 @@ from ._dev import D, device as _device
 from .waveform import Waveform
 
 
+def host_tables(pdsch, channel, codeRate, baseGraphNo=1):
+    """Everything of a link that depends only on (configuration, slot number in frame), computed ON THE HOST with the
+    class surface's own index/DMRS/TBS/channel-setup code (NumPy only, no device call): the DMRS-filled grid template and
+    pilot table of every slot of the frame, the layer-mapped RE index, scrambling sequence and LDPC configuration of
+    every codeword, the channel's static ray coefficients and tap matrix, the slot geometry.  PdschLink uploads these;
+    the CPU oracle harness (oracle/link.py, tests/test_oracle_e2e.py) consumes the same dictionary."""
+    bwp = pdsch.bwp
+    car = bwp.carrier
+    dmrs = pdsch.dmrs
+    L, K = bwp.symbolsPerSlot, 12 * bwp.numRbs
+    saved = car.slotNo
+    templ, pil = [], []
+    idx0 = None
+    for s in range(bwp.slotsPerFrame):
+        car.slotNo = s
+        g = pdsch.getGrid()
+        templ.append(g.grid.copy())
+        p, ks, ds = dmrs.getPilots()
+        pil.append(p)
+        if idx0 is None:
+            idx0 = tuple(i.copy() for i in pdsch.dataIndices)
+            tbs_all = [int(v) for v in pdsch.getTxBlockSize(codeRate)]
+            port_ks, dmrs_syms = ks, [int(v) for v in ds]
+        elif not all(np.array_equal(a, b) for a, b in zip(idx0, pdsch.dataIndices)):
+            raise ValueError("PdschLink: the data RE indices must be the same in every slot of the frame")
+    car.slotNo = saved
+    if not (0 <= int(np.min(port_ks)) and int(np.max(port_ks)) < K):
+        raise ValueError("PdschLink: DMRS subcarrier outside the bandwidth part")
+    nl = pdsch.numLayers
+    n_res = pdsch.getNumREsFromIndexes(idx0)
+    lms = pdsch.getLayerMapIndexes(idx0, n_res)
+    cw_layers = [nl] if pdsch.numCW == 1 else [nl // 2, nl - nl // 2]
+    cws = []
+    for q in range(pdsch.numCW):
+        qm = pdsch.modems[q].qm
+        G = n_res[q] * qm
+        lm = lms[q]
+        ccfg = _lib.ldpc_config(baseGraphNo, tbs_all[q] + 24)
+        e_max = max(_lib.ldpc_cb_lens(G, ccfg.C, cw_layers[q], qm))
+        cws.append(dict(tbs=tbs_all[q], qm=qm, nl=cw_layers[q], G=G, cfg=ccfg, e_max=e_max, lm=lm,
+                        re_index=np.int32((np.int64(lm[0]) * L + lm[1]) * K + lm[2]), scr=pdsch._scrambling(q, G)))
+    A, nu, Alos, nulos = channel.staticCoefficients()
+    sc = channel._normalisation()
+    spsf = bwp.slotsPerSubFrame
+    sym_lens = [bwp.symbolLens[s * L:s * L + L + 1].astype(np.int64) for s in range(spsf)]
+    return dict(templates=np.stack(templ), pilots=np.stack(pil), port_ks=port_ks, dmrs_syms=dmrs_syms, idx0=idx0, lms=lms,
+                n_res=n_res, cw=cws, l_cdm=dmrs.symbols, k_cdm=(4 if dmrs.enhanced else 2), first_prb=int(pdsch.prbSet[0]),
+                A=np.complex128(A * sc), nu=np.float64(nu), Alos=None if Alos is None else np.complex128(Alos * sc),
+                nulos=float(nulos), coeff=channel.getCoeffMatrix(), max_delay=channel.getMaxDelay(), fs=bwp.sampleRate,
+                sym_lens=sym_lens, nr=channel.nrNt[0], nt=channel.nrNt[1], nl=nl, K=K, L=L, nfft=bwp.nFFT, n_rb=bwp.numRbs,
+                slots_per_frame=bwp.slotsPerFrame, slots_per_subframe=spsf)
+
+
+def gain_times(tables, slots):
+    """(n, L+1) seconds: starts of the useful part of each symbol (+ first symbol of the next slot) of the absolute
+    slots ``slots`` on the channel's time axis (channelmodel.py:173-193, 328-334)."""
+    spsf, nfft = tables['slots_per_subframe'], tables['nfft']
+    slot_len = [int(v[:-1].sum()) for v in tables['sym_lens']]
+    sub = int(sum(slot_len))
+    out = np.empty((len(slots), tables['L'] + 1))
+    for i, n in enumerate(slots):
+        n = int(n)
+        sl = tables['sym_lens'][n % spsf].copy()
+        sl[0] -= nfft
+        out[i] = ((n // spsf) * sub + int(sum(slot_len[:n % spsf])) + np.cumsum(sl)) / tables['fs']
+    return out
+
+
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
                  decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
@@ -57,49 +125,26 @@ class PdschLink:
         self.K, self.L, self.nfft = 12 * bwp.numRbs, bwp.symbolsPerSlot, bwp.nFFT
         dmrs = pdsch.dmrs
 
-        # ---- per slotNoInFrame: DMRS-filled grid template and pilot table
-        saved = self.carrier.slotNo
-        templ, pil = [], []
-        idx0 = None
-        for s in range(bwp.slotsPerFrame):
-            self.carrier.slotNo = s
-            g = pdsch.getGrid()
-            templ.append(g.grid.copy())
-            p, ks, ds = dmrs.getPilots()
-            pil.append(p)
-            if idx0 is None:
-                idx0 = tuple(i.copy() for i in pdsch.dataIndices)
-                tbs_all = [int(v) for v in pdsch.getTxBlockSize(codeRate)]
-                self.tbs = tbs_all[0]
-                self.port_ks, self.dmrs_syms = ks, [int(v) for v in ds]
-            else:
-                if not all(np.array_equal(a, b) for a, b in zip(idx0, pdsch.dataIndices)):
-                    raise ValueError("PdschLink: the data RE indices must be the same in every slot of the frame")
-        self.carrier.slotNo = saved
-        self.templates = D(np.stack(templ))                    # (S, Nl, L, K) complex128
-        self.pilots = D(np.stack(pil))                         # (S, P, nDs, nK)
-        self.l_cdm, self.k_cdm = dmrs.symbols, (4 if dmrs.enhanced else 2)
+        # ---- host tables (DMRS-filled grid template + pilot table per slotNoInFrame, per-codeword LDPC configuration, layer-
+        # mapped RE index and scrambling, channel static coefficients): computed on the host, uploaded here
+        self.tables = tb_ = host_tables(pdsch, channel, codeRate, baseGraphNo)
+        idx0, lms = tb_['idx0'], tb_['lms']
+        self.tbs = tb_['cw'][0]['tbs']
+        self.port_ks, self.dmrs_syms = tb_['port_ks'], tb_['dmrs_syms']
+        self.templates = D(tb_['templates'])                   # (S, Nl, L, K) complex128
+        self.pilots = D(tb_['pilots'])                         # (S, P, nDs, nK)
+        self.l_cdm, self.k_cdm = tb_['l_cdm'], tb_['k_cdm']
         self.port_ks_d = D(np.ascontiguousarray(np.int32(self.port_ks)))
-        assert 0 <= int(np.min(self.port_ks)) and int(np.max(self.port_ks)) < self.K
         self.n_tg = len(self.dmrs_syms) // self.l_cdm                   # DMRS time groups
         # ---- per codeword (TS 38.211 7.3.1.3: one codeword up to 4 layers, two above: floor(v/2) + the rest): transport
         # block size, LDPC configuration, modulation order, layers, coded bits, layer-mapped RE index, scrambling
-        n_res = pdsch.getNumREsFromIndexes(idx0)
-        lms = pdsch.getLayerMapIndexes(idx0, n_res)
-        cw_layers = [self.nl] if self.numCW == 1 else [self.nl // 2, self.nl - self.nl // 2]
         self.cw = []
-        for q in range(self.numCW):
-            qm = pdsch.modems[q].qm
-            G = n_res[q] * qm
-            lm = lms[q]
-            ccfg = _lib.ldpc_config(baseGraphNo, tbs_all[q] + 24)
+        for c in tb_['cw']:
             # rows of the base graph whose extension parity is actually transmitted (first transmission, rv 0): the
             # others are exact no-ops for the information bits and are not run (ops.ldpc_active_rows)
-            e_max = max(_lib.ldpc_cb_lens(G, ccfg.C, cw_layers[q], qm))
-            self.cw.append(dict(tbs=tbs_all[q], qm=qm, nl=cw_layers[q], G=G, cfg=ccfg,
-                                rows=ops.ldpc_active_rows(ccfg, e_max) if skipPuncturedRows else None,
-                                re_index=D(np.int32((np.int64(lm[0]) * self.L + lm[1]) * self.K + lm[2])),
-                                scr=D(pdsch._scrambling(q, G))))
+            self.cw.append(dict(tbs=c['tbs'], qm=c['qm'], nl=c['nl'], G=c['G'], cfg=c['cfg'],
+                                rows=ops.ldpc_active_rows(c['cfg'], c['e_max']) if skipPuncturedRows else None,
+                                re_index=D(c['re_index']), scr=D(c['scr'])))
         if self.numCW == 1:     # inverse RE map (grid element -> symbol number, -1 = no data): getGrid + populateGrid in one pass
             ri = np.int64(lms[0][0]) * self.L * self.K + np.int64(lms[0][1]) * self.K + np.int64(lms[0][2])
             inv = np.full(self.nl * self.L * self.K, -1, dtype=np.int32)
@@ -135,20 +180,19 @@ class PdschLink:
             self.prg_groups = groups
 
         # ---- channel: static ray coefficients + tap matrix on the device
-        A, nu, Alos, nulos = channel._staticOnDevice()
-        self.A, self.nu, self.Alos, self.nulos = A, nu, Alos, nulos
-        coeff = channel.getCoeffMatrix()
+        self.A, self.nu = D(tb_['A']), D(tb_['nu'])
+        self.Alos, self.nulos = (None if tb_['Alos'] is None else D(tb_['Alos'])), tb_['nulos']
+        coeff = tb_['coeff']
         self.coeff = D(coeff)
         taps, offs = ops.path_taps(coeff, channel.filterLen)
         self.taps, self.tap_off = D(taps), D(offs)
         self.td_hist = int(np.max(offs)) + int(np.asarray(taps).shape[1]) - 1
-        self.max_delay = channel.getMaxDelay()
+        self.max_delay = tb_['max_delay']
         self.fs = bwp.sampleRate
         self.window = windowing
 
         # ---- slot geometry by slot number in subframe
-        spsf = bwp.slotsPerSubFrame
-        self.sym_lens = [bwp.symbolLens[s * self.L:s * self.L + self.L + 1].astype(np.int64) for s in range(spsf)]
+        self.sym_lens = tb_['sym_lens']
         self.slot_len = [int(v[:-1].sum()) for v in self.sym_lens]
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
@@ -161,13 +205,7 @@ class PdschLink:
 
     def gain_times(self, slots):
         """(n, L+1) seconds: starts of the useful part of each symbol (+ first symbol of the next slot)."""
-        spsf = self.bwp.slotsPerSubFrame
-        out = np.empty((len(slots), self.L + 1))
-        for i, n in enumerate(slots):
-            sl = self.sym_lens[n % spsf].copy()
-            sl[0] -= self.nfft
-            out[i] = (self.slot_start(n) + np.cumsum(sl)) / self.fs
-        return out
+        return gain_times(self.tables, slots)
 
     def _cp_gather(self, sis, width):
         """Element offsets of the CP-stripped samples of all Nr rows (Waveform.getRePower, waveform.py:107-117)."""

@@ -22,23 +22,31 @@ class _GainTimes:
         return self.table[int(slot)]
 
 
-def static_from_link(link, slots=None):
-    """Plain-array description of a configured neoradium_amd.engine.PdschLink (host data only, no GPU results).
-    ``slots``: tabulate the gain instants of these slots, so that the result holds no reference to the link."""
-    ch = link.channel
-    A, nu, Alos, nulos = ch.staticCoefficients()
-    s = ch._normalisation()
+def static_from_tables(tb, num_iter, freq_domain, perfect, window, slots=None, gain_times=None):
+    """Plain-array description of a link from the HOST tables of neoradium_amd.engine.host_tables (NumPy data computed on
+    the host by the class surface's index/DMRS/TBS/channel-setup code, which tests/test_host_logic.py pins against the
+    reference) plus the harness settings.  No GPU result enters: this is what tests/test_oracle_e2e.py feeds run_slot
+    with on a host without a GPU.  ``gain_times``: callable slot -> (L+1,) seconds; ``slots``: tabulate it instead."""
+    c = tb['cw'][0]
+    if gain_times is None:
+        from neoradium_amd.engine import gain_times as _gt           # host-only arithmetic on the tables
+        gain_times = _GainTimes({int(s): _gt(tb, [int(s)])[0] for s in slots}) if slots is not None else \
+            (lambda slot: _gt(tb, [slot])[0])
     return dict(
-        templates=link.templates.cpu().numpy(), pilots=link.pilots.cpu().numpy(), port_ks=np.asarray(link.port_ks),
-        dmrs_syms=list(link.dmrs_syms), l_cdm=link.l_cdm, k_cdm=link.k_cdm, re_index=link.re_index.cpu().numpy(),
-        scr=link.scr.cpu().numpy(), tbs=link.tbs, G=link.G, nl=link.nl, qm=link.qm, bg=link.cfg.bg, nr=link.nr, nt=link.nt,
-        K=link.K, L=link.L, nfft=link.nfft, n_rb=link.bwp.numRbs, slots_per_frame=link.bwp.slotsPerFrame,
-        slots_per_subframe=link.bwp.slotsPerSubFrame, sym_lens=[np.asarray(v) for v in link.sym_lens], fs=link.fs,
-        A=A * s, nu=nu, Alos=None if Alos is None else Alos * s, nulos=nulos, coeff=ch.getCoeffMatrix(),
-        max_delay=link.max_delay, first_prb=link.first_prb, num_iter=link.numIter, freq_domain=link.freqDomain,
-        perfect=link.chanEst == "Perfect", window=link.window != "NONE",
-        gain_times=(lambda slot: link.gain_times([slot])[0]) if slots is None else
-        _GainTimes({int(s): link.gain_times([int(s)])[0] for s in slots}))
+        templates=tb['templates'], pilots=tb['pilots'], port_ks=np.asarray(tb['port_ks']), dmrs_syms=list(tb['dmrs_syms']),
+        l_cdm=tb['l_cdm'], k_cdm=tb['k_cdm'], re_index=c['re_index'], scr=c['scr'], tbs=c['tbs'], G=c['G'], nl=tb['nl'],
+        qm=c['qm'], bg=c['cfg'].bg, nr=tb['nr'], nt=tb['nt'], K=tb['K'], L=tb['L'], nfft=tb['nfft'], n_rb=tb['n_rb'],
+        slots_per_frame=tb['slots_per_frame'], slots_per_subframe=tb['slots_per_subframe'],
+        sym_lens=[np.asarray(v) for v in tb['sym_lens']], fs=tb['fs'], A=tb['A'], nu=tb['nu'], Alos=tb['Alos'], nulos=tb['nulos'],
+        coeff=tb['coeff'], max_delay=tb['max_delay'], first_prb=tb['first_prb'], num_iter=num_iter, freq_domain=freq_domain,
+        perfect=perfect, window=window, gain_times=gain_times)
+
+
+def static_from_link(link, slots=None):
+    """:func:`static_from_tables` for a configured neoradium_amd.engine.PdschLink (its host tables, no GPU results).
+    ``slots``: tabulate the gain instants of these slots, so that the result holds no reference to the link."""
+    return static_from_tables(link.tables, link.numIter, link.freqDomain, link.chanEst == "Perfect", link.window != "NONE",
+                              slots=slots)
 
 
 def _job(args):
@@ -64,10 +72,13 @@ def run_slots_parallel(jobs, n_procs):
                 os.environ[k] = v
 
 
-def run_slot(st, slot, snr_db, tb, z, F=None):
+def run_slot(st, slot, snr_db, tb, z, F=None, chan_slot=None):
     """One slot.  tb: (TBS,) bits; z: standard-normal complex array shaped like the noisy signal
     ((Nr,L,K) in frequency-domain mode, (Nr, slotLen+maxDelay) in time-domain mode).  Returns a dict with
-    the per-code-block CRC verdicts, the decoded transport block and the LLRs."""
+    the per-code-block CRC verdicts, the decoded transport block and the LLRs.
+    ``chan_slot``: slot whose start is the channel's time origin when it differs from the carrier's slot number (the
+    reference advances the channel clock only when the channel has been applied since the last goNext,
+    channelmodel.py:180-193, 326, 349: n consecutive goNext() calls leave it at slot min(n, 1))."""
     nl, qm, K, L, nfft = st['nl'], st['qm'], st['K'], st['L'], st['nfft']
     # ---- Tx: CRC24A, segmentation, LDPC encode, rate match (ldpc.py:1167-1204)
     rm, d = oc.encode_chain(tb, st['bg'], st['G'], nl, qm)
@@ -77,7 +88,7 @@ def run_slot(st, slot, snr_db, tb, z, F=None):
     syms = op.modulate(rm ^ st['scr'][:len(rm)].astype(np.int8), qm)
     grid.reshape(-1)[st['re_index']] = syms
     # ---- channel state of the slot (cdl.py:641-645, channelmodel.py:321-354)
-    t = st['gain_times'](slot)
+    t = st['gain_times'](slot if chan_slot is None else chan_slot)
     gains = np.einsum('rtnm,cnm->crtn', st['A'], np.exp(2j * np.pi * t[:, None, None] * st['nu'][None]))
     if st['Alos'] is not None:
         los = st['Alos'][None] * np.exp(2j * np.pi * t * st['nulos'])[:, None, None]

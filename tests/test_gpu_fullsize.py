@@ -103,3 +103,25 @@ def test_engine_counters_at_metric_size(link, dev):
     assert int((a != b).sum()) <= 2
     rel = float((d32[0][1]['llr'].double() - d64[0][1]['llr']).abs().max() / d64[0][1]['llr'].abs().max())
     assert rel <= 1e-5                        # north-star tolerance on float LLRs
+
+
+def test_cfg3_link_at_273_prb(dev):
+    """BASELINE cfg3 through the engine at its full size: 273 PRB, 256-QAM, 4 layers, 4x4 CDL-D 300 ns, BG1 R = 0.75 =>
+    TBS 950 984, 113 code blocks of Zc 384.  With perfect CSI (frequency-domain channel) the link is clean at
+    high SNR; with the DMRS-LS estimate every block fails at any SNR -- the reference's own behaviour for this channel
+    (tests/golden/e2e_cfg3_*: 24 PRB, generated from the reference), so it is asserted, not hidden."""
+    import neoradium_amd as nr
+    nr.random.setSeed(123)
+    car = nr.Carrier(numRbs=273, spacing=30)
+    p = nr.PDSCH(car.curBwp, numLayers=4, nID=car.cellId, modulation='256QAM')
+    p.setDMRS(configType=1, additionalPos=1)
+    ch = nr.CdlChannel(car.curBwp, 'D', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                       txAntenna=nr.AntennaPanel([1, 2], polarization="x"), rxAntenna=nr.AntennaPanel([1, 2], polarization="x"))
+    perfect = nr.PdschLink(p, ch, 0.75, baseGraphNo=1, numIter=20, freqDomain=True, chanEst="Perfect", decoder="f64")
+    c = perfect.cfg
+    assert (perfect.tbs, c.C, c.Zc, perfect.G) == (950984, 113, 384, 1257984)
+    hi = perfect.run(0, 3, 60.0, seed=5).cpu().numpy()
+    assert hi[0] == 0 and hi[2] == 0 and hi[1] == 3 * 113 and hi[3] == 3 * 950984
+    ls = nr.PdschLink(p, ch, 0.75, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS", decoder="f64")
+    lo = ls.run(0, 2, 60.0, seed=5).cpu().numpy()
+    assert lo[0] == lo[1] == 2 * 113

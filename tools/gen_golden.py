@@ -329,6 +329,7 @@ def e2e():
                             t_off=np.int64(ch.getTimingOffset()), max_delay=np.int64(ch.getMaxDelay()))
         print(name, 'TBS', tbs, 'G', nb, 'crc', np.asarray(crc), 'bit errors', int(np.abs(out_tb[:-24] - tb).sum()))
 
+    e2e.one = one
     dm1 = dict(configType=1, additionalPos=1)
     # BASELINE cfg1: 25 PRB @15 kHz, QPSK, 1 layer, TDL-A SISO, BG2 R=0.3, 5 it, time domain, LS
     one('cfg1_tdl_siso', 123, 25, 15, 'QPSK', 1, 0.3, 2, ('tdl', 'A', 30, 5, 1, 1), dm1, 5, 4.0, False, False, 0)
@@ -338,6 +339,19 @@ def e2e():
     one('cdl_mimo_fd_perfect', 55, 24, 30, '64QAM', 4, 0.5, 1, ('cdl', 'C', 100, 5, [1, 2], [1, 2]), dm1, 10, 26.0, True, True, 1)
     # a failing slot (low SNR) -- CRC failures must match too
     one('cdl_fail_td_ls', 77, 25, 15, '16QAM', 2, 0.6, 1, ('cdl', 'D', 100, 30, [1, 2], [1, 1]), dm1, 8, 6.0, False, False, 0)
+    e2e_baseline_configs()
+
+
+def e2e_baseline_configs():
+    """BASELINE.json cfg2 at the size the reference can build it (106 PRB needs 15 kHz) and cfg3's link (4 layers, 256-QAM,
+    4x4 CDL-D, R = 0.75) at 24 PRB @30 kHz: with the DMRS-LS estimate every code block fails at ANY SNR in the reference
+    itself (CDL-D's LOS + 300 ns spread against a linear interpolation between DMRS subcarriers at 256-QAM), with perfect
+    CSI (frequency-domain channel, the BLER notebook's default path) every block passes -- both behaviours are fixtures."""
+    one = e2e.one
+    dm1 = dict(configType=1, additionalPos=1)
+    one('cfg2_cdl_c_2x2', 2024, 106, 15, '64QAM', 2, 666 / 1024, 1, ('cdl', 'C', 300, 5, [1, 1], [1, 1]), dm1, 20, 22.0, False, False, 1)
+    one('cfg3_cdl_d_4x4_ls', 31, 24, 30, '256QAM', 4, 0.75, 1, ('cdl', 'D', 300, 5, [1, 2], [1, 2]), dm1, 20, 45.0, False, False, 1)
+    one('cfg3_cdl_d_4x4_perfect', 31, 24, 30, '256QAM', 4, 0.75, 1, ('cdl', 'D', 300, 5, [1, 2], [1, 2]), dm1, 20, 45.0, True, True, 1)
 
 
 def e2e_2cw():
