@@ -39,6 +39,46 @@ def copy_matlab():
         for f in sorted(os.listdir(src)):
             if f.endswith('.mat'):
                 shutil.copyfile(os.path.join(src, f), os.path.join(d, f))
+    # PDSCH-waveform.ipynb (52 PRB @30 kHz, startRb 1, 2 layers, VRB interleaving bundle 2, 16-QAM): the four small vectors
+    # as they are; of the 4 x 15360 waveform the complete first symbol (long CP, windowed head, wrapped tail of the last
+    # symbol) and the complete last one, plus every 13th sample in between (the full file is 0.9 MB)
+    import scipy.io
+    d = os.path.join(GOLD, 'matlab_pdsch')
+    os.makedirs(d, exist_ok=True)
+    src = os.path.join(PLAY, 'PDSCH', 'MatlabFiles')
+    for f in ('dmrsSymbols.mat', 'pdschBits.mat', 'pdschSymbols.mat', 'pdschGrid.mat'):
+        shutil.copyfile(os.path.join(src, f), os.path.join(d, f))
+    w = scipy.io.loadmat(os.path.join(src, 'txWaveform.mat'))['txWaveform'].T            # (4, 15360)
+    n = w.shape[1]
+    idx = np.unique(np.concatenate([np.arange(0, 1200), np.arange(n - 1200, n), np.arange(0, n, 13)]))
+    np.savez_compressed(os.path.join(d, 'txWaveform_samples.npz'), idx=np.int32(idx), samples=w[:, idx], n=np.int64(n))
+
+
+def matlab_cdl():
+    """CompareWithMatlab/CDL/CDL-Matlab.ipynb: CDL-D, 8 Tx (2x2 cross-polarised panel, MATLAB element order, rotated) x 2 Rx,
+    angle scaling, MATLAB's random phases / ray coupling, 70 dB stop band -- MATLAB's input waveform through applyToSignal.
+    Stored: the first three OFDM symbols' worth of the 1 ms input (the filter is causal), MATLAB's output and the reference's."""
+    import scipy.io
+    carrier = nr.Carrier(startRb=0, numRbs=25, spacing=15)
+    bwp = carrier.curBwp
+    phi, coupling = nr.CdlChannel.getMatlabRandomInit('D', 123)
+    d = 15 * 1000 / 3600 * 4e9 / 299792458
+    ch = nr.CdlChannel(bwp, 'D', delaySpread=10, carrierFreq=4e9, dopplerShift=d, initialPhases=phi, rayCoupling=coupling,
+                       txAntenna=nr.AntennaPanel([2, 2], polarization="x", matlabOrder=True),
+                       rxAntenna=nr.AntennaPanel([1, 1], polarization="+", matlabOrder=True),
+                       txOrientation=[10, 20, 30], rxOrientation=[180, 0, 0],
+                       angleScaling=([130, 70, 80, 110], [5, 11, 3, 3]), stopBandAtten=70)
+    src = os.path.join(PLAY, 'CDL', 'MatlabFiles')
+    tx = scipy.io.loadmat(os.path.join(src, 'txWaveform.mat'))['txWaveform'].T          # (8, 30720)
+    rx_m = scipy.io.loadmat(os.path.join(src, 'rxWaveform.mat'))['rxWaveform'].T        # (2, 30720)
+    n = int(bwp.symbolLens[:3].sum())
+    tin = np.zeros_like(tx)                      # applyToSignal wants a whole slot: the rest is zero (causal filter: the
+    tin[:, :n] = tx[:, :n]                       # first n output samples do not depend on it)
+    rx = ch.applyToSignal(nr.Waveform(tin)).waveform[:, :n]
+    nmse = float((np.abs(rx - rx_m[:, :n]) ** 2).sum() / (np.abs(rx_m[:, :n]) ** 2).sum())
+    np.savez_compressed(os.path.join(GOLD, 'matlab_cdl.npz'), tx=tx[:, :n], rx_matlab=rx_m[:, :n], rx_ref=rx, nmse_ref=nmse,
+                        slot_len=np.int64(tx.shape[1]))
+    print('matlab_cdl: n', n, 'NMSE(reference vs MATLAB)', nmse)
 
 
 def coding():
@@ -490,6 +530,7 @@ if __name__ == '__main__':
             globals()[fn]()
         sys.exit(0)
     copy_matlab()
+    matlab_cdl()
     coding()
     phy()
     host()
