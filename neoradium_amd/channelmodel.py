@@ -105,6 +105,8 @@ class ChannelModel:
         return s
 
     def _staticOnDevice(self):
+        if getattr(self, '_static_per_slot', False):     # statistical models redraw their coefficients for every slot
+            self._static = None
         if self._static is None:
             A, nu, Alos, nulos = self.staticCoefficients()
             sc = self._normalisation()

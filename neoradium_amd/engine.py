@@ -30,6 +30,9 @@ def host_tables(pdsch, channel, codeRate, baseGraphNo=1):
     pilot table of every slot of the frame, the layer-mapped RE index, scrambling sequence and LDPC configuration of
     every codeword, the channel's static ray coefficients and tap matrix, the slot geometry.  PdschLink uploads these;
     the CPU oracle harness (oracle/link.py, tests/test_oracle_e2e.py) consumes the same dictionary."""
+    if getattr(channel, '_static_per_slot', False):
+        raise NotImplementedError("PdschLink: this channel model draws new random coefficients for every slot (TDL sosType="
+                                  "'Xiao'), a sequential process the batched engine does not reproduce; use the class surface")
     bwp = pdsch.bwp
     car = bwp.carrier
     dmrs = pdsch.dmrs

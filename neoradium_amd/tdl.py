@@ -82,8 +82,9 @@ class TdlChannel(ChannelModel):
         self.sosType = kwargs.get('sosType', 'GMEDS1')
         if self.sosType not in ['GMEDS1', 'Xiao']:
             raise ValueError(f"Unsupported 'sosType' ({self.sosType}). It must 'GMEDS1' or 'Xiao'.")
-        if self.sosType == 'Xiao':
-            raise NotImplementedError("sosType='Xiao' (fresh random phases every slot) is not built; use 'GMEDS1'")
+        # 'Xiao' is a statistical model: new random angles and phases for every slot (tdl.py:1043-1067), i.e. the "static"
+        # coefficients are rebuilt -- and the generator advanced -- whenever a slot is prepared
+        self._static_per_slot = self.sosType == 'Xiao'
         self.sosNumSins = kwargs.get('sosNumSins', 32)
         nr, nt = self.nrNt
         self.sosTheta1N = self.rangen.random(size=(1, self.sosNumSins, nr, nt, self.numPaths)) * 2 * np.pi
@@ -110,25 +111,40 @@ class TdlChannel(ChannelModel):
         (tdl.py:1084-1088); the LOS tap uses sqrt(k) of an amplitude that is already a square root (tdl.py:1117-1120)."""
         nr, nt = self.nrNt
         N_, P = self.sosNumSins, self.numPaths
-        a_n = np.pi * (np.arange(N_, dtype=np.float64) + .5) / (2 * N_)
-        a_0 = np.pi * (np.arange(P, dtype=np.float64) + 1) / (4 * N_ * (P + 2))
-        f1 = 2 * np.pi * self.dopplerShift * np.cos(a_n[:, None] + a_0[None, :])       # (N, P)
-        f2 = 2 * np.pi * self.dopplerShift * np.cos(a_n[:, None] - a_0[None, :])
-        th1 = self.sosTheta1N[0]                                                        # (N, nr, nt, P)
-        th2 = self.sosTheta2N[0]
-        amp = np.sqrt(2 / N_)
-        # rays: [ +f1 | -f1 | +f2 | -f2 | LOS ]
-        M = 4 * N_ + 1
-        A = np.zeros((nr, nt, P, M), dtype=np.complex128)
-        nu = np.zeros((P, M))
-        t1 = np.transpose(th1, (1, 2, 3, 0))                                            # (nr, nt, P, N)
-        t2 = np.transpose(th2, (1, 2, 3, 0))
-        A[..., 0 * N_:1 * N_] = 0.5 * amp * np.exp(1j * t1)
-        A[..., 1 * N_:2 * N_] = 0.5 * amp * np.exp(-1j * t1)
-        A[..., 2 * N_:3 * N_] = 0.5j * amp * np.exp(1j * t2)
-        A[..., 3 * N_:4 * N_] = 0.5j * amp * np.exp(-1j * t2)
-        nu[:, 0 * N_:1 * N_], nu[:, 1 * N_:2 * N_] = f1.T, -f1.T
-        nu[:, 2 * N_:3 * N_], nu[:, 3 * N_:4 * N_] = f2.T, -f2.T
+        if self.sosType == 'Xiao':
+            # tdl.py:1043-1067 (Xiao et al., "Novel sum-of-sinusoids simulation models ...", eq. 6-7): N unit phasors per
+            # (r,t,path), Doppler f_D cos(alpha_n) with alpha_n = (2 pi n + theta_n) / N; theta (per path) and phi (per
+            # r,t,path) are drawn from the channel's generator in the reference's order, one pair of draws per call
+            theta = self.rangen.random(size=(1, N_, 1, 1, P)) * 2 * np.pi - np.pi
+            phi = self.rangen.random(size=(1, N_, nr, nt, P)) * 2 * np.pi - np.pi
+            alpha = (2 * np.pi * (np.arange(N_, dtype=np.float64).reshape(1, -1, 1, 1, 1) + 1) + theta) / N_
+            M = N_ + 1                                                                      # + one LOS ray
+            A = np.zeros((nr, nt, P, M), dtype=np.complex128)
+            nu = np.zeros((P, M))
+            A[..., :N_] = np.sqrt(1 / N_) * np.exp(1j * np.transpose(phi[0], (1, 2, 3, 0)))
+            nu[:, :N_] = (self.dopplerShift * np.cos(alpha[0, :, 0, 0, :])).T
+            los_col = N_
+        else:
+          a_n = np.pi * (np.arange(N_, dtype=np.float64) + .5) / (2 * N_)
+          a_0 = np.pi * (np.arange(P, dtype=np.float64) + 1) / (4 * N_ * (P + 2))
+          f1 = 2 * np.pi * self.dopplerShift * np.cos(a_n[:, None] + a_0[None, :])       # (N, P)
+          f2 = 2 * np.pi * self.dopplerShift * np.cos(a_n[:, None] - a_0[None, :])
+          th1 = self.sosTheta1N[0]                                                        # (N, nr, nt, P)
+          th2 = self.sosTheta2N[0]
+          amp = np.sqrt(2 / N_)
+          # rays: [ +f1 | -f1 | +f2 | -f2 | LOS ]
+          M = 4 * N_ + 1
+          A = np.zeros((nr, nt, P, M), dtype=np.complex128)
+          nu = np.zeros((P, M))
+          t1 = np.transpose(th1, (1, 2, 3, 0))                                            # (nr, nt, P, N)
+          t2 = np.transpose(th2, (1, 2, 3, 0))
+          A[..., 0 * N_:1 * N_] = 0.5 * amp * np.exp(1j * t1)
+          A[..., 1 * N_:2 * N_] = 0.5 * amp * np.exp(-1j * t1)
+          A[..., 2 * N_:3 * N_] = 0.5j * amp * np.exp(1j * t2)
+          A[..., 3 * N_:4 * N_] = 0.5j * amp * np.exp(-1j * t2)
+          nu[:, 0 * N_:1 * N_], nu[:, 1 * N_:2 * N_] = f1.T, -f1.T
+          nu[:, 2 * N_:3 * N_], nu[:, 3 * N_:4 * N_] = f2.T, -f2.T
+          los_col = 4 * N_
         if not np.isscalar(self.correlationMatrix):                                     # tdl.py:1101-1110
             cm = self.correlationMatrix
             if self.normalizeGains:
@@ -138,8 +154,8 @@ class TdlChannel(ChannelModel):
         if self.hasLos:
             k1 = np.sqrt(toLinear(self.kFactorLos))
             A[:, :, 0, :] /= np.sqrt(k1 + 1)
-            A[:, :, 0, 4 * N_] = np.sqrt(k1) / np.sqrt(k1 + 1)
-            nu[0, 4 * N_] = self.losDopplerShift
+            A[:, :, 0, los_col] = np.sqrt(k1) / np.sqrt(k1 + 1)
+            nu[0, los_col] = self.losDopplerShift
         A = A * np.sqrt(toLinear(self.pathPowers)).reshape(1, 1, -1, 1)
         return A, nu, None, 0.0
 

@@ -644,3 +644,28 @@ def test_cdl_filtering_vs_matlab(dev):
     assert np.abs(rx - g['rx_ref']).max() <= 1e-11 * np.abs(g['rx_ref']).max()
     nmse = float((np.abs(rx - g['rx_matlab']) ** 2).sum() / (np.abs(g['rx_matlab']) ** 2).sum())
     assert nmse <= 1.05 * float(g['nmse_ref']) and nmse < 2e-4
+
+
+def test_tdl_xiao_channel_vs_reference(dev):
+    """TdlChannel(sosType='Xiao') on the class surface (tdl.py:1043-1067): new random angles / phases for every slot, drawn
+    from the package generator in the reference's order; gains of two consecutive slots and the channel matrix of the second
+    against the reference.  The batched engine refuses the model (sequential draws) instead of approximating it."""
+    import neoradium_amd as nr
+    g = np.load(os.path.join(GOLD, 'channels_xiao.npz'))
+    specs = [('B', dict(delaySpread=100, dopplerShift=70, sosType='Xiao')),
+             ('D', dict(delaySpread=30, dopplerShift=20, sosType='Xiao', txAntennaCount=2, rxAntennaCount=2, mimoCorrelation='Medium'))]
+    for i, (prof, kw) in enumerate(specs):
+        nr.random.setSeed(300 + i)
+        car = nr.Carrier(numRbs=25, spacing=15)
+        ch = nr.TdlChannel(car.curBwp, prof, **kw)
+        assert np.array_equal(ch.chanGainSamples, g[f'x{i}_samples0'])
+        assert np.abs(ch.chanGains - g[f'x{i}_gains0']).max() < 1e-11 * np.abs(g[f'x{i}_gains0']).max()
+        ch.goNext()
+        H = ch.getChannelMatrix()
+        assert np.array_equal(ch.chanGainSamples, g[f'x{i}_samples1'])
+        assert np.abs(ch.chanGains - g[f'x{i}_gains1']).max() < 1e-11 * np.abs(g[f'x{i}_gains1']).max()
+        assert np.abs(H[::6, ::25] - g[f'x{i}_H']).max() < 1e-10 * np.abs(g[f'x{i}_H']).max()
+    p = nr.PDSCH(car.curBwp, numLayers=1)
+    p.setDMRS(configType=1, additionalPos=1)
+    with pytest.raises(NotImplementedError):
+        nr.PdschLink(p, ch, 0.5)

@@ -177,3 +177,26 @@ def test_no_cpu_fallback():
         ma.Modem('QPSK').modulate(np.int8([0, 1, 1, 0]))
     with pytest.raises((RuntimeError, ValueError)):
         ma.LdpcEncoder().getRateMatchedCodeBlocks(np.zeros(100, dtype=np.int8), 400)
+
+
+def test_tdl_xiao_coefficients_vs_reference(monkeypatch):
+    """TDL sosType='Xiao' (tdl.py:1043-1067): a statistical model that draws new angles and phases for every slot.  The
+    host-built ray tensors reproduce the reference's gains of two consecutive preparations (same generator, same draw
+    order), SISO Rayleigh and 2x2 correlated with a LOS tap."""
+    from neoradium_amd import channelmodel
+    monkeypatch.setattr(channelmodel.ChannelModel, 'prepareForNextSlot', lambda self: None)
+    g = np.load(os.path.join(GOLD, 'channels_xiao.npz'))
+    specs = [('B', dict(delaySpread=100, dopplerShift=70, sosType='Xiao')),
+             ('D', dict(delaySpread=30, dopplerShift=20, sosType='Xiao', txAntennaCount=2, rxAntennaCount=2, mimoCorrelation='Medium'))]
+    for i, (prof, kw) in enumerate(specs):
+        ma.random.setSeed(300 + i)
+        car = ma.Carrier(numRbs=25, spacing=15)
+        ch = ma.TdlChannel(car.curBwp, prof, **kw)
+        for k in range(2):                                  # construction prepares slot 0, the next use prepares slot 1
+            A, nu, Alos, nulos = ch.staticCoefficients()
+            t = g[f'x{i}_samples{k}'][:-1] / ch.sampleRate
+            gains = np.einsum('rtnm,cnm->crtn', A, np.exp(2j * np.pi * t[:, None, None] * nu[None])) * ch._normalisation()
+            ref = g[f'x{i}_gains{k}']
+            assert Alos is None and np.abs(gains - ref).max() < 1e-11 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        ma.TdlChannel(car.curBwp, 'A', sosType='Jakes')

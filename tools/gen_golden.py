@@ -228,6 +228,26 @@ def channels():
     np.savez_compressed(os.path.join(GOLD, 'channels.npz'), **out)
 
 
+def channels_xiao():
+    """TDL with the statistical sum-of-sinusoids model (sosType='Xiao'): new random angles / phases are drawn for every slot,
+    so the fixture follows the generator: construction (first slot prepared), two goNext, the slot prepared again."""
+    out = {}
+    specs = [('B', dict(delaySpread=100, dopplerShift=70, sosType='Xiao')),
+             ('D', dict(delaySpread=30, dopplerShift=20, sosType='Xiao', txAntennaCount=2, rxAntennaCount=2, mimoCorrelation='Medium'))]
+    for i, (prof, kw) in enumerate(specs):
+        nr.random.setSeed(300 + i)
+        car = nr.Carrier(numRbs=25, spacing=15)
+        ch = nr.TdlChannel(car.curBwp, prof, **kw)
+        out[f'x{i}_samples0'] = ch.chanGainSamples
+        out[f'x{i}_gains0'] = ch.chanGains
+        ch.goNext()
+        H = ch.getChannelMatrix()                      # prepares slot 1: the second pair of draws
+        out[f'x{i}_samples1'] = ch.chanGainSamples
+        out[f'x{i}_gains1'] = ch.chanGains
+        out[f'x{i}_H'] = H[::6, ::25]
+    np.savez_compressed(os.path.join(GOLD, 'channels_xiao.npz'), **out)
+
+
 def chest():
     """Grid.estimateChannelLS with both subcarrier interpolators (complex-linear and polar-linear) and its noise
     side output, on noisy received grids of three small links (inputs: the received grid and the DMRS tables)."""
@@ -535,6 +555,7 @@ if __name__ == '__main__':
     phy()
     host()
     channels()
+    channels_xiao()
     snr_walks()
     harq_loop()
     polar()
