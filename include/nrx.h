@@ -435,7 +435,10 @@ int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, const int32_t*
  *   adds its 2^s0 penalties in leaf order -- same values, same path costs, far fewer sequential steps; msg_src[m]: which non-frozen leaf (in leaf order) carries message bit m after input
  *   de-interleaving (K entries).  msg_out: n_cw x K (first CRC-passing candidate, else the cheapest), crc_ok: n_cw;
  *   optional cand_out: n_cw x list_size x K and cost_out: n_cw x list_size (all candidates, cheapest first).
- *   crc_poly_id -1 = no CRC (cheapest candidate). */
+ *   crc_poly_id -1 = no CRC (cheapest candidate).  crc_expect (nullable, device, n_cw entries): the value the CRC register
+ *   over message + parity must end at for code word cw instead of 0 -- a mask XORed onto the parity bits (the RNTI of a
+ *   DCI, the effect of the 24 ones TS 38.212 7.3.2 prepends to the CRC input) moves the end value to the register value of
+ *   the mask alone, because the CRC is linear; one entry per code word lets one launch test candidates x RNTIs. */
 int32_t nrx_polar_encode(const uint8_t* cbs, int32_t n_cw, int32_t K, int32_t N, const int32_t* in_il,
                          const int32_t* msg_pos, const int32_t* pc_pos, int32_t n_pc, uint8_t* coded, void* stream);
 int32_t nrx_polar_rate_match(const uint8_t* coded, int32_t n_cw, int32_t N, int32_t E, const int32_t* gather,
@@ -445,8 +448,8 @@ int32_t nrx_polar_rate_recover_f64(const double* llr, int32_t n_cw, int32_t N, i
                                    void* stream);
 int32_t nrx_polar_scl_decode_f64(const double* llr, int32_t n_cw, int32_t N, int32_t list_size,
                                  const uint8_t* info_mask, int32_t n_info, const int32_t* msg_src, int32_t K,
-                                 int32_t crc_poly_id, uint8_t* msg_out, uint8_t* crc_ok, uint8_t* cand_out,
-                                 double* cost_out, void* stream);
+                                 int32_t crc_poly_id, const uint32_t* crc_expect, uint8_t* msg_out, uint8_t* crc_ok,
+                                 uint8_t* cand_out, double* cost_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,5 +27,6 @@ from .engine import PdschLink, run_sweep                       # noqa: F401
 
 try:                                                           # polar codec (control channel path)
     from .polar import PolarEncoder, PolarDecoder              # noqa: F401
+    from .pdcch import PDCCH                                   # noqa: F401
 except ImportError:                                            # pragma: no cover
     pass

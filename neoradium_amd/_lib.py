@@ -93,7 +93,7 @@ SIGNATURES.update({
     'nrx_polar_encode': (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     'nrx_polar_rate_match': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'nrx_polar_rate_recover_f64': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
-    'nrx_polar_scl_decode_f64': (i32, [vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]),
+    'nrx_polar_scl_decode_f64': (i32, [vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
 })
 
 _lib = None

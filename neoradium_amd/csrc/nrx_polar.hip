@@ -151,8 +151,9 @@ __device__ __forceinline__ void unrolled(F&& f) {
 // One wavefront per codeword.  info_mask[i] = 1 for every non-frozen leaf (message and parity-check bits).
 __global__ __launch_bounds__(64) void polar_scl_kernel(
     const double* __restrict__ llr_in, int n, int L, const uint8_t* __restrict__ info_mask, int k_info,
-    const int32_t* __restrict__ msg_src, int K, int crc_id, uint8_t* __restrict__ msg_out,
-    uint8_t* __restrict__ crc_ok, uint8_t* __restrict__ cand_out, double* __restrict__ cost_out) {
+    const int32_t* __restrict__ msg_src, int K, int crc_id, const uint32_t* __restrict__ crc_expect,
+    uint8_t* __restrict__ msg_out, uint8_t* __restrict__ crc_ok, uint8_t* __restrict__ cand_out,
+    double* __restrict__ cost_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const SclLayout lay = scl_layout(n, k_info);
   double* const lds_llr = reinterpret_cast<double*>(smem + lay.llr_off);
@@ -404,7 +405,10 @@ __global__ __launch_bounds__(64) void polar_scl_kernel(
       const uint32_t topb = ((reg >> (CL - 1)) ^ bit) & 1u;
       reg = ((reg << 1) & mask) ^ (topb ? low : 0u);
     }
-    pass = (reg == 0);
+    // plain CRC: the register over message + parity ends at zero.  A mask XORed onto the parity bits (a DCI's RNTI, the
+    // 24 ones prepended to the CRC input: TS 38.212 7.3.2) shifts that end value by the register value of the mask
+    // alone (the CRC is linear), which the caller passes per code word
+    pass = (reg == (crc_expect ? crc_expect[cw] : 0u));
   }
   const unsigned long long ok = __ballot(pass);
   const int best = ok ? (__ffsll((long long)ok) - 1) : 0;
@@ -469,8 +473,8 @@ int32_t nrx_polar_rate_recover_f64(const double* llr, int32_t n_cw, int32_t N, i
 
 int32_t nrx_polar_scl_decode_f64(const double* llr, int32_t n_cw, int32_t N, int32_t list_size,
                                  const uint8_t* info_mask, int32_t n_info, const int32_t* msg_src, int32_t K,
-                                 int32_t crc_poly_id, uint8_t* msg_out, uint8_t* crc_ok, uint8_t* cand_out,
-                                 double* cost_out, void* stream) {
+                                 int32_t crc_poly_id, const uint32_t* crc_expect, uint8_t* msg_out, uint8_t* crc_ok,
+                                 uint8_t* cand_out, double* cost_out, void* stream) {
   NRX_REQUIRE(llr && info_mask && msg_src && msg_out && crc_ok, NRX_E_ARG, "nrx_polar_scl_decode_f64: null pointer");
   NRX_REQUIRE(N >= 32 && N <= 1024 && (N & (N - 1)) == 0, NRX_E_SHAPE, "nrx_polar_scl_decode_f64: N=%d is not 2^5..2^10",
               N);
@@ -491,7 +495,7 @@ int32_t nrx_polar_scl_decode_f64(const double* llr, int32_t n_cw, int32_t N, int
                 hipGetErrorString(e));
   }
   hipLaunchKernelGGL(polar_scl_kernel, dim3(n_cw), dim3(64), lay.total, (hipStream_t)stream, llr, n, list_size,
-                     info_mask, n_info, msg_src, K, crc_poly_id, msg_out, crc_ok, cand_out, cost_out);
+                     info_mask, n_info, msg_src, K, crc_poly_id, crc_expect, msg_out, crc_ok, cand_out, cost_out);
   NRX_CHECK_LAUNCH("nrx_polar_scl_decode_f64");
   return NRX_OK;
 }

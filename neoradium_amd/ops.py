@@ -863,8 +863,9 @@ def polar_rate_recover(llr, N, K, inv_subblock, deinterleave=None):
     return out
 
 
-def polar_scl_decode(llr, info_mask, n_info, msg_src, list_size=8, crc_poly=None, want_candidates=False):
-    """polar.py:606-720 + :931-982: (n_cw, N) float64 -> msg (n_cw, K), crc_ok (n_cw,) [, cands (n_cw,L,K), costs]."""
+def polar_scl_decode(llr, info_mask, n_info, msg_src, list_size=8, crc_poly=None, want_candidates=False, crc_expect=None):
+    """polar.py:606-720 + :931-982: (n_cw, N) float64 -> msg (n_cw, K), crc_ok (n_cw,) [, cands (n_cw,L,K), costs].
+    ``crc_expect``: int32/uint32 device tensor (n_cw,), the CRC register value a passing candidate ends at (masked CRCs)."""
     if llr.dtype != torch.float64:
         raise ValueError("polar LLRs are float64")
     llr = llr.contiguous()
@@ -878,7 +879,11 @@ def polar_scl_decode(llr, info_mask, n_info, msg_src, list_size=8, crc_poly=None
     cands = torch.empty((n_cw, list_size, K), dtype=torch.uint8, device=dev) if want_candidates else None
     costs = torch.empty((n_cw, list_size), dtype=torch.float64, device=dev) if want_candidates else None
     crc_id = -1 if crc_poly is None else CRC_ID[crc_poly]
+    if crc_expect is not None:
+        if crc_expect.dtype != torch.int32 or crc_expect.numel() != n_cw or crc_expect.device != dev:
+            raise ValueError("crc_expect must be an int32 device tensor with one entry per code word")
+        crc_expect = crc_expect.contiguous()
     check(lib().nrx_polar_scl_decode_f64(ptr(llr), n_cw, N, int(list_size), ptr(info_mask.contiguous()), int(n_info),
-                                         ptr(_idx32(msg_src, K, 'msg_src')), K, crc_id, ptr(msg), ptr(ok), ptr(cands),
-                                         ptr(costs), stream()))
+                                         ptr(_idx32(msg_src, K, 'msg_src')), K, crc_id, ptr(crc_expect), ptr(msg), ptr(ok),
+                                         ptr(cands), ptr(costs), stream()))
     return (msg, ok, cands, costs) if want_candidates else (msg, ok)

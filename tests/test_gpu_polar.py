@@ -145,3 +145,50 @@ def test_polar_bad_arguments(dev):
         dec.recoverRate(np.zeros((1, 100)))
     with pytest.raises(ValueError):
         dec.decode(np.zeros((1, 64)))
+
+
+def test_pdcch_blind_decoding_vs_oracle(dev):
+    """The PDCCH candidate layer (neoradium_amd/pdcch.py; absent from the reference, defined by TS 38.212 7.3 / 38.211 7.3.2):
+    DCI encoding bit-identical to the oracle for every aggregation level (AL 8 / 16 repeat: E > N), and a batch of
+    monitoring occasions -- two DCIs for this UE at different aggregation levels, one for another UE, noise -- blind-decoded
+    over all 31 aligned candidates of a 16-CCE CORESET: the detections (RNTI-masked CRC tested inside the SCL kernel) and
+    payloads equal the oracle's, which tests the CRC the long way."""
+    import torch
+    import neoradium_amd as nr
+    from oracle import pdcch as opd
+    rng = np.random.default_rng(12)
+    A, rnti, other, n_id, n_cce = 44, 0x1A2B, 0x0C0D, 77, 16
+    pd = nr.PDCCH(n_cce, nID=n_id, rnti=rnti)
+    for al in (1, 2, 4, 8, 16):
+        a = rng.integers(0, 2, (3, A)).astype(np.uint8)
+        assert np.array_equal(pd.dciEncode(a, al).cpu().numpy(), opd.dci_encode(a, al, rnti))
+        sym = pd.encode(a, al).cpu().numpy()
+        assert np.abs(sym - opd.pdcch_symbols(opd.dci_encode(a, al, rnti), rnti, n_id)).max() < 1e-12
+    n_occ = 6
+    grid = np.zeros((n_occ, n_cce * 54), dtype=np.complex128)
+    sent = []
+    for o in range(n_occ):
+        a4, a2, ax = (rng.integers(0, 2, (1, A)).astype(np.uint8) for _ in range(3))
+        grid[o, 4 * 54:8 * 54] = pd.encode(a4, 4).cpu().numpy()[0]                 # this UE, AL 4 at CCE 4
+        grid[o, 10 * 54:12 * 54] = pd.encode(a2, 2).cpu().numpy()[0]               # this UE, AL 2 at CCE 10
+        grid[o, 0:54] = pd.encode(ax, 1, rnti=other).cpu().numpy()[0]              # another UE, AL 1 at CCE 0
+        sent.append((a4[0], a2[0]))
+    sigma = 0.45
+    noisy = grid + sigma / np.sqrt(2) * (rng.standard_normal(grid.shape) + 1j * rng.standard_normal(grid.shape))
+    found, bits, cands = pd.blindDecode(noisy, sigma ** 2, A)
+    found, bits = found.cpu().numpy(), bits.cpu().numpy()
+    assert len(cands) == 31 and found.shape == (n_occ, 31)
+    for o in range(n_occ):
+        ref = opd.blind_decode(noisy[o], sigma ** 2, A, rnti, n_id, cands)
+        assert [f for f, _ in ref] == found[o].tolist()
+        for i, (f, b) in enumerate(ref):
+            if f:
+                assert np.array_equal(bits[o, i], b)
+        assert found[o, cands.index((4, 4))] and np.array_equal(bits[o, cands.index((4, 4))], sent[o][0])
+        assert not found[o, cands.index((1, 0))]                                    # the other UE's DCI is not ours
+    hits = found.sum()
+    assert hits >= 2 * n_occ - 2                                                    # (AL 2 at this SNR may be missed)
+    # the other UE sees its own DCI and none of ours
+    f2, b2, _ = pd.blindDecode(noisy, sigma ** 2, A, rnti=other)
+    f2 = f2.cpu().numpy()
+    assert not f2[:, cands.index((4, 4))].any() and not f2[:, cands.index((2, 10))].any()
