@@ -2,7 +2,7 @@
 
 DMRS values depend only on (configuration, slotNoInFrame, symbol), so they are generated on the host once per
 slot number and cached; the kernels consume them as pilot tables (ops.chest_ls) or as a pre-filled grid template
-(engine).  PTRS (dmrs.py:554-797) is outside the PDSCH link path and not built.
+(engine).  PTRS (dmrs.py:554-797): configuration and insertion, like the reference (which has no PTRS-based estimator).
 """
 import numpy as np
 
@@ -103,10 +103,12 @@ class DMRS:
 
     @property
     def ptrsEnabled(self):
-        return False
+        return False if self.ptrs is None else (self.ptrs.timeDensity != 0)
 
     def setPTRS(self, **kwargs):
-        raise NotImplementedError("PTRS is not built in neoradium_amd (outside the PDSCH link-level hot path)")
+        """Attach phase-tracking reference signals (dmrs.py PTRS, TS 38.211 7.4.1.2) to this DMRS."""
+        self.ptrs = PTRS(self, **kwargs)
+        self._cache = {}
 
     def getSymSet(self):
         """DMRS symbol positions, TS 38.211 7.4.1.1.2 (dmrs.py:390-428)."""
@@ -188,6 +190,8 @@ class DMRS:
                 if len(rbs) == 0:
                     continue
                 k, v = self._portValues(p, li, l, rbs)
+                if li == 0 and self.ptrs is not None:           # the PTRS repeats the first DMRS symbol's r(n) (dmrs.py:538-539)
+                    self.ptrs.saveDmrsL0Values(self.pxxch.portSet[p], k, self._rawValues(p, l, rbs))
                 cur = grid.reTypeIds[p, l, k]
                 bad = ~np.isin(cur, [RES, UNA, DM])
                 if bad.any():
@@ -205,6 +209,17 @@ class DMRS:
                     if li == 0 and free[:len(base)].any():
                         marked += (base[free[:len(base)]] + sh).tolist()
         self.dataREs = [x for x in range(12) if x not in marked]
+        if self.ptrsEnabled:
+            self.ptrs.populateGrid(grid)
+
+    def _rawValues(self, p, l, rbs):
+        """r(n) of the port's DMRS subcarriers on symbol l without beta / w_f / w_t, in the order of _portValues."""
+        n = len(self._baseREs())
+        bwp = self.pxxch.bwp
+        off = bwp.startRb * n
+        r = self._sequence(l, self.cdmGroups[p], 2 * (off + bwp.numRbs * n))[off:]
+        rbs = np.asarray(rbs, dtype=np.int64)
+        return r[(rbs[:, None] * n + np.arange(n)[None, :])].reshape(-1)
 
     def getPilots(self):
         """Pilot table of the current slot: (pilots (P,nDs,nK), subcarriers (P,nK) int32, DMRS symbols)."""
@@ -240,6 +255,137 @@ class DMRS:
         print(s)
 
 
+# TS 38.211 Table 7.4.1.2.2-1: subcarrier offset k_ref^RE by DMRS configuration type, DMRS port and resourceElementOffset
+_PTRS_REF_RE = {1: [[0, 2, 6, 8], [2, 4, 8, 10], [1, 3, 7, 9], [3, 5, 9, 11]],
+                2: [[0, 1, 6, 7], [1, 6, 7, 0], [2, 3, 8, 9], [3, 8, 9, 2], [4, 5, 10, 11], [5, 10, 11, 4]]}
+
+
 class PTRS:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("PTRS is not built in neoradium_amd (outside the PDSCH link-level hot path)")
+    """Phase-tracking reference signals of a PDSCH (reference dmrs.py:554-797; TS 38.211 7.4.1.2, TS 38.214 5.1.6.3):
+    configuration (time / frequency density directly or from the MCS / bandwidth thresholds), the PTRS symbol set, and the
+    insertion into the grid (values: the first DMRS symbol's r(n) of the associated port at the same subcarrier).  PTRS REs
+    are excluded from the data REs by PDSCH.getReIndexes / getBitSizes.  Like the reference, nothing on the receive side
+    uses them (there is no common-phase-error estimator in the reference)."""
+
+    def __init__(self, dmrs, **kwargs):
+        self.pxxch = dmrs.pxxch
+        self.dmrs = dmrs
+        self.mcsi = kwargs.get('mcsi', None)
+        self.iMCS = kwargs.get('iMCS', None)
+        self.nRBi = kwargs.get('nRBi', None)
+        if (self.mcsi is not None) or (self.iMCS is not None) or (self.nRBi is not None):
+            if (self.mcsi is None) or (self.iMCS is None) or (self.nRBi is None):
+                raise ValueError("The parameters 'mcsi', 'iMCS', and 'nRBi' must all be None or all have valid values.")
+            # (dmrs.py:640-641, 649-650: the reference REJECTS Python lists here -- its type test is inverted -- so tuples /
+            #  arrays are what works; kept, it is argument checking a notebook can run into)
+            if type(self.mcsi) == list or len(self.mcsi) != 3:
+                raise ValueError("The parameters 'mcsi' must be a list with 3 values!")
+            if self.iMCS < self.mcsi[0]:
+                self.timeDensity = self.freqDensity = 0                 # PTRS disabled (TS 38.214 Table 5.1.6.3-1)
+            elif self.iMCS < self.mcsi[1]:
+                self.timeDensity = 4
+            elif self.iMCS < self.mcsi[2]:
+                self.timeDensity = 2
+            else:
+                self.timeDensity = 1
+            numRBs = len(self.pxxch.prbSet)
+            if type(self.nRBi) == list or len(self.nRBi) != 2:
+                raise ValueError("The parameters 'nRBi' must be a list with 2 values!")
+            if numRBs < self.nRBi[0]:
+                self.timeDensity = self.freqDensity = 0                 # Table 5.1.6.3-2
+            elif numRBs < self.nRBi[1]:
+                self.freqDensity = 2
+            else:
+                self.freqDensity = 4
+        else:
+            self.timeDensity = kwargs.get('timeDensity', 1)
+            if self.timeDensity not in [1, 2, 4]:
+                raise ValueError("Invalid 'timeDensity' value! (It must be 1, 2, or 4)")
+            if self.timeDensity >= len(self.pxxch.symSet):
+                self.timeDensity = 0                                    # TS 38.214 5.1.6.3
+            self.freqDensity = kwargs.get('freqDensity', 2)
+            if self.freqDensity not in [2, 4]:
+                raise ValueError("Invalid 'freqDensity' value! (It must be 2 or 4)")
+        self.reOffset = kwargs.get('reOffset', 0)
+        if self.reOffset in ['00', '01', '10', '11']:
+            self.reOffset = {'00': 0, '01': 1, '10': 2, '11': 3}[self.reOffset]
+        if self.reOffset not in [0, 1, 2, 3]:
+            raise ValueError("Invalid 'reOffset' value! (It must be 0, 1, 2, or 3)")
+        self.portSet = kwargs.get('portSet', self.pxxch.portSet[0:1])
+        self.dmrsL0Values = {portNo: {} for portNo in self.portSet}
+        self.epreRatio = kwargs.get('epreRatio', 0)
+        if self.epreRatio not in [0, 1]:
+            raise ValueError("Invalid 'epreRatio' value! (It must be 0 or 1)")
+        # PTRS symbols: every timeDensity-th symbol, counted from the last DMRS symbol (TS 38.211 7.4.1.2.2, dmrs.py:713-719)
+        self.symSet = []
+        skip = 0
+        if len(self.pxxch.symSet):
+            for sym in range(int(self.pxxch.symSet[0]), int(self.pxxch.symSet[-1]) + 1):
+                if sym in self.dmrs.symSet:
+                    skip = self.timeDensity
+                if skip == 0:
+                    if sym in self.pxxch.symSet:
+                        self.symSet += [sym]
+                    skip = self.timeDensity
+                skip -= 1
+
+    def __repr__(self): return self.print(getStr=True)
+
+    def print(self, indent=0, title="PTRS Properties:", getStr=False):
+        pad = indent * ' '
+        s = ("\n" if indent == 0 else "") + pad + title + "\n"
+        if (self.mcsi is not None) or (self.iMCS is not None) or (self.nRBi is not None):
+            s += pad + "  MCS1,MCS2,MCS3: %d %d %d\n" % (self.mcsi[0], self.mcsi[1], self.mcsi[2])
+            s += pad + "  Imcs: %d\n" % (self.iMCS)
+            s += pad + "  Nrb1, Nrb2: %d %d\n" % (self.nRBi[0], self.nRBi[1])
+        for name, val in (("timeDensity", "%d" % self.timeDensity), ("freqDensity", "%d" % self.freqDensity),
+                          ("reOffset", "%d" % self.reOffset), ("portSet", str(self.portSet)),
+                          ("epreRatio", "%d" % self.epreRatio), ("symSet", str(self.symSet))):
+            s += pad + f"  {name}: {val}\n"
+        if getStr:
+            return s
+        print(s)
+
+    def saveDmrsL0Value(self, portNo, k, value):
+        if portNo not in self.portSet:
+            return
+        self.dmrsL0Values[portNo][int(k)] = value
+
+    def saveDmrsL0Values(self, portNo, ks, values):
+        if portNo not in self.portSet:
+            return
+        self.dmrsL0Values[portNo].update(zip((int(k) for k in ks), values))
+
+    def populateGrid(self, grid):
+        """Write the PTRS values into ``grid`` (dmrs.py:740-797); called by DMRS.populateGrid."""
+        px = self.pxxch
+        if len(px.symSet) == 0 or len(self.dmrs.symSet) == 0:
+            return
+        slotMap = px.slotMap
+        beta = 1.0
+        if self.epreRatio == 0:
+            beta = toLinear([0, 3, 4.77, 6, 7, 7.78][len(self.portSet)] / 2)     # TS 38.214 Table 4.1-2
+        skip = [grid.retNameToId[n] for n in ("DMRS", "CSIRS_ZP", "CSIRS_NZP", "RESERVED")]
+        fine = [grid.retNameToId[n] for n in ("UNASSIGNED", "PTRS")]
+        for p, portNo in enumerate(px.portSet):
+            if portNo not in self.portSet:
+                continue
+            refRE = _PTRS_REF_RE[self.dmrs.configType][portNo][self.reOffset]
+            for l in self.symSet:
+                rbs = sorted(int(r) for r in slotMap[l])     # (interleaving shuffles the RBs of the map)
+                numRBs = len(rbs)
+                if numRBs == 0:
+                    continue
+                if (numRBs % self.freqDensity) == 0:
+                    refRB = px.rnti % self.freqDensity
+                else:
+                    refRB = px.rnti % (numRBs % self.freqDensity)
+                for kc in range(refRE + 12 * refRB, 12 * numRBs, 12 * self.freqDensity):
+                    k = rbs[kc // 12] * 12 + kc % 12
+                    cur = grid.reTypeIds[p, l, k]
+                    if cur in skip:
+                        continue
+                    if cur not in fine:
+                        raise ValueError(f"Trying to allocate the RE at ({p},{l},{k}) for PTRS," +
+                                         f"while it is currently allocated for \"{grid.reTypeAt(p, l, k)}\"!")
+                    grid[p, l, k] = (beta * self.dmrsL0Values[portNo][k], "PTRS")

@@ -669,3 +669,22 @@ def test_tdl_xiao_channel_vs_reference(dev):
     p.setDMRS(configType=1, additionalPos=1)
     with pytest.raises(NotImplementedError):
         nr.PdschLink(p, ch, 0.5)
+
+
+def test_engine_with_ptrs(dev):
+    """A PDSCH with PTRS through the engine: the PTRS REs are part of the slot templates (values per slot number), are
+    excluded from the data REs (G shrinks by exactly the number of PTRS REs x Qm) and the link decodes cleanly."""
+    import neoradium_amd as nr
+    cfg = dict(seed=5, numRbs=24, spacing=30, mod='16QAM', layers=2, dm=dict(configType=1, additionalPos=1),
+               chan=('cdl', 'C', 30, 5, [1, 2], [1, 1]), slot0=0)
+    car, bwp, p, ch = _slot(nr, cfg)
+    plain = nr.PdschLink(p, ch, 0.5, numIter=10, decoder="f64")
+    p.setPTRS(timeDensity=2, freqDensity=2)
+    link = nr.PdschLink(p, ch, 0.5, numIter=10, decoder="f64")
+    g = p.getGrid()
+    n_ptrs = int((g.reTypeIds == g.retNameToId['PTRS']).sum())
+    assert n_ptrs > 0 and link.G == plain.G - n_ptrs * 4
+    t = link.templates.cpu().numpy()
+    assert np.abs(t[0][g.reTypeIds == g.retNameToId['PTRS']] - g.grid[g.reTypeIds == g.retNameToId['PTRS']]).max() < 1e-14
+    hi = link.run(0, 4, 40.0, seed=2).cpu().numpy()
+    assert hi[0] == 0 and hi[2] == 0 and hi[3] == 4 * link.tbs

@@ -200,3 +200,35 @@ def test_tdl_xiao_coefficients_vs_reference(monkeypatch):
             assert Alos is None and np.abs(gains - ref).max() < 1e-11 * np.abs(ref).max()
     with pytest.raises(ValueError):
         ma.TdlChannel(car.curBwp, 'A', sosType='Jakes')
+
+
+def test_ptrs_vs_reference():
+    """PTRS (dmrs.py:554-797): densities from the MCS / bandwidth thresholds or set directly, the PTRS symbol set, the
+    inserted values and positions (with VRB interleaving, mapping type B, a partial allocation, DMRS type 2, both EPRE
+    ratios), and the data bits that remain -- against the reference, for two slots of the frame."""
+    import json
+    g = np.load(os.path.join(GOLD, 'ptrs.npz'))
+    cfgs = json.loads(str(g['cfgs']))
+    for i, c in enumerate(cfgs):
+        car = ma.Carrier(numRbs=c['numRbs'], spacing=c['spacing'])
+        pt = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c['pt'].items()}     # (JSON turned the tuples into lists)
+        p = ma.PDSCH(car.curBwp, numLayers=c['layers'], modulation=c['mod'], **c['pk'])
+        p.setDMRS(**c['dm'])
+        p.setPTRS(**pt)
+        assert [p.dmrs.ptrs.timeDensity, p.dmrs.ptrs.freqDensity] == g[f'p{i}_dens'].tolist()
+        assert list(p.dmrs.ptrs.symSet) == g[f'p{i}_syms'].tolist() and p.dmrs.ptrsEnabled
+        for slot in (0, 7):
+            car.slotNo = slot
+            grid = p.getGrid()
+            idx = np.nonzero(grid.reTypeIds == grid.retNameToId['PTRS'])
+            assert np.array_equal(np.int32(np.stack(idx)), g[f'p{i}_s{slot}_idx'])
+            assert np.abs(grid.grid[idx] - g[f'p{i}_s{slot}_val']).max() < 1e-14
+            assert [int(v) for v in p.getBitSizes(grid)] == g[f'p{i}_s{slot}_bits'].tolist()
+    assert "timeDensity" in repr(p.dmrs.ptrs)
+    with pytest.raises(ValueError):
+        p.setPTRS(timeDensity=3)
+    with pytest.raises(ValueError):
+        p.setPTRS(mcsi=[5, 10, 20], iMCS=12, nRBi=(10, 40))          # the reference rejects Python lists here (dmrs.py:640)
+    q = ma.PDSCH(car.curBwp)
+    with pytest.raises(ValueError):
+        q.setPTRS()                                                    # no DMRS yet

@@ -228,6 +228,35 @@ def channels():
     np.savez_compressed(os.path.join(GOLD, 'channels.npz'), **out)
 
 
+def ptrs():
+    """PTRS configuration + insertion (dmrs.py:554-797) on three PDSCHs: grid values at the PTRS REs, their positions, the bit
+    sizes left for data, the PTRS symbol set -- for slots 0 and 7."""
+    out = {}
+    cfgs = [dict(numRbs=25, spacing=15, layers=2, mod='16QAM', dm=dict(configType=1, additionalPos=1), pk={},
+                 pt=dict(timeDensity=2, freqDensity=2, reOffset='01')),
+            dict(numRbs=51, spacing=30, layers=3, mod='64QAM', dm=dict(configType=2, additionalPos=2),
+                 pk=dict(interleavingBundleSize=2, rnti=7), pt=dict(mcsi=(5, 10, 20), iMCS=12, nRBi=(10, 40), epreRatio=1, reOffset=2)),
+            dict(numRbs=24, spacing=60, layers=1, mod='QPSK', dm=dict(configType=1, additionalPos=0),
+                 pk=dict(symStart=2, symLen=9, mappingType='B', prbSet=list(range(3, 20)), rnti=3), pt=dict(timeDensity=1, freqDensity=4))]
+    import json
+    out['cfgs'] = np.array(json.dumps(cfgs))
+    for i, c in enumerate(cfgs):
+        car = nr.Carrier(numRbs=c['numRbs'], spacing=c['spacing'])
+        p = nr.PDSCH(car.curBwp, numLayers=c['layers'], modulation=c['mod'], **c['pk'])
+        p.setDMRS(**c['dm'])
+        p.setPTRS(**c['pt'])
+        out[f'p{i}_dens'] = np.int64([p.dmrs.ptrs.timeDensity, p.dmrs.ptrs.freqDensity])
+        out[f'p{i}_syms'] = np.int64(p.dmrs.ptrs.symSet)
+        for slot in (0, 7):
+            car.slotNo = slot
+            g = p.getGrid()
+            idx = np.nonzero(g.reTypeIds == g.retNameToId['PTRS'])
+            out[f'p{i}_s{slot}_idx'] = np.int32(np.stack(idx))
+            out[f'p{i}_s{slot}_val'] = g.grid[idx]
+            out[f'p{i}_s{slot}_bits'] = np.int64(p.getBitSizes(g))
+    np.savez_compressed(os.path.join(GOLD, 'ptrs.npz'), **out)
+
+
 def channels_xiao():
     """TDL with the statistical sum-of-sinusoids model (sosType='Xiao'): new random angles / phases are drawn for every slot,
     so the fixture follows the generator: construction (first slot prepared), two goNext, the slot prepared again."""
@@ -554,6 +583,7 @@ if __name__ == '__main__':
     coding()
     phy()
     host()
+    ptrs()
     channels()
     channels_xiao()
     snr_walks()
