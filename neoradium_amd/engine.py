@@ -152,7 +152,9 @@ class PdschLink:
             ri = np.int64(lms[0][0]) * self.L * self.K + np.int64(lms[0][1]) * self.K + np.int64(lms[0][2])
             inv = np.full(self.nl * self.L * self.K, -1, dtype=np.int32)
             if len(np.unique(ri)) != len(ri) or int(ri.min()) < 0 or int(ri.max()) >= len(inv) or len(ri) * self.cw[0]['qm'] != self.cw[0]['G']:
-                raise ValueError("PdschLink: the layer/RE map must address distinct grid elements, one per modulated symbol")
+                raise ValueError("PdschLink: the layer/RE map must address distinct grid elements, one per modulated symbol "
+                                 "(layers with different numbers of data REs -- e.g. PTRS on a subset of the ports -- make the "
+                                 "reference's layer mapping, pdsch.py:619-639, write some REs twice)")
             inv[ri] = np.arange(len(ri), dtype=np.int32)
             self.re_inv = D(inv)
         c0 = self.cw[0]     # (single-codeword attribute names kept: bench.py, the oracle harness and the tests use them)

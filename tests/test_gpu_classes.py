@@ -679,7 +679,12 @@ def test_engine_with_ptrs(dev):
                chan=('cdl', 'C', 30, 5, [1, 2], [1, 1]), slot0=0)
     car, bwp, p, ch = _slot(nr, cfg)
     plain = nr.PdschLink(p, ch, 0.5, numIter=10, decoder="f64")
-    p.setPTRS(timeDensity=2, freqDensity=2)
+    p.setPTRS(timeDensity=2, freqDensity=2)                 # PTRS on the first port only (the default) ...
+    with pytest.raises(ValueError):
+        # ... leaves the layers with different numbers of data REs, and the reference's layer mapping (pdsch.py:619-639, kept
+        # on the class surface) then writes 36 REs twice; the engine refuses instead of racing
+        nr.PdschLink(p, ch, 0.5, numIter=10, decoder="f64")
+    p.setPTRS(timeDensity=2, freqDensity=2, portSet=list(p.portSet))
     link = nr.PdschLink(p, ch, 0.5, numIter=10, decoder="f64")
     g = p.getGrid()
     n_ptrs = int((g.reTypeIds == g.retNameToId['PTRS']).sum())
