@@ -144,6 +144,9 @@ def cpu_baseline(link, snr_db, n_single=2, n_procs=None):
     zc = z[..., 0] + 1j * z[..., 1]
     _, det = link.run(0, n, snr_db, tb_bits=torch.from_numpy(tb), noise=D(zc), details=True)
     d = det[0][1]
+    # the same slots through the throughput path (fused rate recovery + decode + CRC where it applies): same verdicts
+    _, dv = link.run(0, n, snr_db, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
+    fused_equal = bool(torch.equal(torch.cat([x['cb_ok'].reshape(-1) for _, x in dv]), d['cb_ok'].reshape(-1)))
     torch.cuda.synchronize()
     F = d['F'].cpu().numpy()
     got_llr = d['llr'].cpu().numpy().astype(np.float64)
@@ -182,6 +185,7 @@ def cpu_baseline(link, snr_db, n_single=2, n_procs=None):
         dec_crc_diff += int((cb_ok[0].cpu().numpy().astype(bool) != ref['crc']).sum())
         dec_bit_diff += int((tb_o[0].cpu().numpy()[:nb] != want).sum())
     parity = dict(slots=len(refs), blocks=blocks, blocks_ok=ok, llr_max_rel_err=err,
+                  fused_entry_verdicts_equal_separate_stages=fused_equal,
                   chain={"crc_verdicts_differing": crc_diff, "hard_bits_differing": bit_diff},
                   decoder_on_oracle_llrs={"crc_verdicts_differing": dec_crc_diff, "hard_bits_differing": dec_bit_diff,
                                           "bit_exact": dec_crc_diff == 0 and dec_bit_diff == 0})

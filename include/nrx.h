@@ -139,11 +139,12 @@ int32_t nrx_ldpc_decode_rows_f64(const double* llr, int32_t n_cb, const nrx_ldpc
 
 /* ldpc.py:1330-1418 recoverRate (first transmission: rv 0, no HARQ soft buffer, no LBRM, no wrap-around repetition)
  * + ldpc.py:1495-1581 decode + ldpc.py:1584-1619 checkCrcAndMerge (C > 1: CRC24B per code block) in ONE launch (SURVEY 7
- * step 4): the decoder's initial fill gathers the de-interleaved LLRs straight from the demapper output
- * llr (n_tb, llr_len = G), fillers become the clipped LARGE_LLR in-register, and its tail writes the merged hard bits
+ * step 4): the decoder's initial fill reads the LLRs straight from the demapper output llr (n_tb, llr_len = G = sum E_r)
+ * in the per-code-block DE-INTERLEAVED layout nrx_qam_demap_cb_* writes (block r at offset_r, position e = q*(E_r/qm) + s:
+ * the buffer order of ldpc.py:1390-1397; contiguous loads), fillers become the clipped LARGE_LLR in-register, and its tail writes the merged hard bits
  * tb_out (n_tb, C*(cb_len-24)) and the per-code-block CRC verdicts cb_ok (n_tb*C); the (n_tb*C, N) rate-recovered LLRs and
- * the (n_tb*C, K) hard-bit matrix never exist in HBM.  Results are bit-identical to nrx_ldpc_rate_recover_f64 ->
- * nrx_ldpc_decode_rows_f64 -> nrx_ldpc_crc_merge.  n_rows: rows of the base graph to run (0 = as many as the received
+ * the (n_tb*C, K) hard-bit matrix never exist in HBM.  Results are bit-identical to nrx_ldpc_rate_recover_f64 (on the
+ * symbol-major LLRs of nrx_qam_demap_*) -> nrx_ldpc_decode_rows_f64 -> nrx_ldpc_crc_merge.  n_rows: rows of the base graph to run (0 = as many as the received
  * bits reach; raised to that number when smaller).  Returns NRX_E_UNSUPPORTED when (bg, Zc, C, rows) has no fused
  * instantiation (today: BG1, Zc 384, C > 1, <= 15 rows): the caller then uses the three separate entries. */
 int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
@@ -207,6 +208,23 @@ int32_t nrx_qam_demap_f64o32(const void* syms, int64_t sym_stride, const void* s
                              int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index,
                              int32_t n_sym, void* llr, int64_t llr_stride, int32_t n_batch, int32_t exact,
                              double nv_floor, void* stream);
+/* The same max-log demapper with the rate-recovery de-interleaver of ldpc.py:1390-1397 done by its stores: the G = n_sym*qm
+ * LLRs of an item are split into n_code_blocks blocks of E_r bits exactly as nrx_ldpc_cb_lens splits them (n_layers*qm
+ * granularity, smaller blocks first), and LLR (symbol s, bit q) of block r is written to  offset_r + q*(E_r/qm) + s  -- the
+ * position it has in the code block's circular buffer -- instead of offset_r + s*qm + q.  Stores stay coalesced (consecutive
+ * symbols = consecutive lanes = consecutive addresses per q).  This is the input layout of nrx_ldpc_recover_decode_merge_f64. */
+int32_t nrx_qam_demap_cb_f32(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,
+                             int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym,
+                             int32_t n_code_blocks, int32_t n_layers, void* llr, int64_t llr_stride, int32_t n_batch,
+                             double nv_floor, void* stream);
+int32_t nrx_qam_demap_cb_f64(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,
+                             int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym,
+                             int32_t n_code_blocks, int32_t n_layers, void* llr, int64_t llr_stride, int32_t n_batch,
+                             double nv_floor, void* stream);
+int32_t nrx_qam_demap_cb_f64o32(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,
+                                int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym,
+                                int32_t n_code_blocks, int32_t n_layers, void* llr, int64_t llr_stride, int32_t n_batch,
+                                double nv_floor, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ grid stages
  * grid.py:456-518 Grid.precode (wideband): grid (n_batch,nl,lk) x f (nt,nl; item b at f + b*f_stride elements,

@@ -99,12 +99,13 @@ template <uint32_t K> __device__ __forceinline__ uint32_t gf2_mulc24(uint32_t a)
 }
 
 // Fused front and back: rate recovery (ldpc.py:1330-1418, first transmission: rv 0, empty soft buffer,
-// no wrap-around repetition) is done by the initial fill, which gathers the de-interleaved LLRs straight from the
-// demapper's (n_tb, llr_len) output; the code-block CRC24B check and the merge into the transport block
+// no wrap-around repetition) is done by the initial fill, which reads the LLRs straight from the demapper's
+// (n_tb, llr_len) output -- written per code block in de-interleaved order by the demapper itself (nrx_qam_demap_* with
+// the code-block geometry: its stores stay coalesced, and this kernel's loads become contiguous; gathering the
+// symbol-major order here cost 3.6x the algorithmic HBM traffic, profiles/r2_decoder_traffic.json); the code-block CRC24B check and the merge into the transport block
 // (ldpc.py:1584-1619) are done by the tail.  Geometry as nrx_ldpc_enc.hip's RmGeom.
 struct FuseGeom {
   int C, e_small, n_small, f, qm, sys_len, F, llr_len, cb_len, payload;
-  uint32_t qm_magic;   // ceil(2^32 / qm)
 };
 struct FuseArgs {
   FuseGeom g;
@@ -169,7 +170,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     const bool live = cb < n_cb && one != 0;
     const int cbq = live ? cb : n_cb - 1;                   // (a wave without a code block loads an existing one)
     const double* in = FUSED ? llr : llr + (size_t)cbq * N;
-    int fE = 0, feq = 1, foff = 0;                         // FUSED: E_r, E_r / Qm, offset of the block in the LLR stream
+    int fE = 0, foff = 0;                                  // FUSED: E_r and the offset of the block in the LLR stream
     FuseGeom fg{};
     if constexpr (FUSED) {
       const fargs_t fa = fuse_args();
@@ -178,77 +179,49 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       const int t = cbq / fg.C, r = cbq - t * fg.C;
       if (r < fg.n_small) { fE = fg.e_small; foff = r * fg.e_small; }
       else { fE = fg.e_small + fg.f; foff = fg.n_small * fg.e_small + (r - fg.n_small) * fE; }
-      feq = fE / fg.qm;
       in = llr + (size_t)t * fg.llr_len;
     }
-    // element p of the rate-recovered (punctured) code word, clipped like ldpc.py:1536; + 0.0 turns -0.0 into +0.0
-    auto fetch = [&](int p) __attribute__((always_inline)) -> double {
+    // Element z of the column that starts at code-word position p0 (rate-recovered, punctured code word), clipped like
+    // ldpc.py:1536; + 0.0 turns -0.0 into +0.0.  FUSED: the block's E_r LLRs arrive DE-INTERLEAVED (buffer order, written
+    // that way by nrx_qam_demap_cb_*: position e = q*(E_r/Qm) + s of ldpc.py:1390-1397), so consecutive lanes read
+    // consecutive addresses.  Branch-free: every lane issues its load from a clamped address (all 35 loads of a lane are in
+    // flight together) and the value is selected afterwards.
+    // (zl: the lane index as a value the optimiser cannot see through, redefined for every code block: otherwise the
+    //  per-lane, per-column addresses and flags below -- invariant over the code-block loop -- are hoisted in front of it,
+    //  35 of them, spilled to scratch there, and come back one dependent round trip at a time: ~100 serial memory round
+    //  trips per code block)
+    int zl = z;
+    asm volatile("" : "+v"(zl));
+    auto fetch = [&](int p0) __attribute__((always_inline)) -> double {
       if constexpr (!FUSED) {
-        return clip10(in[p]) + 0.0;
+        return clip10(in[p0 + zl]) + 0.0;
       } else {
-        // branch-free: every lane issues its load (clamped address), the cases are selected afterwards
-        const bool filler = p >= fg.sys_len && p < fg.sys_len + fg.F;     // LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
-        const int ci = p < fg.sys_len ? p : p - fg.F;                     // position in the circular buffer (no fillers)
-        const bool sent = ci < fE;
-        const int cic = sent ? ci : 0;
-        const int q = cic / feq;
-        const int src = foff + (cic - q * feq) * fg.qm + q;               // de-interleave: x[e] = rx[(e mod E/Qm)*Qm + e div (E/Qm)]
-        const double x = in[src < fg.llr_len ? src : fg.llr_len - 1];
-        const double v = (sent && src < fg.llr_len) ? clip10(x) + 0.0 : 0.0;   // short input is zero padded (ldpc.py:1401-1402)
+        // lanes [0, a): before the fillers (buffer position p0 + z); [a, b): fillers; [b, Zc): behind them (p0 - F + z);
+        // transmitted iff the buffer position is < E_r, i.e. z < t1 resp. z < t2 -- four wave-uniform thresholds per column
+        const int a = fg.sys_len - p0, b = a + fg.F, t1 = fE - p0, t2 = t1 + fg.F;
+        const bool use1 = zl < a && zl < t1, use2 = zl >= b && zl < t2;
+        const double x = in[foff + (use1 ? p0 + zl : (use2 ? p0 - fg.F + zl : 0))];
+        // (the selection is recomputed from an opaque copy of the lane index: otherwise the flags of all 35 columns are kept
+        //  alive across the loads -- 11 of them went to scratch and came back one dependent round trip at a time)
+        int zz = zl;
+        asm volatile("" : "+v"(zz));
+        const bool sent = (zz < a && zz < t1) || (zz >= b && zz < t2);
+        const bool filler = zz >= a && zz < b;                             // LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
+        const double v = sent ? clip10(x) + 0.0 : 0.0;
         return filler ? 1e10 : v;
       }
     };
     // ---- load: prepend the two punctured columns as zeros (ldpc.py:1536-1538)
-    if constexpr (!FUSED) {
-      static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
-        constexpr int c = decltype(cc)::value;
-        if constexpr (c < 2) Ps[c * ZS + z] = 0.0;
-        else Ps[c * ZS + z] = fetch((c - 2) * ZC + z);
-      });
-    } else {
-      // The core columns are linear in the code-word position (column stride = Zc): element p sits at Ps[2*Zc + p].
-      // (a) what no received LLR reaches: the punctured columns, the fillers, the untransmitted tail
-      static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
-        constexpr int c = decltype(cc)::value;
-        if constexpr (c < 2) {
-          Ps[c * ZS + z] = 0.0;
-        } else {
-          const int p = (c - 2) * ZC + z;
-          if (p >= fg.sys_len && p < fg.sys_len + fg.F) Ps[c * ZS + z] = 1e10;   // LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
-          else if ((p < fg.sys_len ? p : p - fg.F) >= fE) Ps[c * ZS + z] = 0.0;
-        }
-      });
-      // (b) one coalesced sweep over the block's E_r LLRs in the order the demapper wrote them (symbol-major, Qm bits
-      // per symbol): LLR i = (symbol s, bit q) de-interleaves to buffer position q*(E/Qm) + s (ldpc.py:1390-1397); core
-      // positions are scattered into LDS, the extension columns are fetched in (c)
-      const uint32_t magic = fuse_args()->g.qm_magic;        // ceil(2^32 / Qm): i / Qm = umulhi(i, magic) for i < 2^16
-      constexpr int UN = 12;                                 // loads in flight per lane (one round trip per UN*Zc LLRs)
-      for (int i0 = 0; i0 < fE; i0 += UN * ZC) {
-        double v[UN];
-        int pp[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const int i = i0 + u * ZC + z;
-          const int sidx = (int)__umulhi((uint32_t)i, magic), q = i - sidx * fg.qm;
-          const int ci = q * feq + sidx;
-          const int p = ci < fg.sys_len ? ci : ci + fg.F;
-          const int src = foff + i;
-          pp[u] = (i < fE && p < 24 * ZC) ? p : -1;
-          // unconditional load from a clamped address (every lane issues it, nothing branches around it); short input is
-          // zero padded (ldpc.py:1401-1402)
-          const double x = in[src < fg.llr_len ? src : fg.llr_len - 1];
-          v[u] = src < fg.llr_len ? x : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-          if (pp[u] >= 0) Ps[2 * ZC + pp[u]] = clip10(v[u]) + 0.0;
-      }
-    }
+    static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (c < 2) Ps[c * ZS + zl] = 0.0;
+      else Ps[c * ZS + zl] = fetch((c - 2) * ZC);
+    });
     static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
       constexpr int L = decltype(lc)::value;
       m1[L] = 0.0;
       m2[L] = 0.0;
-      if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC + z);   // (c)
+      if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC);
     });
     static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
     static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
@@ -305,7 +278,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // (the "was edge j the minimum" tests go into SGPR pairs a few edges ahead of their use: a VALU-written mask
           //  needs wait states before v_cndmask may read it; all D at once would hold 19 SGPR pairs and the allocator
           //  then re-issues compares instead)
-          constexpr int CH = 5;
+          constexpr int CH = 19;      // (5 left 2-8 scratch accesses per iteration in the layer loop, 19 = the whole layer none)
           uint32_t wrun = word << (top - (D - 1));           // sign of edge D-1 at bit 31; doubled per edge
           static_for<(D + CH - 1) / CH>([&](auto kc) __attribute__((always_inline)) {
             constexpr int hi = D - 1 - decltype(kc)::value * CH;            // edges hi, hi-1, ... of this chunk
@@ -404,10 +377,12 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
 
     // ---- hard decisions of the information columns (ldpc.py:1578-1581)
     if constexpr (!FUSED) {
+      int zh = z;
+      asm volatile("" : "+v"(zh));
       if (live) {
         static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
           constexpr int c = decltype(cc)::value;
-          hard[(size_t)cb * K + c * ZC + z] = Ps[c * ZS + z] < 0.0 ? 1 : 0;
+          hard[(size_t)cb * K + c * ZC + zh] = Ps[c * ZS + zh] < 0.0 ? 1 : 0;
         });
       }
     } else {
@@ -417,6 +392,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       // (lane z weighs x^(Zc-1-z)).  The common factor x^(...) against the reference's long division (chancodebase.py:
       // 119-128) is invertible mod g, so the remainder is zero for exactly the same bit strings.
       uint32_t v = 0;
+      int zt = z;
+      asm volatile("" : "+v"(zt));                          // (as zl above: nothing of the tail is computed in front of the loop)
       const int cbm = live ? cb : 0;
       const fargs_t fa = fuse_args();
       const int payload = fa->g.payload, cb_len = fa->g.cb_len;
@@ -424,22 +401,21 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
         constexpr uint32_t w = gf2_xpow24((uint32_t)((B::KB - 1 - c) * ZC));
-        const int n = c * ZC + z;
-        const uint32_t bit = Ps[c * ZS + z] < 0.0 ? 1u : 0u;
-        if (live && n < payload) dst[n] = (uint8_t)bit;
-        v ^= (n < cb_len && bit) ? w : 0u;
+        const uint32_t bit = Ps[c * ZS + zt] < 0.0 ? 1u : 0u;
+        if (live && zt < payload - c * ZC) dst[c * ZC + zt] = (uint8_t)bit;    // (thresholds are wave-uniform)
+        v ^= (zt < cb_len - c * ZC && bit) ? w : 0u;
       });
       // join inside the wave: level k pairs blocks of 2^k lanes, left * x^(2^k) + right
       static_for<6>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         const uint32_t other = (uint32_t)__shfl_xor((int)v, 1 << k, 64);
-        const bool upper = (z >> k) & 1;
+        const bool upper = (zt >> k) & 1;
         v = gf2_mulc24<gf2_xpow24(1u << k)>(upper ? other : v) ^ (upper ? v : other);
       });
       uint32_t* red = (uint32_t*)Praw;                      // the padding in front of the columns is never addressed
-      if ((z & 63) == 0) red[slot * (ZC / 64) + (z >> 6)] = v;
+      if ((zt & 63) == 0) red[slot * (ZC / 64) + (zt >> 6)] = v;
       __syncthreads();
-      if (z == 0 && live) {
+      if (zt == 0 && live) {
         uint32_t tot = 0;
         for (int w = 0; w < ZC / 64; ++w) tot = gf2_mulc24<gf2_xpow24(64)>(tot) ^ red[slot * (ZC / 64) + w];
         fa->cb_ok[cb] = tot == 0 ? 1 : 0;
@@ -521,14 +497,13 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t 
   fg.n_small = cfg->C - gb % cfg->C;
   fg.sys_len = cfg->K - 2 * cfg->Zc - cfg->F;
   fg.payload = cfg->cb_len - 24;
-  fg.qm_magic = (uint32_t)((0x100000000ull + (uint64_t)qm - 1) / (uint64_t)qm);
   const int e_max = fg.e_small + (fg.n_small < cfg->C ? f : 0);
   // the rows that can matter for e_max received bits (as ops.ldpc_active_rows): never fewer than the caller asks for
   const int last = e_max - 1 + (e_max > fg.sys_len ? cfg->F : 0);
   int need = last / cfg->Zc + 2 - 26 + 1 + 4;
   if (need < 4) need = 4;
   if (n_rows < need) n_rows = need;
-  if (cfg->C < 2 || cfg->cb_len <= 24 || e_max > cfg->N - cfg->F || e_max >= 65536 || fg.e_small % qm || (fg.e_small + f) % qm || !chip64_covers(cfg, n_rows)) {
+  if (cfg->C < 2 || cfg->cb_len <= 24 || e_max > cfg->N - cfg->F || fg.n_small * fg.e_small + (cfg->C - fg.n_small) * (fg.e_small + f) != llr_len || fg.e_small % qm || (fg.e_small + f) % qm || !chip64_covers(cfg, n_rows)) {
     ::nrx::set_error("nrx_ldpc_recover_decode_merge: no fused instantiation for bg %d Zc %d C %d rows %d", cfg->bg, cfg->Zc, cfg->C, n_rows);
     return NRX_E_UNSUPPORTED;
   }

@@ -107,12 +107,18 @@ pdsch_populate_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, con
 // QM is a template parameter: the per-axis minima live in registers and the level loop unrolls.  The float-output
 // (throughput) instantiation multiplies by 1/s2 instead of dividing twice per bit; the double-output one keeps the
 // reference's divisions so that it stays bit-identical to NumPy.
+// Code-block de-interleaving done by the demapper's stores (nrx_qam_demap_cb_*): E_r = e_small for the first n_small blocks,
+// e_small + f for the others (ldpc.py:846-856); e_small = 0: plain symbol-major output.
+struct DeintGeom {
+  int e_small, n_small, f;
+};
+
 template <typename T, typename TL, int QM>
 __global__ void __launch_bounds__(256)
 qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __restrict__ scales,
                  const T* __restrict__ noise_var, int nv_stride, const uint8_t* __restrict__ scr, double scale,
                  const int32_t* __restrict__ re_index, int n_sym, TL* __restrict__ llr, int64_t llr_stride,
-                 int n_batch, double nv_floor) {
+                 int n_batch, double nv_floor, DeintGeom dg) {
   constexpr int h = QM / 2;
   constexpr bool RECIP = sizeof(TL) == 4;
   double lev[h > 0 ? (1 << h) : 1];
@@ -127,7 +133,18 @@ qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __
     nv = nv > nv_floor ? nv : nv_floor;  // pdsch.py:966 max(noiseVar, 1e-10)
     const double sc = scales ? (double)scales[(size_t)b * sym_stride + src] : 1.0;
     const double rn = RECIP ? sc / nv : 0.0;
+    // LLR q of symbol i goes to i*QM + q (the reference's order), or -- code-block option -- to its de-interleaved place
+    // inside its code block: position q*(E_r/QM) + s of block r (ldpc.py:1390-1397 done by the store; stride dq between the
+    // QM values of a symbol, consecutive symbols = consecutive lanes = consecutive addresses)
     TL* dst = llr + (size_t)b * llr_stride + (size_t)i * QM;
+    int dq = 1;
+    if (dg.e_small > 0) {
+      const int ss = dg.e_small / QM, split = dg.n_small * ss;
+      int r, sidx, off;
+      if (i < split) { r = i / ss; sidx = i - r * ss; dq = ss; off = r * dg.e_small; }
+      else { dq = (dg.e_small + dg.f) / QM; r = (i - split) / dq; sidx = (i - split) - r * dq; off = dg.n_small * dg.e_small + r * (dg.e_small + dg.f); }
+      dst = llr + (size_t)b * llr_stride + off + sidx;
+    }
     if constexpr (QM == 1) {
       const double d0 = ((double)y.re - scale) * ((double)y.re - scale) + ((double)y.im - scale) * ((double)y.im - scale);
       const double d1 = ((double)y.re + scale) * ((double)y.re + scale) + ((double)y.im + scale) * ((double)y.im + scale);
@@ -168,7 +185,7 @@ qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __
         }
       }
 #pragma unroll
-      for (int q = 0; q < QM; ++q) dst[q] = out[q];
+      for (int q = 0; q < QM; ++q) dst[(size_t)q * dq] = out[q];
     }
   }
 }
@@ -263,8 +280,18 @@ int32_t populate_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* 
 template <typename T, typename TL>
 int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var, int32_t nv_stride,
                     const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym, void* llr,
-                    int64_t llr_stride, int32_t n_batch, int32_t exact, double nv_floor, void* stream) {
+                    int64_t llr_stride, int32_t n_batch, int32_t exact, double nv_floor, void* stream,
+                    int32_t n_code_blocks = 0, int32_t n_layers = 0) {
   NRX_REQUIRE(syms && noise_var && llr, NRX_E_ARG, "nrx_qam_demap: NULL buffer");
+  DeintGeom dg{0, 0, 0};
+  if (n_code_blocks > 0) {      // per-code-block de-interleaved output (E_r split as nrx_ldpc_cb_lens, ldpc.py:846-856)
+    NRX_REQUIRE(!exact && n_layers >= 1, NRX_E_UNSUPPORTED, "nrx_qam_demap_cb: max-log LLRs only, n_layers >= 1");
+    const int f = n_layers * qm, G = n_sym * qm, gb = (G + f - 1) / f;
+    NRX_REQUIRE(G % f == 0 && gb / n_code_blocks > 0, NRX_E_SHAPE, "nrx_qam_demap_cb: G=%d is not %d code blocks of multiples of %d bits", G, n_code_blocks, f);
+    dg.e_small = (gb / n_code_blocks) * f;
+    dg.n_small = n_code_blocks - gb % n_code_blocks;
+    dg.f = f;
+  }
   NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_qam_demap: unsupported modulation order %d", qm);
   NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && llr_stride >= (int64_t)n_sym * qm, NRX_E_SHAPE, "nrx_qam_demap: bad sizes");
   if (n_sym == 0 || n_batch == 0) return NRX_OK;
@@ -278,7 +305,7 @@ int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, co
   case Q:                                                                                                              \
     hipLaunchKernelGGL((qam_demap_kernel<T, TL, Q>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,      \
                        sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qam_scale(Q), re_index,      \
-                       n_sym, (TL*)llr, llr_stride, n_batch, nv_floor);                                                \
+                       n_sym, (TL*)llr, llr_stride, n_batch, nv_floor, dg);                                            \
     break;
     switch (qm) {
       NRX_DEMAP_CASE(1)
@@ -318,6 +345,18 @@ extern "C" int32_t nrx_qam_map_f64(const uint8_t* bits, int64_t bits_stride, con
 NRX_DEMAP(nrx_qam_demap_f32, float, float)
 NRX_DEMAP(nrx_qam_demap_f64, double, double)
 NRX_DEMAP(nrx_qam_demap_f64o32, double, float)
+#define NRX_DEMAP_CB(NAME, T, TL)                                                                                  \
+  extern "C" int32_t NAME(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,         \
+                          int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym, \
+                          int32_t n_code_blocks, int32_t n_layers, void* llr, int64_t llr_stride, int32_t n_batch, \
+                          double nv_floor, void* stream) {                                                         \
+    NRX_REQUIRE(n_code_blocks >= 1, NRX_E_ARG, "nrx_qam_demap_cb: n_code_blocks must be >= 1");                    \
+    return demap_entry<T, TL>(syms, sym_stride, scales, noise_var, nv_stride, scr, qm, re_index, n_sym, llr,       \
+                              llr_stride, n_batch, 0, nv_floor, stream, n_code_blocks, n_layers);                  \
+  }
+NRX_DEMAP_CB(nrx_qam_demap_cb_f32, float, float)
+NRX_DEMAP_CB(nrx_qam_demap_cb_f64, double, double)
+NRX_DEMAP_CB(nrx_qam_demap_cb_f64o32, double, float)
 
 extern "C" int32_t nrx_pdsch_populate_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) { return populate_entry<float>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, stream); }
 extern "C" int32_t nrx_pdsch_populate_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) { return populate_entry<double>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, stream); }

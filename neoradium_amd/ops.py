@@ -188,9 +188,10 @@ def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False, rows=None):
 
 def ldpc_recover_decode_merge(llr, cfg, nl, qm, n_iter, rows=0):
     """recoverRate (first transmission) + decode + checkCrcAndMerge in one launch (nrx_ldpc_recover_decode_merge_f64):
-    (n_tb, G) float64 demapper LLRs -> (tb_out (n_tb, C*(cb_len-24)), cb_ok (n_tb, C)), bit-identical to
-    ldpc_rate_recover -> ldpc_decode(rows=...) -> ldpc_crc_merge.  Returns None when this configuration has no fused
-    instantiation (the caller then runs the three separate stages)."""
+    (n_tb, G) float64 LLRs in the per-code-block de-interleaved layout of ``qam_demap(code_blocks=(C, nl))`` ->
+    (tb_out (n_tb, C*(cb_len-24)), cb_ok (n_tb, C)), bit-identical to ldpc_rate_recover (on the symbol-major LLRs) ->
+    ldpc_decode(rows=...) -> ldpc_crc_merge.  Returns None when this configuration has no fused instantiation (the caller
+    then runs the three separate stages on symbol-major LLRs)."""
     if llr.dtype != torch.float64 or llr.dim() != 2:
         return None
     if not (cfg.bg == 1 and cfg.Zc == 384 and cfg.C > 1):          # (cheap pre-check; the library decides)
@@ -206,6 +207,18 @@ def ldpc_recover_decode_merge(llr, cfg, nl, qm, n_iter, rows=0):
         return None
     check(rc)
     return tb_out, cb_ok
+
+
+def ldpc_fused_supported(cfg, nl, qm, G, rows):
+    """Host-side mirror of nrx_ldpc_recover_decode_merge_f64's capability test (so that a caller can choose the demapper's
+    output layout before it demaps)."""
+    if rows is None or not (cfg.bg == 1 and cfg.Zc == 384 and cfg.iLS == 1 and cfg.C > 1 and cfg.cb_len > 24):
+        return False
+    f = nl * qm
+    if G % f:
+        return False
+    lens = _lib.ldpc_cb_lens(G, cfg.C, nl, qm)
+    return int(rows) <= 15 and ldpc_active_rows(cfg, max(lens)) <= 15 and max(lens) <= cfg.N - cfg.F and sum(lens) == G
 
 
 def ldpc_crc_merge(dec, cfg, want_tb=True, want_tb_crc=True):
@@ -310,8 +323,10 @@ def pdsch_populate(bits, qm, scr, re_inv, templates, templ_sel):
 
 
 def qam_demap(syms, noise_var, qm, n_sym=None, scr=None, re_index=None, scales=None, exact=False, nv_floor=0.0,
-              llr_dtype=None):
-    """Modem.getLLRsFromSymbols / PDSCH.getLLRsFromGrid: (n, E) complex -> (n, n_sym*qm) LLRs."""
+              llr_dtype=None, code_blocks=None):
+    """Modem.getLLRsFromSymbols / PDSCH.getLLRsFromGrid: (n, E) complex -> (n, n_sym*qm) LLRs.
+    ``code_blocks`` = (C, n_layers): write every code block's LLRs de-interleaved (nrx_qam_demap_cb_*: the input layout of
+    :func:`ldpc_recover_decode_merge`) instead of symbol-major."""
     flat = syms.reshape(syms.shape[0], -1).contiguous()
     n, E = flat.shape
     sfx, rt = _ct(flat)
@@ -340,6 +355,13 @@ def qam_demap(syms, noise_var, qm, n_sym=None, scr=None, re_index=None, scales=N
     elif llr_dtype != rt:
         raise ValueError("unsupported LLR dtype for this input type")
     llr = torch.empty((n, n_sym * qm), dtype=llr_dtype, device=dev)
+    if code_blocks is not None:
+        if exact:
+            raise ValueError("code_blocks: max-log LLRs only")
+        fn = getattr(lib(), 'nrx_qam_demap_cb_' + sfx)
+        check(fn(ptr(flat), E, ptr(sc), ptr(nv), 0 if nv.numel() == 1 else 1, ptr(scr_t), qm, ptr(ri), n_sym,
+                 int(code_blocks[0]), int(code_blocks[1]), ptr(llr), n_sym * qm, n, float(nv_floor), stream()))
+        return llr
     fn = getattr(lib(), 'nrx_qam_demap_' + sfx)
     check(fn(ptr(flat), E, ptr(sc), ptr(nv), 0 if nv.numel() == 1 else 1, ptr(scr_t), qm, ptr(ri), n_sym, ptr(llr),
              n_sym * qm, n, 1 if exact else 0, float(nv_floor), stream()))

@@ -323,15 +323,34 @@ def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_e
     rr = ops.ldpc_rate_recover(x, cfg, nl, qm)
     dec = ops.ldpc_decode(rr, cfg, 12, rows=rows)
     tb_ref, ok_ref, _ = ops.ldpc_crc_merge(dec, cfg, want_tb_crc=False)
-    got = ops.ldpc_recover_decode_merge(x, cfg, nl, qm, 12, rows=rows)
+    # the fused entry reads every code block's LLRs de-interleaved (what nrx_qam_demap_cb_* writes): buffer position
+    # q*(E_r/Qm) + s instead of s*Qm + q (ldpc.py:1390-1397)
+    xd = np.empty_like(llr)
+    off = 0
+    for E in lens:
+        xd[:, off:off + E] = llr[:, off:off + E].reshape(n_tb, E // qm, qm).transpose(0, 2, 1).reshape(n_tb, E)
+        off += E
+    xd = torch.from_numpy(xd).to(dev)
+    assert ops.ldpc_fused_supported(cfg, nl, qm, G, rows)
+    got = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, 12, rows=rows)
     assert got is not None, "no fused instantiation for BG1 / Zc 384 / <= 15 rows"
     tb_out, ok = got
     assert torch.equal(ok, ok_ref) and torch.equal(tb_out, tb_ref)
     n_ok = int(ok.sum())
     assert 0 < n_ok < ok.numel(), f"want both outcomes, got {n_ok}/{ok.numel()} passing"
     # rows = 0: the library works the row count out itself
-    tb2, ok2 = ops.ldpc_recover_decode_merge(x, cfg, nl, qm, 12, rows=0)
+    tb2, ok2 = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, 12, rows=0)
     assert torch.equal(ok2, ok_ref) and torch.equal(tb2, tb_ref)
     # unsupported configurations are reported, not approximated: Zc 352
     cfg2 = _lib.ldpc_config(1, 7500 * 3)
-    assert cfg2.Zc != 384 and ops.ldpc_recover_decode_merge(x[:, :cfg2.C * 1200], cfg2, nl, qm, 5) is None
+    assert cfg2.Zc != 384 and ops.ldpc_recover_decode_merge(xd[:, :cfg2.C * 1200], cfg2, nl, qm, 5) is None
+    assert not ops.ldpc_fused_supported(cfg2, nl, qm, cfg2.C * 1200, 15)
+    # the demapper's code-block option produces exactly that layout: same values as the symbol-major demap, permuted
+    n_sym = G // qm
+    sym = torch.from_numpy(rng.standard_normal((2, n_sym)) + 1j * rng.standard_normal((2, n_sym))).to(dev)
+    std = ops.qam_demap(sym, 0.3, qm).cpu().numpy()
+    dei = ops.qam_demap(sym, 0.3, qm, code_blocks=(cfg.C, nl)).cpu().numpy()
+    off = 0
+    for E in lens:
+        assert np.array_equal(dei[:, off:off + E], std[:, off:off + E].reshape(2, E // qm, qm).transpose(0, 2, 1).reshape(2, E))
+        off += E
