@@ -286,13 +286,14 @@ int32_t nrx_random_bits(uint8_t* out, int64_t n_per, int32_t n_batch, uint64_t s
 /* ------------------------------------------------------------------------------------------------------ OFDM
  * grid.py:521-582 Grid.ofdmModulate (f0=0) + waveform.py:380-470 applyWindowing: grid rows (n_rows = items*ports,
  * each n_sym x K) -> waveform rows of wave_stride samples (slot length = sum(cp)+n_sym*nfft used).
- * cp_lens: HOST array of n_sym CP lengths.  window_len: raised-cosine overlap length (0 = "NONE";
+ * cp_lens: HOST array of n_sym CP lengths (up to 112: several consecutive slots of a subframe in one call, grid.py:546-549).  window_len: raised-cosine overlap length (0 = "NONE";
  * "STD" = min over symbols of (cp+1)/2, waveform.py:99-122). */
 int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens,
                               int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream);
 int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens,
                               int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream);
-/* waveform.py:317-341 sync + :473-527 ofdmDemodulate (f0=0, cpOffsetRatio=0.5): waveform rows (n_items*n_ant rows
+/* waveform.py:317-341 sync + :473-527 ofdmDemodulate (f0=0: the down-conversion phase of f0 > 0 is one factor per symbol,
+ * applied by the caller; cp_offset_ratio = cpOffsetRatio, where in the CP the FFT window starts, 0.5 by default): waveform rows (n_items*n_ant rows
  * of wave_stride samples, wave_len valid) -> grid (n_items,n_ant,n_sym,K).  t_off (nullable, device): timing
  * offset of item b at t_off[b*t_off_stride]. */
 /* nrx_awgn_* followed by nrx_ofdm_demodulate_* in one pass (throughput mode: the noisy waveform is never written):
@@ -323,10 +324,10 @@ int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int3
                                        void* stream);
 int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
                                 int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
-                                const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream);
+                                const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream);
 int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
                                 int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
-                                const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream);
+                                const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream);
 
 /* ------------------------------------------------------------------------------------- tapped-delay-line channel
  * cdl.py:641-645,741-811,672-738,871-887 getPathGains, time-varying part: gains (n_items,n_t,n_rx,n_tx,P) with

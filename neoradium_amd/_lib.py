@@ -64,7 +64,7 @@ for _t in ('f32', 'f64'):
         'nrx_awgn_' + _t: (i32, [vp, vp, i32, i64, vp, i32, u64_, u64_, i64, vp, vp]),
         'nrx_ofdm_modulate_' + _t: (i32, [vp, i32, i32, i32, _i32p, i32, i32, vp, i64, vp]),
         'nrx_ofdm_modulate_precoded_' + _t: (i32, [vp, i32, i32, i32, vp, i64, i32, i32, _i32p, i32, i32, vp, i64, vp, vp]),
-        'nrx_ofdm_demodulate_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, vp, vp]),
+        'nrx_ofdm_demodulate_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, f64, vp, vp]),
         'nrx_ofdm_demodulate_awgn_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, vp, i32, u64_, u64_,
                                                  i64, vp, vp, vp]),
         'nrx_chest_ls_' + _t: (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),

@@ -10,10 +10,12 @@
 namespace {
 using nrx::cx;
 
+// up to 8 consecutive slots of one subframe per call (Grid.ofdmModulate takes several slots, grid.py:546-549)
+constexpr int NRX_MAX_SYMS = 112;
 struct SymGeom {
   int32_t n_sym;
-  int32_t cp[16];     // CP length of each symbol of the slot (samples)
-  int32_t start[16];  // first sample of each symbol (CP included) inside the slot
+  int32_t cp[NRX_MAX_SYMS];     // CP length of each symbol of the slot(s) (samples)
+  int32_t start[NRX_MAX_SYMS];  // first sample of each symbol (CP included) inside the slot(s)
 };
 
 // One workgroup per (batch item, antenna port): the 14 symbols are produced in order because the windowed tail
@@ -103,7 +105,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
                   const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
                   cx<T>* __restrict__ grid, int n_tasks, const cx<double>* __restrict__ tw,
                   const T* __restrict__ sigma, int sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset,
-                  const int64_t* __restrict__ item_ids) {
+                  const int64_t* __restrict__ item_ids, double cp_offset_ratio) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
@@ -113,7 +115,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
     const int64_t ts = t_off ? (int64_t)t_off[(size_t)item * t_off_stride] : 0;  // Waveform.sync (waveform.py:317-341)
     const cx<T>* src = wave + (size_t)row * wave_stride;
     const int cp = g.cp[l];
-    const int off = (int)rint((double)cp * 0.5);  // np.round(cpLens * cpOffsetRatio), waveform.py:507
+    const int off = (int)rint((double)cp * cp_offset_ratio);  // np.round(cpLens * cpOffsetRatio), waveform.py:507
     __syncthreads();
 #pragma unroll 4
     for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
@@ -234,7 +236,7 @@ int ilog2(int n) {
 }
 
 int32_t fill_geom(const int32_t* cp_lens, int32_t n_sym, int32_t nfft, SymGeom* g, int* slot_len) {
-  NRX_REQUIRE(cp_lens && n_sym >= 1 && n_sym <= 16, NRX_E_ARG, "nrx_ofdm: need 1..16 CP lengths");
+  NRX_REQUIRE(cp_lens && n_sym >= 1 && n_sym <= NRX_MAX_SYMS, NRX_E_ARG, "nrx_ofdm: need 1..%d CP lengths", NRX_MAX_SYMS);
   NRX_REQUIRE(nfft >= 64 && nfft <= 8192 && (nfft & (nfft - 1)) == 0, NRX_E_ARG, "nrx_ofdm: nfft must be a power of two in [64, 8192]");
   g->n_sym = n_sym;
   int s = 0;
@@ -299,7 +301,9 @@ template <typename T>
 int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride,
                     int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
                     void* grid, void* stream, const void* sigma = nullptr, int32_t sigma_stride = 0, uint64_t seed = 0,
-                    uint64_t stream_id = 0, int64_t batch_offset = 0, const int64_t* item_ids = nullptr) {
+                    uint64_t stream_id = 0, int64_t batch_offset = 0, const int64_t* item_ids = nullptr,
+                    double cp_offset_ratio = 0.5) {
+  NRX_REQUIRE(cp_offset_ratio >= 0.0 && cp_offset_ratio <= 1.0, NRX_E_ARG, "nrx_ofdm_demodulate: cpOffsetRatio must be in [0, 1]");
   NRX_REQUIRE(!sigma || wave_stride == wave_len, NRX_E_SHAPE,
               "nrx_ofdm_demodulate_awgn: rows must be contiguous (element numbering of nrx_awgn)");
   NRX_REQUIRE(wave && grid, NRX_E_ARG, "nrx_ofdm_demodulate: NULL buffer");
@@ -320,7 +324,7 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
   const int grid_dim = n_tasks < 4096 ? n_tasks : 4096;
   hipLaunchKernelGGL(kern, dim3(grid_dim), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)wave, wave_stride, wave_len,
                      t_off, t_off_stride, n_ant, K, nfft, ilog2(nfft), g, (cx<T>*)grid, n_tasks, tw, (const T*)sigma,
-                     sigma_stride, seed, stream_id, batch_offset, item_ids);
+                     sigma_stride, seed, stream_id, batch_offset, item_ids, cp_offset_ratio);
   NRX_CHECK_LAUNCH("nrx_ofdm_demodulate");
   return NRX_OK;
 }
@@ -333,5 +337,5 @@ extern "C" int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32
 extern "C" int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
 extern "C" int32_t nrx_ofdm_modulate_precoded_f32(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); NRX_REQUIRE(tails_ws || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_precoded: windowing needs the tails workspace"); return mod_entry<float>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports, tails_ws); }
 extern "C" int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); NRX_REQUIRE(tails_ws || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_precoded: windowing needs the tails workspace"); return mod_entry<double>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports, tails_ws); }
-extern "C" int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }
-extern "C" int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, void* grid, void* stream) { return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream); }
+extern "C" int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream) { return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, nullptr, 0, 0, 0, 0, nullptr, cp_offset_ratio); }
+extern "C" int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream) { return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, nullptr, 0, 0, 0, 0, nullptr, cp_offset_ratio); }

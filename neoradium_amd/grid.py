@@ -265,8 +265,6 @@ class Grid:
     def ofdmModulate(self, f0=0, windowing="STD"):
         """grid.py:521-582 + waveform.py:380-470."""
         from .waveform import Waveform
-        if f0 != 0:
-            raise NotImplementedError("ofdmModulate: carrier up-conversion (f0>0) is not built")
         pp, ll, kk = self.shape
         bwp = self.bwp
         if ll % bwp.symbolsPerSlot:
@@ -276,9 +274,18 @@ class Grid:
             raise ValueError("Cannot modulate across subframe boundary! (At most %d symbols)" % (bwp.symbolsPerSubFrame - l0))
         cps = (bwp.symbolLens[l0:l0 + ll] - bwp.nFFT).astype(np.int32)
         w = Waveform.windowLength(cps, windowing, bwp)
-        if ll > 16:
-            raise NotImplementedError("ofdmModulate: more than one slot per call is not built")
-        wave = ops.ofdm_modulate(D(self.grid[None]), bwp.nFFT, list(cps), window_len=w)
+        if ll > 112:
+            raise NotImplementedError("ofdmModulate: more than 8 slots per call is not built")
+        grid = self.grid
+        if f0 > 0:
+            # up-conversion, TS 38.211 5.4 (grid.py:568-572): one phase factor per symbol, exp(j 2 pi f0 (-t_start - t_cp)),
+            # applied to the symbol's subcarriers before the IFFT (a scalar per symbol commutes with it)
+            symLens = bwp.symbolLens[l0:l0 + ll]
+            n0 = bwp.symbolLens[:l0].sum()
+            starts = np.cumsum(np.append(n0, symLens[:-1]))
+            phase = np.exp(2j * np.pi * f0 * (-starts - cps) / bwp.sampleRate)
+            grid = grid * phase[None, :, None]
+        wave = ops.ofdm_modulate(D(grid[None]), bwp.nFFT, list(cps), window_len=w)
         return Waveform(N(wave)[0])
 
     def getRePower(self):

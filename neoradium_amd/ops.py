@@ -513,7 +513,7 @@ def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0, f=None):
     return wave
 
 
-def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None):
+def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None, cp_offset_ratio=0.5):
     """Waveform.sync(t_off).ofdmDemodulate: (n,Nr,S_in) -> (n,Nr,L,K).
 
     ``awgn`` = (sigma, seed, stream_id, batch_offset[, item_ids]): add the noise of :func:`awgn` while loading (same values)."""
@@ -529,6 +529,8 @@ def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None):
             raise ValueError("one timing offset per batch item expected")
     grid = torch.empty((n, nr, L, K), dtype=wave.dtype, device=dev)
     if awgn is not None:
+        if cp_offset_ratio != 0.5:
+            raise ValueError("the fused AWGN + demodulation entry uses cpOffsetRatio = 0.5")
         sigma, seed, stream_id, batch_offset = awgn[:4]
         ids = _item_ids(awgn[4] if len(awgn) > 4 else None, n, dev)
         _, rt = _ct(wave)
@@ -540,7 +542,7 @@ def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None):
         return grid
     fn = getattr(lib(), 'nrx_ofdm_demodulate_' + sfx)
     check(fn(ptr(wave), S_in, S_in, ptr(to), 0 if to is None or to.numel() == 1 else 1, n, nr, K, nfft,
-             _host_i32(cp_lens), L, ptr(grid), stream()))
+             _host_i32(cp_lens), L, float(cp_offset_ratio), ptr(grid), stream()))
     return grid
 
 

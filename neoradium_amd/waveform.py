@@ -124,17 +124,22 @@ class Waveform:
 
     # ------------------------------------------------------------------------------------------ demodulate
     def ofdmDemodulate(self, bwp, f0=0, cpOffsetRatio=0.5):
-        """waveform.py:473-527: one slot, FFT window half-way into each CP."""
+        """waveform.py:473-527: one slot; the FFT window starts cpOffsetRatio of the way into each CP; f0 > 0 undoes the
+        up-conversion phase of Grid.ofdmModulate(f0) (one factor per symbol)."""
         from .grid import Grid
-        if f0 != 0 or cpOffsetRatio != 0.5:
-            raise NotImplementedError("ofdmDemodulate: only f0=0, cpOffsetRatio=0.5 is built")
+        if not 0.0 <= cpOffsetRatio <= 1.0:
+            raise ValueError("'cpOffsetRatio' must be between 0 and 1")
         cps = bwp.getCpLens()
         kk = 12 * bwp.numRbs
         if self.shape[1] < int(cps.sum()) + len(cps) * bwp.nFFT:
             raise ValueError("The waveform is shorter than one slot")
-        g = ops.ofdm_demodulate(D(np.complex128(self.waveform)[None]), bwp.nFFT, list(cps), kk)
+        g = ops.ofdm_demodulate(D(np.complex128(self.waveform)[None]), bwp.nFFT, list(cps), kk, cp_offset_ratio=cpOffsetRatio)
         grid = Grid(bwp, numPlanes=self.shape[0])
         grid.grid = N(g)[0]
+        if f0 > 0:                                          # waveform.py:525-526
+            symLens = bwp.getSymLens()[:-1]
+            symStarts = np.cumsum(np.append(0, symLens[:-1])) + np.asarray(cps)
+            grid.grid = grid.grid * np.exp(2j * np.pi * f0 * symStarts / bwp.sampleRate).reshape(1, -1, 1)
         grid.reTypeIds = np.full(grid.shape, grid.retNameToId["RX_DATA"], dtype=np.uint8)
         grid.noiseVar = self.noiseVar * bwp.nFFT        # time -> frequency domain (waveform.py:523)
         return grid

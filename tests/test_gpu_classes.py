@@ -693,3 +693,27 @@ def test_engine_with_ptrs(dev):
     assert np.abs(t[0][g.reTypeIds == g.retNameToId['PTRS']] - g.grid[g.reTypeIds == g.retNameToId['PTRS']]).max() < 1e-14
     hi = link.run(0, 4, 40.0, seed=2).cpu().numpy()
     assert hi[0] == 0 and hi[2] == 0 and hi[3] == 4 * link.tbs
+
+
+def test_ofdm_non_default_options_vs_reference(dev):
+    """Grid.ofdmModulate with two slots in one call and with carrier up-conversion (f0 > 0), Waveform.ofdmDemodulate with f0
+    and with the FFT window 30 % / 80 % into the cyclic prefix (grid.py:521-582, waveform.py:473-527) against the reference."""
+    import neoradium_amd as nr
+    g = np.load(os.path.join(GOLD, 'ofdm_options.npz'))
+    car = nr.Carrier(numRbs=24, spacing=30)
+    bwp = car.curBwp
+    rng = np.random.default_rng(99)
+    grid = nr.Grid(bwp, numPlanes=2, numSlots=2)
+    grid.grid = rng.standard_normal(grid.shape) + 1j * rng.standard_normal(grid.shape)
+    for name, f0 in (('base', 0), ('up', 3.5e9)):
+        w = grid.ofdmModulate(f0=f0)
+        assert list(w.waveform.shape) == g[f'w2_{name}_shape'].tolist()
+        scale = np.abs(g[f'w2_{name}']).max()
+        assert np.abs(w.waveform[:, ::9] - g[f'w2_{name}']).max() <= 1e-12 * scale
+        assert np.abs(w.waveform[:, :600] - g[f'w2_{name}_head']).max() <= 1e-12 * scale
+        for ratio in (0.3, 0.8):
+            rx = w.ofdmDemodulate(bwp, f0=f0, cpOffsetRatio=ratio)
+            ref = g[f'rx_{name}_{int(ratio * 10)}']
+            assert np.abs(rx.grid - ref).max() <= 1e-11 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        w.ofdmDemodulate(bwp, cpOffsetRatio=1.5)

@@ -257,6 +257,27 @@ def ptrs():
     np.savez_compressed(os.path.join(GOLD, 'ptrs.npz'), **out)
 
 
+def ofdm_options():
+    """The non-default kwargs of Grid.ofdmModulate / Waveform.ofdmDemodulate: two slots in one call, carrier up-conversion
+    (f0 > 0), an FFT window that starts 30 % / 80 % into the CP.  Input grid from the seed; outputs stored."""
+    out = {}
+    car = nr.Carrier(numRbs=24, spacing=30)
+    bwp = car.curBwp
+    rng = np.random.default_rng(99)
+    g = nr.Grid(bwp, numPlanes=2, numSlots=2)
+    vals = rng.standard_normal(g.shape) + 1j * rng.standard_normal(g.shape)
+    g.grid = vals
+    for name, f0 in (('base', 0), ('up', 3.5e9)):
+        w = g.ofdmModulate(f0=f0)
+        out[f'w2_{name}'] = w.waveform[:, ::9]                     # every ninth sample of the two-slot waveform
+        out[f'w2_{name}_shape'] = np.int64(w.waveform.shape)
+        out[f'w2_{name}_head'] = w.waveform[:, :600]
+        for ratio in (0.3, 0.8):
+            rx = w.ofdmDemodulate(bwp, f0=f0, cpOffsetRatio=ratio)  # first slot
+            out[f'rx_{name}_{int(ratio * 10)}'] = rx.grid
+    np.savez_compressed(os.path.join(GOLD, 'ofdm_options.npz'), **out)
+
+
 def channels_xiao():
     """TDL with the statistical sum-of-sinusoids model (sosType='Xiao'): new random angles / phases are drawn for every slot,
     so the fixture follows the generator: construction (first slot prepared), two goNext, the slot prepared again."""
@@ -584,6 +605,7 @@ if __name__ == '__main__':
     phy()
     host()
     ptrs()
+    ofdm_options()
     channels()
     channels_xiao()
     snr_walks()
