@@ -50,6 +50,8 @@ def main():
     ap.add_argument('--slots', type=int, default=24)
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r1_bler_overlay.json'))
     ap.add_argument('--configs', default='cfg1,cdl_2x2_16qam', help="comma list of cfg1, cdl_2x2_16qam, metric")
+    ap.add_argument('--procs', type=int, default=1, help="CPU oracle: one single-threaded process per core (oracle.link.run_slots_parallel)")
+    ap.add_argument('--snrs', default='', help="comma list overriding the configuration's SNR points")
     a = ap.parse_args()
     import neoradium_amd as nr
     from neoradium_amd._dev import D
@@ -58,7 +60,9 @@ def main():
     for which in a.configs.split(','):
         link, snrs = build(nr, which, 'f32')
         link64, _ = build(nr, which, 'f64')
-        st = olink.static_from_link(link)
+        if a.snrs:
+            snrs = [float(v) for v in a.snrs.split(',')]
+        st = olink.static_from_link(link, slots=range(0, 20 * len(snrs) + a.slots))
         rows = []
         t_cpu = 0.0
         for si, snr in enumerate(snrs):
@@ -73,18 +77,23 @@ def main():
             gpu_ok = d['cb_ok'].cpu().numpy().astype(bool)
             _, det64 = link64.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details=True)
             gpu64_ok = det64[0][1]['cb_ok'].cpu().numpy().astype(bool)
+            # the float64 THROUGHPUT path (fused rate recovery + decode + CRC/merge where it applies) on the same slots
+            _, dv = link64.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
+            fused_ok = torch.cat([x['cb_ok'] for _, x in dv]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
             F = d['F'].cpu().numpy()
-            cpu_ok = []
             t0 = time.time()
-            for i in range(n):
-                ref = olink.run_slot(st, slots0 + i, snr, tb[i].astype(np.int8), zc[i], F=F[i])
-                cpu_ok.append(ref['crc'])
+            jobs = [(st, slots0 + i, snr, tb[i].astype(np.int8), zc[i], F[i]) for i in range(n)]
+            if a.procs > 1:
+                cpu_ok = [r['crc'] for r in olink.run_slots_parallel(jobs, a.procs)]
+            else:
+                cpu_ok = [olink.run_slot(*j)['crc'] for j in jobs]
             t_cpu += time.time() - t0
             cpu_ok = np.array(cpu_ok)
             rows.append(dict(snr_db=snr, blocks=int(cpu_ok.size), cpu_block_errors=int((~cpu_ok).sum()),
                              gpu_f32_block_errors=int((~gpu_ok).sum()), gpu_f64_block_errors=int((~gpu64_ok).sum()),
                              f32_crc_vectors_differ_in=int((cpu_ok != gpu_ok).sum()),
-                             f64_crc_vectors_differ_in=int((cpu_ok != gpu64_ok).sum())))
+                             f64_crc_vectors_differ_in=int((cpu_ok != gpu64_ok).sum()),
+                             f64_throughput_path_differs_from_f64_in=int((fused_ok != gpu64_ok).sum())))
             print(which, rows[-1], flush=True)
         res[which] = dict(tbs=link.tbs, code_blocks=link.cfg.C, slots_per_point=a.slots, points=rows,
                           cpu_oracle_s_per_slot=t_cpu / (len(snrs) * a.slots))
