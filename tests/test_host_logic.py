@@ -232,3 +232,59 @@ def test_ptrs_vs_reference():
     q = ma.PDSCH(car.curBwp)
     with pytest.raises(ValueError):
         q.setPTRS()                                                    # no DMRS yet
+
+
+def test_csirs_vs_reference():
+    """CSI-RS (csirs.py): the row of TS 38.211 Table 7.4.1.5.3-1 inferred from the parameters, the populated values and
+    positions of ten configurations (all CDM types, both densities, one- and two-symbol rows, a partial RB range with
+    power and scrambling settings, several slot numbers), the reserved map, and which slots a periodic NZP set and a
+    semi-persistent ZP set occupy -- against the reference."""
+    g = np.load(os.path.join(GOLD, 'csirs.npz'))
+    for i, c in enumerate(json.loads(str(g['cfgs']))):
+        car = ma.Carrier(numRbs=c['rb'], spacing=c['sp'])
+        car.slotNo = c['slot']
+        bwp = car.curBwp
+        cc = ma.CsiRsConfig(csiType='NZP', bwp=bwp, **c['kw'])
+        r = cc.csiRsSetList[0].csiRsList[0]
+        assert [r.row] + list(r.ks) + list(r.ls) == g[f'c{i}_row'].tolist()
+        grid = bwp.createGrid(cc.numPorts)
+        cc.populateGrid(grid)
+        idx = np.nonzero(grid.reTypeIds == grid.retNameToId['CSIRS_NZP'])
+        assert np.array_equal(np.int32(np.stack(idx)), g[f'c{i}_idx']), i
+        assert np.abs(grid.grid[idx] - g[f'c{i}_val']).max() < 1e-14
+        assert int((grid.reTypeIds == 0).sum()) == int(g[f'c{i}_untouched'][0])
+        g2 = bwp.createGrid(3)
+        cc.reserveGridResources(g2)
+        assert np.array_equal(np.int32(np.stack(np.nonzero(g2.reTypeIds == g2.retNameToId['CSIRS_NZP']))), g[f'c{i}_res'])
+        if cc.numPorts <= 3:
+          with pytest.raises(AssertionError):
+            cc.populateGrid(g2)                                # NZP values onto REs that are already CSIRS_NZP
+    assert "Table Row" in repr(cc) and r.period == 5 and r.startRb == 4
+    car = ma.Carrier(numRbs=24, spacing=15)
+    bwp = car.curBwp
+    zp = ma.CsiRsSet("ZP", bwp, csiRsList=[ma.CsiRs(offset=1, symbols=[1], numPorts=1, freqMap="000001000000", density=0.5)],
+                     resourceType='semiPersistent', period=10)
+    nz = ma.CsiRsSet("NZP", bwp, csiRsList=[ma.CsiRs(offset=0, symbols=[1], numPorts=1, freqMap="0010", density=3),
+                                             ma.CsiRs(offset=3, symbols=[3], numPorts=1, freqMap="000000001000", density=1)],
+                     resourceType='periodic', period=5)
+    cc = ma.CsiRsConfig([zp, nz])
+    counts = []
+    for slot in range(10):
+        car.slotNo = slot
+        grid = bwp.createGrid(1)
+        cc.populateGrid(grid)
+        counts.append([int((grid.reTypeIds == grid.retNameToId[t]).sum()) for t in ('CSIRS_ZP', 'CSIRS_NZP')])
+        if slot in (0, 1, 3):
+            assert np.array_equal(grid.reTypeIds, g[f'mix_s{slot}_types'])
+            assert np.abs(grid.grid - g[f'mix_s{slot}_grid']).max() < 1e-14
+    assert counts == g['mix_counts'].tolist()
+    zp.active = False
+    car.slotNo = 1
+    grid = bwp.createGrid(1)
+    cc.populateGrid(grid)
+    assert not (grid.reTypeIds == grid.retNameToId['CSIRS_ZP']).any()
+    for bad in (dict(numPorts=3), dict(numPorts=4, density=0.5), dict(numPorts=8, cdmSize=3), dict(numPorts=2, freqMap='0110')):
+        with pytest.raises((ValueError, KeyError)):
+            ma.CsiRsConfig(csiType='NZP', bwp=bwp, **bad)
+    with pytest.raises(ValueError):
+        ma.CsiRsConfig().populateGrid(grid)

@@ -257,6 +257,119 @@ def ptrs():
     np.savez_compressed(os.path.join(GOLD, 'ptrs.npz'), **out)
 
 
+def csirs():
+    """CSI-RS (csirs.py) on ten configurations that cover the rows of TS 38.211 Table 7.4.1.5.3-1 with every CDM type, both
+    densities, two-symbol rows, ZP + NZP sets with periods/offsets: populated values and RE types, the reserved map;
+    then CSI-RS based channel estimation (grid.py:740-873) through every interpolation kind (every fifth subcarrier
+    of the estimate is stored), and the timing estimate
+    (grid.py:592-622)."""
+    import json
+    out = {}
+    cfgs = [dict(rb=24, sp=15, slot=0, kw=dict(numPorts=1)),
+            dict(rb=24, sp=15, slot=4, kw=dict(numPorts=1, density=3, freqMap='0100', symbols=[6], powerDb=3)),
+            dict(rb=25, sp=30, slot=8, kw=dict(numPorts=2, density=0.5, scramblingID=7, symbols=[3])),
+            dict(rb=24, sp=15, slot=0, kw=dict(numPorts=4, freqMap='010')),
+            dict(rb=24, sp=15, slot=0, kw=dict(numPorts=4, freqMap='000100', symbols=[9])),
+            dict(rb=24, sp=30, slot=12, kw=dict(numPorts=8, cdmSize=4, symbols=[4], scramblingID=100)),
+            dict(rb=26, sp=15, slot=0, kw=dict(numPorts=16, cdmSize=4, density=0.5, symbols=[7])),
+            dict(rb=24, sp=15, slot=0, kw=dict(numPorts=32, cdmSize=8, symbols=[5])),
+            dict(rb=24, sp=15, slot=0, kw=dict(numPorts=24, cdmSize=2, symbols=[2, 8])),
+            dict(rb=52, sp=30, slot=5, kw=dict(numPorts=8, cdmSize=2, freqMap='001111', symbols=[10], startRb=4, numRbs=40,
+                                                period=5, offset=0, powerDb=-3, scramblingID=33))]
+    out['cfgs'] = np.array(json.dumps(cfgs))
+    for i, c in enumerate(cfgs):
+        car = nr.Carrier(numRbs=c['rb'], spacing=c['sp'])
+        car.slotNo = c['slot']
+        bwp = car.curBwp
+        cc = nr.CsiRsConfig(csiType='NZP', bwp=bwp, **c['kw'])
+        r = cc.csiRsSetList[0].csiRsList[0]
+        out[f'c{i}_row'] = np.int64([r.row] + list(r.ks) + list(r.ls))
+        g = bwp.createGrid(cc.numPorts)
+        cc.populateGrid(g)
+        idx = np.nonzero(g.reTypeIds == g.retNameToId['CSIRS_NZP'])
+        out[f'c{i}_idx'] = np.int32(np.stack(idx))
+        out[f'c{i}_val'] = g.grid[idx]
+        out[f'c{i}_untouched'] = np.int64([(g.reTypeIds == g.retNameToId['UNASSIGNED']).sum()])
+        g2 = bwp.createGrid(3)
+        cc.reserveGridResources(g2)
+        out[f'c{i}_res'] = np.int32(np.stack(np.nonzero(g2.reTypeIds == g2.retNameToId['CSIRS_NZP'])))
+    # a ZP set and an NZP set with different slot behaviour: which slots of 0..9 carry which
+    car = nr.Carrier(numRbs=24, spacing=15)
+    bwp = car.curBwp
+    zp = nr.CsiRsSet("ZP", bwp, csiRsList=[nr.CsiRs(offset=1, symbols=[1], numPorts=1, freqMap="000001000000", density=0.5)],
+                     resourceType='semiPersistent', period=10)
+    nz = nr.CsiRsSet("NZP", bwp, csiRsList=[nr.CsiRs(offset=0, symbols=[1], numPorts=1, freqMap="0010", density=3),
+                                             nr.CsiRs(offset=3, symbols=[3], numPorts=1, freqMap="000000001000", density=1)],
+                     resourceType='periodic', period=5)
+    cc = nr.CsiRsConfig([zp, nz])
+    counts = []
+    for slot in range(10):
+        car.slotNo = slot
+        g = bwp.createGrid(1)
+        cc.populateGrid(g)
+        counts.append([(g.reTypeIds == g.retNameToId[t]).sum() for t in ('CSIRS_ZP', 'CSIRS_NZP')])
+        if slot in (0, 1, 3):
+            out[f'mix_s{slot}_types'] = g.reTypeIds
+            out[f'mix_s{slot}_grid'] = g.grid
+    out['mix_counts'] = np.int64(counts)
+
+    # estimation: a smooth channel (a few delayed taps, slow time variation) applied to the CSI-RS grid, noise from the seed
+    rng = np.random.default_rng(2024)
+    est = [dict(rb=24, sp=15, nr=2, kw=dict(numPorts=4, freqMap='000100', symbols=[9])),          # ports on two symbols
+           dict(rb=25, sp=30, nr=3, kw=dict(numPorts=2, density=0.5, symbols=[3])),
+           dict(rb=24, sp=15, nr=2, kw=dict(numPorts=8, cdmSize=4, symbols=[4])),
+           dict(rb=24, sp=15, nr=1, kw=dict(numPorts=24, cdmSize=2, symbols=[2, 8])),               # four pilot symbols
+           dict(rb=24, sp=15, nr=1, kw=dict(numPorts=1, density=3, freqMap='0100', symbols=[6]))]
+    out['est_cfgs'] = np.array(json.dumps(est))
+    for i, c in enumerate(est):
+        car = nr.Carrier(numRbs=c['rb'], spacing=c['sp'])
+        bwp = car.curBwp
+        cc = nr.CsiRsConfig(csiType='NZP', bwp=bwp, **c['kw'])
+        nt = cc.numPorts
+        tx = bwp.createGrid(nt)
+        cc.populateGrid(tx)
+        L, K = tx.shape[1:]
+        taps = (rng.standard_normal((4, c['nr'], nt)) + 1j * rng.standard_normal((4, c['nr'], nt))) * np.float64([1, .6, .3, .15])[:, None, None]
+        dl = np.float64([0, 1.3, 2.9, 5.2])
+        dop = rng.uniform(-.02, .02, (4,))
+        k = np.arange(K)[None, :, None]
+        l = np.arange(L)[:, None, None]
+        h = (taps[None, None] * np.exp(-2j * np.pi * (k * dl / 256 - l * dop))[..., None, None]).sum(2)       # (L,K,nr,nt)
+        rx = tx.applyChannel(h)
+        noise = (rng.standard_normal(rx.shape) + 1j * rng.standard_normal(rx.shape)) * 0.02
+        rx.grid = rx.grid + noise
+        out[f'e{i}_rx'] = rx.grid
+        he, nv = rx.estimateChannelLS(cc)
+        out[f'e{i}_lin'], out[f'e{i}_lin_nv'] = he[:, ::5], np.float64([nv])
+        he, nv = rx.estimateChannelLS(cc, polarInt=True)
+        out[f'e{i}_pol'], out[f'e{i}_pol_nv'] = he[:, ::5], np.float64([nv])
+        if i in (0, 1, 3):
+            for kern in ('nearest', 'quadratic', 'thin_plate_spline', 'multiquadric'):
+                he, nv = rx.estimateChannelLS(cc, kernel=kern)
+                out[f'e{i}_{kern}'], out[f'e{i}_{kern}_nv'] = he[:, ::5], np.float64([nv])
+            he, nv = rx.estimateChannelLS(cc, meanCdm=False)
+            out[f'e{i}_nomean'], out[f'e{i}_nomean_nv'] = he[:, ::5], np.float64([nv])
+        if i == 3:
+            he, nv, hps = rx.estimateChannelLsEx(cc)                       # the Ex defaults: polar + 2-D thin-plate spline
+            out[f'e{i}_ex'], out[f'e{i}_ex_nv'] = he[:, ::5], np.float64([nv])
+            he, nv, hps = rx.estimateChannelLsEx(cc, polarInt=False, int2d=True, kernel='thin_plate_spline', neighbors=9, smoothing=0.1)
+            out[f'e{i}_ex2'], out[f'e{i}_ex2_nv'] = he[:, ::5], np.float64([nv])
+    # timing estimate: the CSI-RS grid's waveform against a delayed, noisy copy through a 2x1 mix
+    car = nr.Carrier(numRbs=24, spacing=15)
+    bwp = car.curBwp
+    cc = nr.CsiRsConfig(csiType='NZP', bwp=bwp, numPorts=2, symbols=[3])
+    tx = bwp.createGrid(2)
+    cc.populateGrid(tx)
+    w = tx.ofdmModulate(windowing="NONE").waveform
+    for d in (0, 7, 23):
+        mix = np.complex128([[0.8, 0.3j], [-0.2, 0.9]])
+        rxw = np.concatenate([np.zeros((2, d), complex), (mix @ w)[:, :w.shape[1] - d]], 1)
+        rxw = rxw + (rng.standard_normal(rxw.shape) + 1j * rng.standard_normal(rxw.shape)) * 1e-3
+        out[f't{d}_rx'] = rxw[:, ::1].astype(np.complex64)
+        out[f't{d}_off'] = np.int64([tx.estimateTimingOffset(nr.Waveform(rxw.astype(np.complex64).astype(np.complex128)))])
+    np.savez_compressed(os.path.join(GOLD, 'csirs.npz'), **out)
+
+
 def ofdm_options():
     """The non-default kwargs of Grid.ofdmModulate / Waveform.ofdmDemodulate: two slots in one call, carrier up-conversion
     (f0 > 0), an FFT window that starts 30 % / 80 % into the CP.  Input grid from the seed; outputs stored."""
@@ -605,6 +718,7 @@ if __name__ == '__main__':
     phy()
     host()
     ptrs()
+    csirs()
     ofdm_options()
     channels()
     channels_xiao()
