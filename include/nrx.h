@@ -401,11 +401,40 @@ int32_t nrx_chest_ls_ex_f64(const void* rx, const void* pilots, const int32_t* p
  * values are written to deltas (n_batch, P*n_ds*n_k*nr) complex128; their np.var is the raw noise variance
  * (nrx_noise_level_f64 computes it).  tw: e^{2 pi i q/K}, q = 0..K-1 (complex128, caller table); cir_ws: scratch of
  * n_batch*(n_ds/l_cdm)*nr*P*2*rise complex128.  QUIRK kept (grid.py:823): the denoised estimate of EVERY port is sampled
- * at the pilot subcarriers of the LAST port. */
+ * at the pilot subcarriers of the LAST port -- row P-1 of port_ks, or ks_sample (device, n_k entries) when the call
+ * covers only some of the ports (CSI-RS ports that sit on different symbols are estimated in separate calls). */
 int32_t nrx_chest_noise_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
-                            const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
+                            const int32_t* ks_sample, const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
                             int32_t K, int32_t nr, int32_t P, const void* hk, const void* tw, const double* win,
                             int32_t rise, void* cir_ws, void* deltas, int32_t n_batch, void* stream);
+
+/* The non-default interpolators of estimateChannelLsEx (grid.py:740-871: kernel = 'nearest' | 'quadratic' |
+ * 'thin_plate_spline' | 'multiquadric', int2d) in two steps.
+ *   nrx_chest_pilot_means_f64: the LS estimates rx/pilot averaged over each CDM group (grid.py:775-793) as pairs of
+ *     doubles, out[row][j][2], row = ((b*(n_ds/l_cdm) + tg)*nr + r)*P + p, j < n_k/k_cdm: (re, im), or with polar != 0
+ *     (np.unwrap(angle), abs) as utils.py:39 forms them.
+ *   nrx_interp_taps_f64: out[q] = sum_t w[q][t] * in[idx[q][t]] on both components; polar pairs are recombined as
+ *     abs * e^{i angle} (utils.py:42).  idx/w (n_tabs, n_out, n_taps) hold the linear operator of the reference's
+ *     interpolator for one pilot geometry (utils.py:26-35 interp1d / RBFInterpolator with nearest neighbours in one
+ *     dimension, grid.py:853-861 in two) -- a host table, like the RE indices.  Rows are (outer, in) with in < inner;
+ *     table = in % n_tabs; element j of a row is at in[outer*in_outer + in*in_inner + j*in_j], output q at
+ *     out[outer*out_outer + in*out_inner + q*out_q] (units of complex128), so the same entry serves the subcarrier
+ *     axis, the symbol axis and the 2-D case without a transpose. */
+int32_t nrx_chest_pilot_means_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                  const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                  int32_t L, int32_t K, int32_t nr, int32_t P, int32_t polar, void* out, int32_t n_batch,
+                                  void* stream);
+int32_t nrx_interp_taps_f64(const void* in, const int32_t* idx, const double* w, int32_t n_taps, int32_t n_tabs,
+                            int64_t tab_stride, int64_t n_outer, int32_t inner, int32_t n_out, int64_t in_outer,
+                            int64_t in_inner, int64_t in_j, int64_t out_outer, int64_t out_inner, int64_t out_q,
+                            int32_t polar, void* out, void* stream);
+
+/* Grid.estimateTimingOffset (grid.py:592-622): xc[d] = sum over rx antennas and ports of |sum_n rx[r][n+d] conj(ref[p][n])|
+ * for every lag d = 0..n_samples-1 (the second half of scipy.signal.correlate(..., 'full')); the caller takes the argmax.
+ * rx (nr, n_samples), ref (P, n_ref) complex128; ref is zero outside [ref_start, ref_start+ref_len) (the CSI-RS symbols),
+ * which is all the kernel reads. */
+int32_t nrx_xcorr_abs_f64(const void* rx, const void* ref, int32_t n_samples, int32_t n_ref, int32_t ref_start,
+                          int32_t ref_len, int32_t nr, int32_t P, double* xc, void* stream);
 
 /* ------------------------------------------------------------------------------------- per-PRG precoding
  * pdsch.py:1132-1165 (getPrecodingMatrix with prgSize 2/4, or the wideband precoder of a partial allocation: a list of

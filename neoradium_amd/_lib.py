@@ -84,7 +84,10 @@ SIGNATURES.update({
     'nrx_effective_channel_f64': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_chest_ls_mmse_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp]),
     'nrx_chest_ls_ex_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
-    'nrx_chest_noise_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]),
+    'nrx_chest_noise_f64': (i32, [vp, vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]),
+    'nrx_chest_pilot_means_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    'nrx_interp_taps_f64': (i32, [vp, vp, vp, i32, i32, i64, i64, i32, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
+    'nrx_xcorr_abs_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_group_mean_f64': (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
     'nrx_precode_prg_f32': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),
     'nrx_precode_prg_f64': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),

@@ -118,7 +118,9 @@ chest_ls_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ pilots, 
 
 
 // ---- polar interpolation, step 1 (utils.py:39): angle and magnitude of every CDM-group estimate.
-// pol[row][j] = (atan2(im, re), hypot(re, im)), row = ((b*n_g + tg)*nr + r)*P + p.
+// pol[row][j] = (atan2(im, re), hypot(re, im)), row = ((b*n_g + tg)*nr + r)*P + p.  POLAR = false leaves (re, im) in the
+// same layout: the CDM-group means themselves, input of the tap-table interpolators (nrx_interp_taps_f64).
+template <bool POLAR>
 __global__ void __launch_bounds__(256)
 chest_polar_prep_kernel(const cd* __restrict__ rx, const cd* __restrict__ pilots, const int32_t* __restrict__ pil_set,
                         const int32_t* __restrict__ port_ks, ChestGeom g, double* __restrict__ pol, int n_batch) {
@@ -139,8 +141,8 @@ chest_polar_prep_kernel(const cd* __restrict__ rx, const cd* __restrict__ pilots
         s = s + nrx::cdiv(rxb[(size_t)g.ds[di] * g.K + ks[j * g.k_cdm + q]], pil[(size_t)di * g.n_k + j * g.k_cdm + q]);
     }
     s = cd(s.re / (double)cdm, s.im / (double)cdm);
-    pol[2 * gi] = atan2(s.im, s.re);
-    pol[2 * gi + 1] = hypot(s.re, s.im);
+    pol[2 * gi] = POLAR ? atan2(s.im, s.re) : s.re;
+    pol[2 * gi + 1] = POLAR ? hypot(s.re, s.im) : s.im;
   }
 }
 
@@ -195,12 +197,12 @@ chest_cir_kernel(const cd* __restrict__ hk, const cd* __restrict__ tw, const dou
 //     deltas[b][((p*n_ds + di)*n_k + q)*nr + r]
 __global__ void __launch_bounds__(256)
 chest_delta_kernel(const cd* __restrict__ rx, const cd* __restrict__ pilots, const int32_t* __restrict__ pil_set,
-                   const int32_t* __restrict__ port_ks, ChestGeom g, const cd* __restrict__ cirw,
-                   const cd* __restrict__ tw, int rise, cd* __restrict__ deltas, int n_batch) {
+                   const int32_t* __restrict__ port_ks, const int32_t* __restrict__ ks_sample, ChestGeom g,
+                   const cd* __restrict__ cirw, const cd* __restrict__ tw, int rise, cd* __restrict__ deltas, int n_batch) {
   const int n_g = g.n_ds / g.l_cdm;
   const int64_t per = (int64_t)g.P * g.n_ds * g.n_k * g.nr;
   const int64_t total = (int64_t)n_batch * per;
-  const int32_t* ks_last = port_ks + (size_t)(g.P - 1) * g.n_k;
+  const int32_t* ks_last = ks_sample ? ks_sample : port_ks + (size_t)(g.P - 1) * g.n_k;
   for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(gi / per);
     int64_t e = gi - (int64_t)b * per;
@@ -315,6 +317,77 @@ mmse_interp_kernel(const cd* __restrict__ rx, const cd* __restrict__ hk, ChestGe
     }
   }
 }
+// ---- interpolation by tap tables: out[q] = sum_t w[q][t] * in[idx[q][t]] for every row, both components of the pair
+// separately; polar pairs (angle, magnitude) are recombined as magnitude * e^{i angle} (utils.py:42).  The tables are the
+// linear operator of the reference's interpolators (interp1d nearest / quadratic, RBFInterpolator with k nearest
+// neighbours in one or two dimensions, utils.py:26-35, grid.py:853-861) for one set of sample positions; they depend
+// on the pilot geometry only, so the caller builds them once.  One lane per (outer, q, inner) with `inner` fastest:
+// rows are numbered outer*inner + in, table = in % n_tabs (the port is the fastest index of every layout used).
+struct TapGeom {
+  int64_t n_outer;
+  int32_t inner, n_out, n_taps, n_tabs, polar;
+  int64_t tab_stride, in_outer, in_inner, in_j, out_outer, out_inner, out_q;
+};
+
+__global__ void __launch_bounds__(256)
+interp_taps_kernel(const cd* __restrict__ in, const int32_t* __restrict__ idx, const double* __restrict__ w, TapGeom t,
+                   cd* __restrict__ out) {
+  const int64_t per = (int64_t)t.n_out * t.inner;
+  const int64_t total = t.n_outer * per;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = gi / per;
+    const int64_t e = gi - o * per;
+    const int q = (int)(e / t.inner), ii = (int)(e - (int64_t)q * t.inner);
+    const size_t tab = (size_t)(ii % t.n_tabs) * t.tab_stride + (size_t)q * t.n_taps;
+    const cd* src = in + o * t.in_outer + (int64_t)ii * t.in_inner;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < t.n_taps; ++k) {
+      const double wk = w[tab + k];
+      const cd v = src[(int64_t)idx[tab + k] * t.in_j];
+      a += wk * v.re;
+      b += wk * v.im;
+    }
+    cd r(a, b);
+    if (t.polar) {
+      double sn, cs;
+      sincos(a, &sn, &cs);
+      r = cd(b * cs, b * sn);
+    }
+    out[o * t.out_outer + (int64_t)ii * t.out_inner + (int64_t)q * t.out_q] = r;
+  }
+}
+
+// ---- timing estimate (grid.py:592-622): xc[d] = sum over (rx antenna, port) of | sum_n rx[r][n+d] conj(ref[p][n]) |,
+// d = 0..N-1, with the reference waveform zero outside [n0, n0+M) (the CSI-RS symbols).  One workgroup per lag.
+__global__ void __launch_bounds__(256)
+xcorr_abs_kernel(const cd* __restrict__ rx, const cd* __restrict__ ref, int N, int n_ref, int n0, int M, int nr, int P,
+                 double* __restrict__ xc) {
+  __shared__ double red[2][4];
+  const int d = blockIdx.x;
+  double total = 0.0;
+  for (int r = 0; r < nr; ++r)
+    for (int p = 0; p < P; ++p) {
+      const cd* a = rx + (size_t)r * N + d;
+      const cd* b = ref + (size_t)p * n_ref;
+      cd acc(0, 0);
+      for (int n = n0 + threadIdx.x; n < n0 + M && n + d < N; n += blockDim.x) {
+        const cd v = b[n];
+        nrx::cmac(acc, a[n], cd(v.re, -v.im));
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        acc.re += __shfl_down(acc.re, off);
+        acc.im += __shfl_down(acc.im, off);
+      }
+      if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc.re; red[1][threadIdx.x >> 6] = acc.im; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const double re = red[0][0] + red[0][1] + red[0][2] + red[0][3], im = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        total += hypot(re, im);
+      }
+      __syncthreads();
+    }
+  if (threadIdx.x == 0) xc[d] = total;
+}
 }  // namespace
 
 extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
@@ -392,7 +465,7 @@ extern "C" int32_t nrx_chest_ls_ex_f64(const void* rx, const void* pilots, const
   if (polar) {
     const int n_j = n_k / k_cdm;
     const int64_t rows = (int64_t)n_batch * (n_ds / l_cdm) * nr * P;
-    hipLaunchKernelGGL(chest_polar_prep_kernel, dim3(nrx::stream_grid(rows * n_j, 256)), dim3(256), 0, st, (const cd*)rx,
+    hipLaunchKernelGGL(chest_polar_prep_kernel<true>, dim3(nrx::stream_grid(rows * n_j, 256)), dim3(256), 0, st, (const cd*)rx,
                        (const cd*)pilots, pil_set, port_ks, g, (double*)pol_ws, n_batch);
     hipLaunchKernelGGL(chest_unwrap_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, (double*)pol_ws, n_j, rows);
     hipLaunchKernelGGL((chest_ls_kernel<double, true>), grid, dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set,
@@ -406,7 +479,7 @@ extern "C" int32_t nrx_chest_ls_ex_f64(const void* rx, const void* pilots, const
 }
 
 extern "C" int32_t nrx_chest_noise_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
-                                       const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                       const int32_t* ks_sample, const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
                                        int32_t L, int32_t K, int32_t nr, int32_t P, const void* hk, const void* tw,
                                        const double* win, int32_t rise, void* cir_ws, void* deltas, int32_t n_batch,
                                        void* stream) {
@@ -423,8 +496,66 @@ extern "C" int32_t nrx_chest_noise_f64(const void* rx, const void* pilots, const
   hipLaunchKernelGGL(chest_cir_kernel, dim3((unsigned)rows, (unsigned)((2 * rise + 127) / 128)), dim3(128), 0, st,
                      (const cd*)hk, (const cd*)tw, win, rise, K, nr * P, (cd*)cir_ws);
   hipLaunchKernelGGL(chest_delta_kernel, dim3(nrx::stream_grid((long)n_batch * P * n_ds * n_k * nr, 256)), dim3(256), 0, st,
-                     (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (const cd*)cir_ws, (const cd*)tw, rise,
+                     (const cd*)rx, (const cd*)pilots, pil_set, port_ks, ks_sample, g, (const cd*)cir_ws, (const cd*)tw, rise,
                      (cd*)deltas, n_batch);
   NRX_CHECK_LAUNCH("nrx_chest_noise");
+  return NRX_OK;
+}
+
+
+extern "C" int32_t nrx_chest_pilot_means_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                             const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                             int32_t L, int32_t K, int32_t nr, int32_t P, int32_t polar, void* out,
+                                             int32_t n_batch, void* stream) {
+  NRX_REQUIRE(rx && pilots && port_ks && out, NRX_E_ARG, "nrx_chest_pilot_means: NULL buffer");
+  NRX_REQUIRE(n_batch >= 0, NRX_E_ARG, "nrx_chest_pilot_means: negative batch");
+  ChestGeom g;
+  const int32_t rc = chest_fill_geom(g, dmrs_syms, n_ds, l_cdm, k_cdm, n_k, L, K, nr, P, "nrx_chest_pilot_means");
+  if (rc != NRX_OK) return rc;
+  if (n_batch == 0) return NRX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_j = n_k / k_cdm;
+  const int64_t rows = (int64_t)n_batch * (n_ds / l_cdm) * nr * P;
+  if (polar) {
+    hipLaunchKernelGGL(chest_polar_prep_kernel<true>, dim3(nrx::stream_grid(rows * n_j, 256)), dim3(256), 0, st, (const cd*)rx,
+                       (const cd*)pilots, pil_set, port_ks, g, (double*)out, n_batch);
+    hipLaunchKernelGGL(chest_unwrap_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, (double*)out, n_j, rows);
+  } else {
+    hipLaunchKernelGGL(chest_polar_prep_kernel<false>, dim3(nrx::stream_grid(rows * n_j, 256)), dim3(256), 0, st, (const cd*)rx,
+                       (const cd*)pilots, pil_set, port_ks, g, (double*)out, n_batch);
+  }
+  NRX_CHECK_LAUNCH("nrx_chest_pilot_means");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_interp_taps_f64(const void* in, const int32_t* idx, const double* w, int32_t n_taps, int32_t n_tabs,
+                                       int64_t tab_stride, int64_t n_outer, int32_t inner, int32_t n_out, int64_t in_outer,
+                                       int64_t in_inner, int64_t in_j, int64_t out_outer, int64_t out_inner, int64_t out_q,
+                                       int32_t polar, void* out, void* stream) {
+  NRX_REQUIRE(in && idx && w && out, NRX_E_ARG, "nrx_interp_taps: NULL buffer");
+  NRX_REQUIRE(n_taps >= 1 && n_tabs >= 1 && inner >= 1 && n_out >= 1 && n_outer >= 0 && tab_stride >= 0, NRX_E_ARG,
+              "nrx_interp_taps: bad sizes");
+  NRX_REQUIRE(inner % n_tabs == 0, NRX_E_ARG, "nrx_interp_taps: %d tables do not divide the inner extent %d", n_tabs, inner);
+  if (n_outer == 0) return NRX_OK;
+  TapGeom t;
+  t.n_outer = n_outer; t.inner = inner; t.n_out = n_out; t.n_taps = n_taps; t.n_tabs = n_tabs; t.polar = polar;
+  t.tab_stride = tab_stride; t.in_outer = in_outer; t.in_inner = in_inner; t.in_j = in_j;
+  t.out_outer = out_outer; t.out_inner = out_inner; t.out_q = out_q;
+  hipLaunchKernelGGL(interp_taps_kernel, dim3(nrx::stream_grid((long)(n_outer * n_out * inner), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const cd*)in, idx, w, t, (cd*)out);
+  NRX_CHECK_LAUNCH("nrx_interp_taps");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_xcorr_abs_f64(const void* rx, const void* ref, int32_t n_samples, int32_t n_ref, int32_t ref_start,
+                                     int32_t ref_len, int32_t nr, int32_t P, double* xc, void* stream) {
+  NRX_REQUIRE(rx && ref && xc, NRX_E_ARG, "nrx_xcorr_abs: NULL buffer");
+  NRX_REQUIRE(n_samples >= 1 && n_ref >= 1 && nr >= 1 && P >= 1, NRX_E_ARG, "nrx_xcorr_abs: bad sizes");
+  NRX_REQUIRE(ref_start >= 0 && ref_len >= 0 && ref_start + ref_len <= n_ref && n_ref <= n_samples, NRX_E_ARG,
+              "nrx_xcorr_abs: reference support [%d, %d) outside its %d samples (or longer than the received %d)", ref_start,
+              ref_start + ref_len, n_ref, n_samples);
+  hipLaunchKernelGGL(xcorr_abs_kernel, dim3((unsigned)n_samples), dim3(256), 0, (hipStream_t)stream, (const cd*)rx,
+                     (const cd*)ref, n_samples, n_ref, ref_start, ref_len, nr, P, xc);
+  NRX_CHECK_LAUNCH("nrx_xcorr_abs");
   return NRX_OK;
 }

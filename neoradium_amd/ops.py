@@ -668,9 +668,10 @@ def chest_ls_ex(rx, pilots, port_ks, dmrs_syms, l_cdm=1, k_cdm=2, pil_set=None, 
 _noise_tabs = {}
 
 
-def chest_noise_var(rx, pilots, port_ks, dmrs_syms, hk, nfft, cp_min, l_cdm=1, k_cdm=2, pil_set=None):
-    """Raw noise variance of estimateChannelLsEx (grid.py:808-837): np.var of the pilot residuals against the
-    delay-domain-windowed estimate, per batch item (float64 tensor (n,)) + the number of residuals."""
+def chest_noise_deltas(rx, pilots, port_ks, dmrs_syms, hk, nfft, cp_min, l_cdm=1, k_cdm=2, pil_set=None, ks_sample=None):
+    """The pilot residuals of grid.py:808-835 against the delay-domain-windowed estimate: (n, P*nDs*nK*Nr) complex128.
+    ``ks_sample``: the subcarriers every port's denoised estimate is sampled at (default: the last port's, as the
+    reference does)."""
     rx, pilots, pk, ps, (n, nr, L, K, P, nds, nk) = _chest_tables(rx, pilots, port_ks, dmrs_syms, pil_set)
     dev = _dev(rx)
     rise = int(cp_min) * K // int(nfft)
@@ -688,10 +689,67 @@ def chest_noise_var(rx, pilots, port_ks, dmrs_syms, hk, nfft, cp_min, l_cdm=1, k
         raise ValueError("hk must be (n, nTg, K, Nr, P)")
     cir = torch.empty((n, n_g * nr * P * 2 * rise), dtype=torch.complex128, device=dev)
     deltas = torch.empty((n, P * nds * nk * nr), dtype=torch.complex128, device=dev)
-    check(lib().nrx_chest_noise_f64(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), _host_i32(dmrs_syms), nds, l_cdm, k_cdm, nk, L, K,
-                                    nr, P, ptr(hk), ptr(tw), ptr(win), rise, ptr(cir), ptr(deltas), n, stream()))
+    kss = _i32(ks_sample, dev)
+    if kss is not None and (kss.numel() != nk or int(kss.max()) >= K or int(kss.min()) < 0):
+        raise ValueError("ks_sample must hold n_k subcarrier indices")
+    check(lib().nrx_chest_noise_f64(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), ptr(kss), _host_i32(dmrs_syms), nds, l_cdm, k_cdm,
+                                    nk, L, K, nr, P, ptr(hk), ptr(tw), ptr(win), rise, ptr(cir), ptr(deltas), n, stream()))
+    return deltas
+
+
+def chest_noise_var(rx, pilots, port_ks, dmrs_syms, hk, nfft, cp_min, l_cdm=1, k_cdm=2, pil_set=None):
+    """Raw noise variance of estimateChannelLsEx (grid.py:808-837): np.var of the pilot residuals against the
+    delay-domain-windowed estimate, per batch item (float64 tensor (n,)) + the number of residuals."""
+    deltas = chest_noise_deltas(rx, pilots, port_ks, dmrs_syms, hk, nfft, cp_min, l_cdm, k_cdm, pil_set)
     var, _, _ = noise_level(deltas)
     return var, deltas.shape[1]
+
+
+def chest_pilot_means(rx, pilots, port_ks, dmrs_syms, l_cdm=1, k_cdm=2, pil_set=None, polar=False):
+    """LS estimates at the pilots averaged over each CDM group (grid.py:775-793): (n, nTg, Nr, P, nJ) complex128 whose
+    (re, im) are the estimate -- or, polar, (np.unwrap(angle) along the subcarriers, abs) as utils.py:39."""
+    rx, pilots, pk, ps, (n, nr, L, K, P, nds, nk) = _chest_tables(rx, pilots, port_ks, dmrs_syms, pil_set)
+    out = torch.empty((n, nds // l_cdm, nr, P, nk // k_cdm), dtype=torch.complex128, device=_dev(rx))
+    check(lib().nrx_chest_pilot_means_f64(ptr(rx), ptr(pilots), ptr(ps), ptr(pk), _host_i32(dmrs_syms), nds, l_cdm, k_cdm, nk,
+                                          L, K, nr, P, 1 if polar else 0, ptr(out), n, stream()))
+    return out
+
+
+def interp_taps(x, idx, w, n_outer, inner, n_in, n_out, in_strides, out_strides, out, polar=False):
+    """out[q] = sum_t w[q][t] x[idx[q][t]] per row (both components; polar pairs recombined) -- the tap-table interpolator
+    behind the non-default kinds of estimateChannelLsEx.  idx/w: (n_tabs, n_out, T); strides in complex128 elements as
+    (outer, inner, sample).  The index range is checked here on the host (the tables are host-built)."""
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    if idx.shape != w.shape or idx.ndim != 3 or idx.shape[1] != n_out:
+        raise ValueError("tap tables must be (n_tabs, n_out, T)")
+    if idx.size and (idx.min() < 0 or idx.max() >= n_in):
+        raise ValueError("tap index out of range")
+    dev = _dev(x)
+    reach_in = (n_outer - 1) * in_strides[0] + (inner - 1) * in_strides[1] + (n_in - 1) * in_strides[2]
+    reach_out = (n_outer - 1) * out_strides[0] + (inner - 1) * out_strides[1] + (n_out - 1) * out_strides[2]
+    if x.dtype != torch.complex128 or out.dtype != torch.complex128 or not x.is_contiguous() or not out.is_contiguous():
+        raise ValueError("interp_taps works on contiguous complex128 tensors")
+    if n_outer and (reach_in >= x.numel() or reach_out >= out.numel()):
+        raise ValueError("interp_taps: strides reach outside the tensors")
+    n_tabs, _, T = idx.shape
+    di, dw = torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev)
+    check(lib().nrx_interp_taps_f64(ptr(x), ptr(di), ptr(dw), T, n_tabs, n_out * T, n_outer, inner, n_out, in_strides[0],
+                                    in_strides[1], in_strides[2], out_strides[0], out_strides[1], out_strides[2],
+                                    1 if polar else 0, ptr(out), stream()))
+    return out
+
+
+def xcorr_abs(rx, ref, ref_start, ref_len):
+    """Grid.estimateTimingOffset's correlation magnitude per lag (grid.py:612-622): rx (Nr, N), ref (P, M <= N) -> (N,) f64."""
+    rx, ref = rx.contiguous(), ref.contiguous()
+    if rx.dtype != torch.complex128 or ref.dtype != torch.complex128:
+        raise ValueError("xcorr_abs works on complex128")
+    dev = _dev(rx)
+    out = torch.empty((rx.shape[1],), dtype=torch.float64, device=dev)
+    check(lib().nrx_xcorr_abs_f64(ptr(rx), ptr(ref), rx.shape[1], ref.shape[1], int(ref_start), int(ref_len), rx.shape[0],
+                                  ref.shape[0], ptr(out), stream()))
+    return out
 
 
 def chest_ls_mmse(rx, pilots, port_ks, dmrs_syms, noise_var, l_cdm=1, k_cdm=2, pil_set=None):

@@ -288,5 +288,5 @@ def test_chest_polar_and_noise_vs_reference(dev, name):
         assert rel(h[b], ref) < 1e-10
         _, raw_ref = op.estimate_noise_var(at_p, at_s, ks, l_cdm, k_cdm, rx.shape[2], nfft, cp_min, spacing)
         assert abs(raw[b] - raw_ref) <= 1e-8 * raw_ref and num == sum(a.size for a in at_p)
-    with pytest.raises(NotImplementedError):
-        grid.estimateChannelLS(p.dmrs, kernel='thin_plate_spline')
+    with pytest.raises(ValueError):
+        grid.estimateChannelLS(p.dmrs, kernel='cubic')          # not one of the reference's kinds (tests/test_gpu_csirs.py)

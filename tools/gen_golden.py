@@ -354,6 +354,32 @@ def csirs():
             out[f'e{i}_ex'], out[f'e{i}_ex_nv'] = he[:, ::5], np.float64([nv])
             he, nv, hps = rx.estimateChannelLsEx(cc, polarInt=False, int2d=True, kernel='thin_plate_spline', neighbors=9, smoothing=0.1)
             out[f'e{i}_ex2'], out[f'e{i}_ex2_nv'] = he[:, ::5], np.float64([nv])
+    # DMRS pilots on four symbols (additionalPos 3): interpolation along the symbols with every kind, and the 2-D RBF path
+    car = nr.Carrier(numRbs=24, spacing=15)
+    bwp = car.curBwp
+    pd = nr.PDSCH(bwp, numLayers=2, modulation='16QAM')
+    pd.setDMRS(configType=1, additionalPos=3)
+    tx = pd.getGrid()
+    bits = rng.integers(0, 2, pd.getBitSizes(tx)[0], dtype=np.int8)
+    pd.populateGrid(tx, bits)
+    L, K = tx.shape[1:]
+    taps = (rng.standard_normal((4, 2, 2)) + 1j * rng.standard_normal((4, 2, 2))) * np.float64([1, .6, .3, .15])[:, None, None]
+    k = np.arange(K)[None, :, None]
+    l = np.arange(L)[:, None, None]
+    h = (taps[None, None] * np.exp(-2j * np.pi * (k * np.float64([0, 1.3, 2.9, 5.2]) / 256 - l * np.float64([.01, -.02, .015, 0])))[..., None, None]).sum(2)
+    rx = tx.applyChannel(h)
+    rx.grid = rx.grid + (rng.standard_normal(rx.shape) + 1j * rng.standard_normal(rx.shape)) * 0.02
+    out['dm_rx'] = rx.grid
+    out['dm_bits'] = bits
+    for kern in ('linear', 'nearest', 'quadratic', 'thin_plate_spline', 'multiquadric'):
+        he, nv = rx.estimateChannelLS(pd.dmrs, kernel=kern, polarInt=(kern == 'quadratic'))
+        out[f'dm_{kern}'], out[f'dm_{kern}_nv'] = he[:, ::5], np.float64([nv])
+    he, nv, hps = rx.estimateChannelLsEx(pd.dmrs)
+    out['dm_ex'], out['dm_ex_nv'], out['dm_ex_hk0'] = he[:, ::5], np.float64([nv]), hps[0][:, ::5]
+    he, nv, hps = rx.estimateChannelLsEx(pd.dmrs, polarInt=False, neighbors=14, smoothing=0.05)
+    out['dm_ex2'], out['dm_ex2_nv'] = he[:, ::5], np.float64([nv])
+    he, nv, hps = rx.estimateChannelLsEx(pd.dmrs, polarInt=False, kernel='linear', neighbors=12, degree=1)
+    out['dm_ex3'], out['dm_ex3_nv'] = he[:, ::5], np.float64([nv])
     # timing estimate: the CSI-RS grid's waveform against a delayed, noisy copy through a 2x1 mix
     car = nr.Carrier(numRbs=24, spacing=15)
     bwp = car.curBwp
