@@ -436,6 +436,12 @@ int32_t nrx_interp_taps_f64(const void* in, const int32_t* idx, const double* w,
 int32_t nrx_xcorr_abs_f64(const void* rx, const void* ref, int32_t n_samples, int32_t n_ref, int32_t ref_start,
                           int32_t ref_len, int32_t nr, int32_t P, double* xc, void* stream);
 
+/* CsiReport.getSINR (csifeedback.py:419-433), the inner loop of the PMI / rank search (csifeedback.py:450-536): for every
+ * codebook entry W (n_cb, nt, nl) and channel sample H (n_re, nr, nt), heff = H W and
+ * sinr[cb][re][l] = 1 / (noise_var * [(heff^H heff + noise_var I)^-1]_ll) - 1  (float64).  nl <= nr <= 8. */
+int32_t nrx_csi_sinr_f64(const void* h, int32_t n_re, int32_t nr, int32_t nt, const void* w, int32_t n_cb, int32_t nl,
+                         double noise_var, double* sinr, void* stream);
+
 /* ------------------------------------------------------------------------------------- per-PRG precoding
  * pdsch.py:1132-1165 (getPrecodingMatrix with prgSize 2/4, or the wideband precoder of a partial allocation: a list of
  * (rbList, F) groups) + grid.py:482-493 (Grid.precode with that list).  The group lists are host bookkeeping (the

@@ -22,6 +22,7 @@ from .waveform import Waveform                                 # noqa: F401
 from .antenna import AntennaElement, AntennaPanel, AntennaArray  # noqa: F401
 from .pdsch import PDSCH, DMRS, PTRS                           # noqa: F401
 from .csirs import CsiRsConfig, CsiRsSet, CsiRs                # noqa: F401
+from .csifeedback import CsiReport                             # noqa: F401
 from .random import random                                     # noqa: F401
 from .snrhelper import SnrScheduler                            # noqa: F401
 from .engine import PdschLink, run_sweep                       # noqa: F401

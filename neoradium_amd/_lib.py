@@ -87,6 +87,7 @@ SIGNATURES.update({
     'nrx_chest_noise_f64': (i32, [vp, vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]),
     'nrx_chest_pilot_means_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     'nrx_interp_taps_f64': (i32, [vp, vp, vp, i32, i32, i64, i64, i32, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
+    'nrx_csi_sinr_f64': (i32, [vp, i32, i32, i32, vp, i32, i32, f64, vp, vp]),
     'nrx_xcorr_abs_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_group_mean_f64': (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
     'nrx_precode_prg_f32': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),

@@ -969,3 +969,17 @@ def polar_scl_decode(llr, info_mask, n_info, msg_src, list_size=8, crc_poly=None
                                          ptr(_idx32(msg_src, K, 'msg_src')), K, crc_id, ptr(crc_expect), ptr(msg), ptr(ok),
                                          ptr(cands), ptr(costs), stream()))
     return (msg, ok, cands, costs) if want_candidates else (msg, ok)
+
+
+def csi_sinr(h, w, noise_var):
+    """CsiReport.getSINR (csifeedback.py:419-433): h (n, Nr, Nt), codebook w (Ncb, Nt, Nl) complex128 -> (Ncb, n, Nl) f64."""
+    h, w = h.contiguous(), w.contiguous()
+    if h.dtype != torch.complex128 or w.dtype != torch.complex128:
+        raise ValueError("csi_sinr works on complex128")
+    if h.dim() != 3 or w.dim() != 3 or h.shape[2] != w.shape[1]:
+        raise ValueError("csi_sinr: h must be (n, Nr, Nt) and w (Ncb, Nt, Nl)")
+    dev = _dev(h)
+    out = torch.empty((w.shape[0], h.shape[0], w.shape[2]), dtype=torch.float64, device=dev)
+    check(lib().nrx_csi_sinr_f64(ptr(h), h.shape[0], h.shape[1], h.shape[2], ptr(w), w.shape[0], w.shape[2],
+                                 float(noise_var), ptr(out), stream()))
+    return out

@@ -396,6 +396,56 @@ def csirs():
     np.savez_compressed(os.path.join(GOLD, 'csirs.npz'), **out)
 
 
+def csi_channel(seed, L, K, nr, nt):
+    """Seeded smooth channel used by the csifeedback fixtures and their tests: four delayed taps with slow phase drift."""
+    rng = np.random.default_rng(seed)
+    taps = (rng.standard_normal((4, nr, nt)) + 1j * rng.standard_normal((4, nr, nt))) * np.float64([1, .7, .4, .2])[:, None, None]
+    k = np.arange(K)[None, :, None]
+    l = np.arange(L)[:, None, None]
+    ph = np.exp(-2j * np.pi * (k * np.float64([0, 1.7, 3.1, 6.4]) / 512 - l * np.float64([.004, -.006, .002, 0])))
+    return (taps[None, None] * ph[..., None, None]).sum(2) / 2
+
+
+def csifeedback():
+    """CSI report (csifeedback.py): Type-I single-panel codebooks (indices + precoders), the per-rank PMI search and the rank
+    choice on seeded channels, sub-band layouts -- for the configurations the reference can run (one-row panels)."""
+    import json
+    out = {}
+    cfgs = [dict(rb=24, ports=4, cdm=2, kw=dict(freqMap='000100'), rep=dict(n1=2, n2=1), nr=4, nv=0.01, ranks=[1, 2, 3, 4]),
+            dict(rb=24, ports=8, cdm=2, kw={}, rep=dict(n1=4, n2=1), nr=4, nv=0.02, ranks=[1, 2, 3, 4]),
+            dict(rb=24, ports=8, cdm=4, kw={}, rep=dict(n1=4, n2=1, codebookMode=2, prgSize=2, cbRiRestriction='00011111'), nr=8, nv=0.01, ranks=[1, 2, 3, 4, 5]),
+            dict(rb=52, ports=16, cdm=4, kw={}, rep=dict(n1=8, n2=1, subbandSize=8), nr=4, nv=0.005, ranks=[1, 2, 3, 4]),
+            dict(rb=24, ports=32, cdm=8, kw={}, rep=dict(n1=16, n2=1, prgSize=0, cbRiRestriction='00000011'), nr=2, nv=0.05, ranks=[1, 2]),
+            dict(rb=20, ports=12, cdm=2, kw={}, rep=dict(n1=6, n2=1), nr=4, nv=0.01, ranks=[1, 2, 3, 4]),
+            dict(rb=24, ports=2, cdm=2, kw={}, rep=dict(n1=1, n2=1, cbRiRestriction='00000001'), nr=2, nv=0.01, ranks=[1])]
+    out['cfgs'] = np.array(json.dumps(cfgs))
+    for i, c in enumerate(cfgs):
+        car = nr.Carrier(numRbs=c['rb'], spacing=15)
+        bwp = car.curBwp
+        cc = nr.CsiRsConfig(csiType='NZP', bwp=bwp, numPorts=c['ports'], cdmSize=c['cdm'], **c['kw'])
+        rep = nr.CsiReport(cc, **c['rep'])
+        h = csi_channel(100 + i, 14, 12 * c['rb'], c['nr'], c['ports'])
+        for rank in c['ranks']:
+            idx, cb = rep.getCodebook(rank)
+            out[f'r{i}_{rank}_idx'] = np.int32([list(a) + [b] for a, b in idx])
+            out[f'r{i}_{rank}_cb'] = cb[::max(1, len(cb) // 24)]                  # a spread of entries (all when <= 24)
+            pmi, ws, sb = rep.bestPmiForRank(h, rank, c['nv'])
+            out[f'r{i}_{rank}_pmi'] = np.int32(list(pmi[0]) + list(pmi[1]))
+            out[f'r{i}_{rank}_w'] = np.array([np.asarray(w).reshape(c['ports'], rank) for w in ws])
+            out[f'r{i}_{rank}_sinr'] = np.concatenate([np.asarray(v) for v in sb])
+        rank, pmi, sb = rep.getBestRank(h, c['nv'])
+        out[f'r{i}_best'] = np.int32([rank] + list(pmi[0]) + list(pmi[1]))
+        out[f'r{i}_subbands'] = np.int32(list(rep.subbands(4)) + [-1] + list(rep.subbands(8)))
+        out[f'r{i}_cqi2pmi'] = np.array(json.dumps([rep.getCqiToPmiIdxes(0), rep.getCqiToPmiIdxes(2), rep.getCqiToPmiIdxes(4)]))
+    car = nr.Carrier(startRb=3, numRbs=50, spacing=15)
+    cc = nr.CsiRsConfig(csiType='NZP', bwp=car.curBwp, numPorts=8)
+    rep = nr.CsiReport(cc, n1=4, n2=1, subbandSizeCqi=8, subbandSizePmi=4)
+    out['off_subbands'] = np.int32(list(rep.subbands(4)) + [-1] + list(rep.subbands(8)))
+    out['off_cqi2pmi'] = np.array(json.dumps([rep.getCqiToPmiIdxes(4), rep.getCqiToPmiIdxes(2)]))
+    out['cqi_tables'] = np.array(json.dumps(nr.csifeedback.cqiTables))
+    np.savez_compressed(os.path.join(GOLD, 'csifeedback.npz'), **out)
+
+
 def ofdm_options():
     """The non-default kwargs of Grid.ofdmModulate / Waveform.ofdmDemodulate: two slots in one call, carrier up-conversion
     (f0 > 0), an FFT window that starts 30 % / 80 % into the CP.  Input grid from the seed; outputs stored."""
@@ -745,6 +795,7 @@ if __name__ == '__main__':
     host()
     ptrs()
     csirs()
+    csifeedback()
     ofdm_options()
     channels()
     channels_xiao()
