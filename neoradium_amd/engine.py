@@ -367,7 +367,27 @@ class PdschLink:
             else:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'], rv=harq[0], circ=harq[1], reset=harq[2])
             rows = cw['rows'] if harq is None else None        # HARQ soft buffers fill other columns: all rows
-            if self.firstPassIter is None:
+            if harq is not None and self.firstPassIter is None and cw['rows'] is not None:
+                # ... of the retransmissions.  A process that starts a new block holds rv 0 alone in a fresh buffer, which is
+                # the single-shot case: the rows whose parity is punctured are exact no-ops there as well, and the truncated
+                # graph has the on-chip float64 instantiation.  One small host read per round (n_proc flags) splits the batch.
+                fresh = harq[2].to(torch.bool).cpu()
+                cbs = torch.arange(rr.shape[0], device=rr.device).reshape(-1, ccfg.C)
+                i_new, i_re = cbs[fresh].reshape(-1), cbs[~fresh].reshape(-1)
+                dec = None
+                for idx, rws in ((i_new, cw['rows']), (i_re, None)):
+                    if idx.numel() == 0:
+                        continue
+                    part = ops.ldpc_decode(rr if idx.numel() == rr.shape[0] else rr.index_select(0, idx), ccfg, self.numIter,
+                                           rows=rws)
+                    if idx.numel() == rr.shape[0]:
+                        dec = part
+                    else:
+                        dec = torch.empty((rr.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device) \
+                            if dec is None else dec
+                        dec.index_copy_(0, idx, part)
+                tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb_crc=False)
+            elif self.firstPassIter is None:
                 dec = ops.ldpc_decode(rr, ccfg, self.numIter, rows=rows)
                 tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb_crc=False)
             else:
@@ -399,8 +419,9 @@ class PdschLink:
         (harq.py:626-631) -- in one batch.  Per process the state is what ``HarqCW`` keeps (harq.py:145-202): the
         transport block being sent, the try counter, and the soft buffer the decoder accumulates into; all of it stays
         on the GPU (soft buffers: n_proc*C x (Ncb-F) LLRs resident in HBM), and the retransmission decision is taken
-        on the device, so a round needs no host round trip.  A process whose block decodes (every code-block CRC
-        passes) or times out after ``maxTries`` starts a new block in its next round.
+        on the device; the one host read per round is the n_proc "new block" flags that let the decoder run first
+        transmissions on the truncated graph (they are the single-shot case).  A process whose block decodes (every
+        code-block CRC passes) or times out after ``maxTries`` starts a new block in its next round.
 
         Returns (stats, state): stats with the fields of ``HarqEntity`` (txBlocks/rxBlocks/txBits/rxBits per try,
         numTimeouts, throughput and BLER in percent, meanTries); pass ``state`` back in to continue the run."""
