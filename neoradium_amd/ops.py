@@ -126,7 +126,7 @@ _ws_cache = {}
 
 def _decode_ws(cfg, device):
     need = lib().nrx_ldpc_decode_ws_bytes(C.byref(cfg), 1)
-    key = (device, cfg.bg)
+    key = (device, cfg.bg, stream())            # one workspace per stream: launches on different streams may overlap
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
@@ -891,12 +891,15 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None):
     nr, P = gains1.shape[2], gains1.shape[4]
     dev = _dev(x)
     taps = taps.to(device=dev, dtype=torch.float64).contiguous()
+    host_off = None if isinstance(tap_off, torch.Tensor) and tap_off.is_cuda else np.asarray(tap_off)
     tap_off = _i32(tap_off, dev)
     if taps.shape[0] != P or tap_off.numel() != P:
         raise ValueError("tap table / path count mismatch")
     flen = taps.shape[1]
     if hist is None:                       # (device -> host read; batched callers pass it)
         hist = int(tap_off.max()) + flen - 1
+    elif host_off is not None and (host_off.min() < 0 or hist < int(host_off.max()) + flen - 1):
+        raise ValueError("hist must cover the longest path: max(tap_off) + flen - 1")
     y = torch.empty((n, nr, ns), dtype=torch.complex128, device=dev)
     check(lib().nrx_apply_td_paths_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen,
                                        hist, _host_i32(set_lens), ptr(y), stream()))

@@ -288,3 +288,36 @@ def test_csirs_vs_reference():
             ma.CsiRsConfig(csiType='NZP', bwp=bwp, **bad)
     with pytest.raises(ValueError):
         ma.CsiRsConfig().populateGrid(grid)
+
+
+def test_interpolation_tap_tables_vs_scipy():
+    """neoradium_amd.interp: the tap tables reproduce the routines the reference calls (utils.py:26-35 interp1d /
+    RBFInterpolator with nearest neighbours, grid.py:853-861 in two dimensions) when applied to sample values."""
+    from scipy.interpolate import RBFInterpolator, interp1d
+    from neoradium_amd.interp import rbf_taps, taps_1d
+    rng = np.random.default_rng(11)
+    x = np.arange(0.5, 288, 4.0)
+    xn = np.arange(288.0)
+    v = rng.standard_normal((len(x), 3)) + 1j * rng.standard_normal((len(x), 3))
+    for kind in ('nearest', 'quadratic', 'linear'):
+        idx, w = taps_1d(x, xn, kind)
+        ref = interp1d(x, v, kind=kind, axis=0, fill_value='extrapolate')(xn)
+        assert np.abs((w[:, :, None] * v[idx]).sum(1) - ref).max() < 1e-12, kind
+    for kind in ('thin_plate_spline', 'multiquadric'):
+        idx, w = taps_1d(x, xn, kind, 12, 0.0)
+        ref = RBFInterpolator(x[:, None], v, 12, 0.0, kind, 1)(xn[:, None])
+        assert idx.shape == (288, 12) and np.abs((w[:, :, None] * v[idx]).sum(1) - ref).max() < 1e-10, kind
+    pts = np.float64(np.meshgrid(np.arange(96.), [2., 5., 8., 11.])).reshape(2, -1).T
+    qs = np.float64(np.meshgrid(range(96), range(14))).reshape(2, -1).T
+    vv = rng.standard_normal((len(pts), 2)) + 1j * rng.standard_normal((len(pts), 2))
+    for kern, nb, sm, deg in (('thin_plate_spline', 12, 0.0, None), ('thin_plate_spline', 16, 0.1, None), ('linear', 12, 0.0, 1),
+                              ('cubic', 14, 0.0, None)):
+        idx, w = rbf_taps(pts, qs, kern, nb, sm, None, deg)
+        ref = RBFInterpolator(pts, vv, nb, sm, kern, degree=deg)(qs)
+        assert np.abs((w[:, :, None] * vv[idx]).sum(1) - ref).max() < 1e-10, kern
+    with pytest.raises(np.linalg.LinAlgError):          # collinear neighbour sets are singular there as well
+        rbf_taps(pts, qs, 'thin_plate_spline', 6, 0.0, None, None)
+    with pytest.raises(ValueError):
+        rbf_taps(pts, qs, 'multiquadric', 12, 0.0, None, None)          # needs epsilon
+    with pytest.raises(ValueError):
+        taps_1d(x, xn, 'cubic')
