@@ -48,6 +48,43 @@ DEF_KERNEL(mov_b64, "v_mov_b64 %0,%8\n v_mov_b64 %1,%8\n v_mov_b64 %2,%8\n v_mov
 DEF_KERNEL(ds_read_b64, "ds_read_b64 %0,%10\n ds_read_b64 %1,%10 offset:2048\n ds_read_b64 %2,%10 offset:4096\n ds_read_b64 %3,%10 offset:6144\n ds_read_b64 %4,%10 offset:8192\n ds_read_b64 %5,%10 offset:10240\n ds_read_b64 %6,%10 offset:12288\n ds_read_b64 %7,%10 offset:14336\n s_waitcnt lgkmcnt(0)\n ")
 DEF_KERNEL(ds_write_b64, "ds_write_b64 %10,%0\n ds_write_b64 %10,%1 offset:2048\n ds_write_b64 %10,%2 offset:4096\n ds_write_b64 %10,%3 offset:6144\n ds_write_b64 %10,%4 offset:8192\n ds_write_b64 %10,%5 offset:10240\n ds_write_b64 %10,%6 offset:12288\n ds_write_b64 %10,%7 offset:14336\n s_waitcnt lgkmcnt(0)\n ")
 
+
+// the decoder's 32-bit companions (selects, sign-word bookkeeping, index compares): same harness on 32-bit registers
+#define DEF_KERNEL32(NAME, ASM8)                                                                            \
+  __global__ void k_##NAME(unsigned long long* cyc, double* sink, int iters) {                              \
+    unsigned r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6,\
+             r7 = r0 + 7;                                                                                   \
+    unsigned s = 0x10001u + blockIdx.x, u = 0x55aa55aau;                                                    \
+    unsigned long long t0, t1;                                                                              \
+    asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x55555555\n\ts_mov_b64 vcc, s[20:21]\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory", "s20", "s21", "vcc"); \
+    for (int i = 0; i < iters; ++i) {                                                                       \
+      asm volatile(ASM8 ASM8 ASM8 ASM8                                                                      \
+                   : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)         \
+                   : "v"(s), "v"(u)                                                                         \
+                   : "s22", "s23", "memory");                                                               \
+    }                                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");     \
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = (double)(r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7);          \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;         \
+  }
+#define R8(FMT_A, FMT_B) FMT_A "%0" FMT_B "\n " FMT_A "%1" FMT_B "\n " FMT_A "%2" FMT_B "\n " FMT_A "%3" FMT_B "\n " FMT_A "%4" FMT_B "\n " FMT_A "%5" FMT_B "\n " FMT_A "%6" FMT_B "\n " FMT_A "%7" FMT_B "\n "
+DEF_KERNEL32(cndmask_vcc, "v_cndmask_b32 %0,%0,%8,vcc\n v_cndmask_b32 %1,%1,%8,vcc\n v_cndmask_b32 %2,%2,%8,vcc\n v_cndmask_b32 %3,%3,%8,vcc\n v_cndmask_b32 %4,%4,%8,vcc\n v_cndmask_b32 %5,%5,%8,vcc\n v_cndmask_b32 %6,%6,%8,vcc\n v_cndmask_b32 %7,%7,%8,vcc\n ")
+DEF_KERNEL32(cndmask_sgpr, "v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %1,%1,%8,s[20:21]\n v_cndmask_b32 %2,%2,%8,s[20:21]\n v_cndmask_b32 %3,%3,%8,s[20:21]\n v_cndmask_b32 %4,%4,%8,s[20:21]\n v_cndmask_b32 %5,%5,%8,s[20:21]\n v_cndmask_b32 %6,%6,%8,s[20:21]\n v_cndmask_b32 %7,%7,%8,s[20:21]\n ")
+DEF_KERNEL32(and_or_b32, "v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %1,%1,%8,%9\n v_and_or_b32 %2,%2,%8,%9\n v_and_or_b32 %3,%3,%8,%9\n v_and_or_b32 %4,%4,%8,%9\n v_and_or_b32 %5,%5,%8,%9\n v_and_or_b32 %6,%6,%8,%9\n v_and_or_b32 %7,%7,%8,%9\n ")
+DEF_KERNEL32(xor_b32, "v_xor_b32 %0,%0,%8\n v_xor_b32 %1,%1,%8\n v_xor_b32 %2,%2,%8\n v_xor_b32 %3,%3,%8\n v_xor_b32 %4,%4,%8\n v_xor_b32 %5,%5,%8\n v_xor_b32 %6,%6,%8\n v_xor_b32 %7,%7,%8\n ")
+DEF_KERNEL32(alignbit_b32, "v_alignbit_b32 %0,%0,%8,7\n v_alignbit_b32 %1,%1,%8,7\n v_alignbit_b32 %2,%2,%8,7\n v_alignbit_b32 %3,%3,%8,7\n v_alignbit_b32 %4,%4,%8,7\n v_alignbit_b32 %5,%5,%8,7\n v_alignbit_b32 %6,%6,%8,7\n v_alignbit_b32 %7,%7,%8,7\n ")
+DEF_KERNEL32(add_u32, "v_add_u32 %0,%0,%8\n v_add_u32 %1,%1,%8\n v_add_u32 %2,%2,%8\n v_add_u32 %3,%3,%8\n v_add_u32 %4,%4,%8\n v_add_u32 %5,%5,%8\n v_add_u32 %6,%6,%8\n v_add_u32 %7,%7,%8\n ")
+DEF_KERNEL32(cmp_eq_u32_vcc, "v_cmp_eq_u32 vcc,%0,%8\n v_cmp_eq_u32 vcc,%1,%8\n v_cmp_eq_u32 vcc,%2,%8\n v_cmp_eq_u32 vcc,%3,%8\n v_cmp_eq_u32 vcc,%4,%8\n v_cmp_eq_u32 vcc,%5,%8\n v_cmp_eq_u32 vcc,%6,%8\n v_cmp_eq_u32 vcc,%7,%8\n ")
+DEF_KERNEL32(cmp_eq_u32_sgpr, "v_cmp_eq_u32 s[22:23],%0,%8\n v_cmp_eq_u32 s[22:23],%1,%8\n v_cmp_eq_u32 s[22:23],%2,%8\n v_cmp_eq_u32 s[22:23],%3,%8\n v_cmp_eq_u32 s[22:23],%4,%8\n v_cmp_eq_u32 s[22:23],%5,%8\n v_cmp_eq_u32 s[22:23],%6,%8\n v_cmp_eq_u32 s[22:23],%7,%8\n ")
+DEF_KERNEL32(bfi_b32, "v_bfi_b32 %0,%8,%0,%9\n v_bfi_b32 %1,%8,%1,%9\n v_bfi_b32 %2,%8,%2,%9\n v_bfi_b32 %3,%8,%3,%9\n v_bfi_b32 %4,%8,%4,%9\n v_bfi_b32 %5,%8,%5,%9\n v_bfi_b32 %6,%8,%6,%9\n v_bfi_b32 %7,%8,%7,%9\n ")
+// a cmp writing an SGPR pair immediately consumed by a cndmask (the decoder's select idiom)
+DEF_KERNEL32(cmp_then_cndmask, "v_cmp_eq_u32 s[22:23],%0,%8\n v_cndmask_b32 %1,%1,%9,s[22:23]\n v_cmp_eq_u32 s[22:23],%2,%8\n v_cndmask_b32 %3,%3,%9,s[22:23]\n v_cmp_eq_u32 s[22:23],%4,%8\n v_cndmask_b32 %5,%5,%9,s[22:23]\n v_cmp_eq_u32 s[22:23],%6,%8\n v_cndmask_b32 %7,%7,%9,s[22:23]\n ")
+// is it the VCC register or the VOP2 encoding?  (a) VOP3 encoding reading vcc; (b) VOP2 with vcc written by a VALU compare
+DEF_KERNEL32(cndmask_e64_vcc, "v_cndmask_b32_e64 %0,%0,%8,vcc\n v_cndmask_b32_e64 %1,%1,%8,vcc\n v_cndmask_b32_e64 %2,%2,%8,vcc\n v_cndmask_b32_e64 %3,%3,%8,vcc\n v_cndmask_b32_e64 %4,%4,%8,vcc\n v_cndmask_b32_e64 %5,%5,%8,vcc\n v_cndmask_b32_e64 %6,%6,%8,vcc\n v_cndmask_b32_e64 %7,%7,%8,vcc\n ")
+DEF_KERNEL32(cmpvcc_cndmask_e32, "v_cmp_eq_u32 vcc,%0,%8\n v_cndmask_b32_e32 %1,%1,%9,vcc\n v_cmp_eq_u32 vcc,%2,%8\n v_cndmask_b32_e32 %3,%3,%9,vcc\n v_cmp_eq_u32 vcc,%4,%8\n v_cndmask_b32_e32 %5,%5,%9,vcc\n v_cmp_eq_u32 vcc,%6,%8\n v_cndmask_b32_e32 %7,%7,%9,vcc\n ")
+DEF_KERNEL32(cmpvcc_2cndmask_e32, "v_cmp_eq_u32 vcc,%0,%8\n v_cndmask_b32_e32 %1,%1,%9,vcc\n v_cndmask_b32_e32 %2,%2,%9,vcc\n v_cndmask_b32_e32 %3,%3,%9,vcc\n v_cmp_eq_u32 vcc,%4,%8\n v_cndmask_b32_e32 %5,%5,%9,vcc\n v_cndmask_b32_e32 %6,%6,%9,vcc\n v_cndmask_b32_e32 %7,%7,%9,vcc\n ")
+DEF_KERNEL32(cndmask_e32_mix, "v_cndmask_b32_e32 %0,%0,%8,vcc\n v_xor_b32 %1,%1,%8\n v_cndmask_b32_e32 %2,%2,%8,vcc\n v_xor_b32 %3,%3,%8\n v_cndmask_b32_e32 %4,%4,%8,vcc\n v_xor_b32 %5,%5,%8\n v_cndmask_b32_e32 %6,%6,%8,vcc\n v_xor_b32 %7,%7,%8\n ")
+
 typedef void (*kern_t)(unsigned long long*, double*, int);
 struct Case { const char* name; kern_t k; int per_iter; };
 
@@ -65,7 +102,9 @@ int main(int argc, char** argv) {
 #define C(N, P) {#N, k_##N, P}
       C(add_f64, 32), C(mul_f64, 32), C(min_f64, 32), C(max_f64, 32), C(add_f64_abs, 32), C(min_f64_abs, 32), C(fma_f64, 32),
       C(cmp_eq_f64_sgpr, 32), C(cmp_lt_f64_vcc, 32), C(cmp_eq_u64_sgpr, 32), C(cmp_lt_u64_sgpr, 32), C(lshlrev_b64, 32),
-      C(mov_b64, 32), C(ds_read_b64, 32), C(ds_write_b64, 32),
+      C(mov_b64, 32), C(ds_read_b64, 32), C(ds_write_b64, 32), C(cndmask_vcc, 32), C(cndmask_sgpr, 32), C(and_or_b32, 32),
+      C(xor_b32, 32), C(alignbit_b32, 32), C(add_u32, 32), C(cmp_eq_u32_vcc, 32), C(cmp_eq_u32_sgpr, 32), C(bfi_b32, 32),
+      C(cmp_then_cndmask, 32), C(cndmask_e64_vcc, 32), C(cmpvcc_cndmask_e32, 32), C(cmpvcc_2cndmask_e32, 32), C(cndmask_e32_mix, 32),
   };
   printf("%-20s %8s %8s %8s %8s   cycles per wave64 instruction per SIMD at W waves/SIMD\n", "op", "W=1", "W=2", "W=3", "W=4");
   for (auto& c : cases) {
