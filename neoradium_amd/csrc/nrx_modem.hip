@@ -101,6 +101,39 @@ pdsch_populate_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, con
   }
 }
 
+// The same with the modulation order as a template parameter (even orders): the qm byte-per-bit values of a symbol and of
+// its scrambling bits are fetched as qm/2 16-bit words (bit 2k = real-axis bit in the low byte, bit 2k+1 = imaginary-axis
+// bit in the high byte), which halves the number of loads per element; needs 2-byte aligned rows (checked by the host).
+template <typename T, int QM>
+__global__ void __launch_bounds__(256)
+pdsch_populate_q_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, const uint8_t* __restrict__ scr, double scale,
+                        const int32_t* __restrict__ re_inv, const cx<T>* __restrict__ templ,
+                        const int64_t* __restrict__ templ_sel, int64_t elems, cx<T>* __restrict__ out, int n_batch) {
+  constexpr int h = QM / 2;
+  const int b = blockIdx.y;
+  const cx<T>* tb = templ + (size_t)templ_sel[b] * elems;
+  const uint8_t* bb = bits + (size_t)b * bits_stride;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)elems; e += gridDim.x * blockDim.x) {
+    const int i = re_inv[e];
+    cx<T> o;
+    if (i < 0) {
+      o = tb[e];
+    } else {
+      const uint16_t* src = (const uint16_t*)(bb + (size_t)i * QM);
+      uint32_t rb = 0, ib = 0;
+#pragma unroll
+      for (int k = 0; k < h; ++k) {
+        uint32_t w = src[k];
+        if (scr) w ^= ((const uint16_t*)(scr + (size_t)i * QM))[k];   // pdsch.py:603-608
+        rb = (rb << 1) | (w & 1u);
+        ib = (ib << 1) | ((w >> 8) & 1u);
+      }
+      o = cx<T>((T)((double)pam_level(rb, h) * scale), (T)((double)pam_level(ib, h) * scale));
+    }
+    out[(size_t)b * elems + e] = o;
+  }
+}
+
 // Max-log LLRs (useMax=True, the reference default).  The exhaustive max over the 2^qm points of
 // -|y-s|^2/s2 separates per axis for square QAM: bits on the real axis only see (Re y - a)^2 because the
 // imaginary-axis minimum is common to both hypotheses and cancels in the difference.
@@ -270,9 +303,23 @@ int32_t populate_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* 
   if (elems == 0 || n_batch == 0) return NRX_OK;
   int gx = (int)((elems + 255) / 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(pdsch_populate_kernel<T>, dim3(gx, n_batch), dim3(256), 0,
-                     (hipStream_t)stream, bits, bits_stride, scr, qm, qam_scale(qm), re_inv, (const cx<T>*)templ, templ_sel,
-                     elems, (cx<T>*)out, n_batch);
+  const bool aligned = (((uintptr_t)bits | (uintptr_t)scr | (uintptr_t)bits_stride) & 1) == 0;
+#define NRX_POP_CASE(Q)                                                                                                    \
+  case Q:                                                                                                                  \
+    hipLaunchKernelGGL((pdsch_populate_q_kernel<T, Q>), dim3(gx, n_batch), dim3(256), 0, (hipStream_t)stream, bits,        \
+                       bits_stride, scr, qam_scale(Q), re_inv, (const cx<T>*)templ, templ_sel, elems, (cx<T>*)out, n_batch); \
+    break;
+  switch (aligned ? qm : 0) {
+    NRX_POP_CASE(2)
+    NRX_POP_CASE(4)
+    NRX_POP_CASE(6)
+    NRX_POP_CASE(8)
+    NRX_POP_CASE(10)
+    default:
+      hipLaunchKernelGGL(pdsch_populate_kernel<T>, dim3(gx, n_batch), dim3(256), 0, (hipStream_t)stream, bits, bits_stride,
+                         scr, qm, qam_scale(qm), re_inv, (const cx<T>*)templ, templ_sel, elems, (cx<T>*)out, n_batch);
+  }
+#undef NRX_POP_CASE
   NRX_CHECK_LAUNCH("nrx_pdsch_populate");
   return NRX_OK;
 }
