@@ -84,6 +84,41 @@ DEF_KERNEL32(cndmask_e64_vcc, "v_cndmask_b32_e64 %0,%0,%8,vcc\n v_cndmask_b32_e6
 DEF_KERNEL32(cmpvcc_cndmask_e32, "v_cmp_eq_u32 vcc,%0,%8\n v_cndmask_b32_e32 %1,%1,%9,vcc\n v_cmp_eq_u32 vcc,%2,%8\n v_cndmask_b32_e32 %3,%3,%9,vcc\n v_cmp_eq_u32 vcc,%4,%8\n v_cndmask_b32_e32 %5,%5,%9,vcc\n v_cmp_eq_u32 vcc,%6,%8\n v_cndmask_b32_e32 %7,%7,%9,vcc\n ")
 DEF_KERNEL32(cmpvcc_2cndmask_e32, "v_cmp_eq_u32 vcc,%0,%8\n v_cndmask_b32_e32 %1,%1,%9,vcc\n v_cndmask_b32_e32 %2,%2,%9,vcc\n v_cndmask_b32_e32 %3,%3,%9,vcc\n v_cmp_eq_u32 vcc,%4,%8\n v_cndmask_b32_e32 %5,%5,%9,vcc\n v_cndmask_b32_e32 %6,%6,%9,vcc\n v_cndmask_b32_e32 %7,%7,%9,vcc\n ")
 DEF_KERNEL32(cndmask_e32_mix, "v_cndmask_b32_e32 %0,%0,%8,vcc\n v_xor_b32 %1,%1,%8\n v_cndmask_b32_e32 %2,%2,%8,vcc\n v_xor_b32 %3,%3,%8\n v_cndmask_b32_e32 %4,%4,%8,vcc\n v_xor_b32 %5,%5,%8\n v_cndmask_b32_e32 %6,%6,%8,vcc\n v_xor_b32 %7,%7,%8\n ")
+// dependent chains: every instruction consumes the previous result (8 per block on ONE register) -> issue-to-use latency
+DEF_KERNEL(dep_add_f64, "v_add_f64 %0,%0,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %0,%0,%8\n ")
+DEF_KERNEL(dep2_add_f64, "v_add_f64 %0,%0,%8\n v_add_f64 %1,%1,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %1,%1,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %1,%1,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %1,%1,%8\n ")
+DEF_KERNEL(dep4_add_f64, "v_add_f64 %0,%0,%8\n v_add_f64 %1,%1,%8\n v_add_f64 %2,%2,%8\n v_add_f64 %3,%3,%8\n v_add_f64 %0,%0,%8\n v_add_f64 %1,%1,%8\n v_add_f64 %2,%2,%8\n v_add_f64 %3,%3,%8\n ")
+DEF_KERNEL32(dep_xor_b32, "v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n v_xor_b32 %0,%0,%8\n ")
+DEF_KERNEL32(dep_and_or_b32, "v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n v_and_or_b32 %0,%0,%8,%9\n ")
+DEF_KERNEL32(dep_cndmask_sgpr, "v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %0,%0,%8,s[20:21]\n v_cndmask_b32 %0,%0,%8,s[20:21]\n ")
+// the decoder's pass-2 chain on one edge: compare -> select -> sign -> (the f64 add is in the f64 harness above)
+DEF_KERNEL32(dep_cmp_cnd_andor, "v_cmp_eq_u32 vcc,%0,%8\n s_nop 0\n v_cndmask_b32_e32 %1,%1,%9,vcc\n v_and_or_b32 %0,%1,%8,%9\n v_cmp_eq_u32 vcc,%0,%8\n s_nop 0\n v_cndmask_b32_e32 %1,%1,%9,vcc\n v_and_or_b32 %0,%1,%8,%9\n ")
+// VGPR bank conflicts: the same instruction stream with both sources in the same register bank (register number mod 4) and
+// in different banks.  Fixed registers (declared clobbered); values are whatever the registers hold (timing only).
+#define DEF_KERNEL_FIXED(NAME, ASM8)                                                                        \
+  __global__ void k_##NAME(unsigned long long* cyc, double* sink, int iters) {                              \
+    unsigned long long t0, t1;                                                                              \
+    asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x55555555\n\ts_mov_b64 vcc, s[20:21]\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory", "s20", "s21", "vcc"); \
+    for (int i = 0; i < iters; ++i) {                                                                       \
+      asm volatile(ASM8 ASM8 ASM8 ASM8 ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", \
+                   "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "memory"); \
+    }                                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");     \
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = 0.0;                                                      \
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;         \
+  }
+DEF_KERNEL_FIXED(add_f64_samebank, "v_add_f64 v[20:21],v[24:25],v[28:29]\n v_add_f64 v[22:23],v[26:27],v[30:31]\n v_add_f64 v[32:33],v[36:37],v[40:41]\n v_add_f64 v[34:35],v[38:39],v[42:43]\n v_add_f64 v[20:21],v[24:25],v[28:29]\n v_add_f64 v[22:23],v[26:27],v[30:31]\n v_add_f64 v[32:33],v[36:37],v[40:41]\n v_add_f64 v[34:35],v[38:39],v[42:43]\n ")
+DEF_KERNEL_FIXED(add_f64_diffbank, "v_add_f64 v[20:21],v[24:25],v[30:31]\n v_add_f64 v[22:23],v[26:27],v[28:29]\n v_add_f64 v[32:33],v[36:37],v[42:43]\n v_add_f64 v[34:35],v[38:39],v[40:41]\n v_add_f64 v[20:21],v[24:25],v[30:31]\n v_add_f64 v[22:23],v[26:27],v[28:29]\n v_add_f64 v[32:33],v[36:37],v[42:43]\n v_add_f64 v[34:35],v[38:39],v[40:41]\n ")
+DEF_KERNEL_FIXED(cnd_e32_samebank, "v_cndmask_b32_e32 v20,v24,v28,vcc\n v_xor_b32 v21,v25,v29\n v_cndmask_b32_e32 v22,v26,v30,vcc\n v_xor_b32 v23,v27,v31\n v_cndmask_b32_e32 v32,v36,v40,vcc\n v_xor_b32 v33,v37,v41\n v_cndmask_b32_e32 v34,v38,v42,vcc\n v_xor_b32 v35,v39,v43\n ")
+DEF_KERNEL_FIXED(cnd_e32_diffbank, "v_cndmask_b32_e32 v20,v24,v29,vcc\n v_xor_b32 v21,v25,v30\n v_cndmask_b32_e32 v22,v26,v31,vcc\n v_xor_b32 v23,v27,v28\n v_cndmask_b32_e32 v32,v36,v41,vcc\n v_xor_b32 v33,v37,v42\n v_cndmask_b32_e32 v34,v38,v43,vcc\n v_xor_b32 v35,v39,v40\n ")
+DEF_KERNEL_FIXED(andor_samebank, "v_and_or_b32 v20,v24,v28,v32\n v_and_or_b32 v21,v25,v29,v33\n v_and_or_b32 v22,v26,v30,v34\n v_and_or_b32 v23,v27,v31,v35\n v_and_or_b32 v36,v40,v44,v24\n v_and_or_b32 v37,v41,v45,v25\n v_and_or_b32 v38,v42,v46,v26\n v_and_or_b32 v39,v43,v47,v27\n ")
+DEF_KERNEL_FIXED(andor_diffbank, "v_and_or_b32 v20,v24,v29,v34\n v_and_or_b32 v21,v25,v30,v35\n v_and_or_b32 v22,v26,v31,v32\n v_and_or_b32 v23,v27,v28,v33\n v_and_or_b32 v36,v40,v45,v26\n v_and_or_b32 v37,v41,v46,v27\n v_and_or_b32 v38,v42,v47,v24\n v_and_or_b32 v39,v43,v44,v25\n ")
+// mixes: does interleaving encodings / data types cost more than the sum of the parts?
+DEF_KERNEL_FIXED(mix_f64_vop2, "v_add_f64 v[20:21],v[24:25],v[30:31]\n v_xor_b32 v32,v36,v41\n v_min_f64 v[22:23],v[26:27],v[28:29]\n v_add_u32 v33,v37,v42\n v_max_f64 v[34:35],v[38:39],v[40:41]\n v_xor_b32 v43,v44,v45\n v_add_f64 v[46:47],v[24:25],v[28:29]\n v_add_u32 v36,v37,v38\n ")
+DEF_KERNEL_FIXED(mix_f64_vop3, "v_add_f64 v[20:21],v[24:25],v[30:31]\n v_and_or_b32 v32,v36,v41,v42\n v_min_f64 v[22:23],v[26:27],v[28:29]\n v_alignbit_b32 v33,v37,v42,31\n v_max_f64 v[34:35],v[38:39],v[40:41]\n v_and_or_b32 v43,v44,v45,v46\n v_add_f64 v[46:47],v[24:25],v[28:29]\n v_cndmask_b32_e64 v36,v37,v38,s[20:21]\n ")
+// one edge of pass 2 as the compiler emits it (registers renamed), twice
+DEF_KERNEL_FIXED(mix_pass2_edge, "v_cmp_eq_f64 vcc,|v[20:21]|,v[22:23]\n v_alignbit_b32 v24,v25,v26,31\n s_nop 0\n v_cndmask_b32_e32 v27,v28,v29,vcc\n v_cndmask_b32_e32 v30,v31,v32,vcc\n v_and_or_b32 v33,v26,s20,v27\n v_add_f64 v[34:35],v[20:21],v[32:33]\n v_cndmask_b32_e64 v36,v37,14,vcc\n v_xor_b32 v26,v38,v39\n "
+                                 "v_cmp_eq_f64 vcc,|v[40:41]|,v[22:23]\n v_alignbit_b32 v25,v24,v26,31\n s_nop 0\n v_cndmask_b32_e32 v27,v28,v29,vcc\n v_cndmask_b32_e32 v30,v31,v32,vcc\n v_and_or_b32 v43,v26,s20,v27\n v_add_f64 v[44:45],v[40:41],v[42:43]\n v_cndmask_b32_e64 v37,v36,13,vcc\n v_xor_b32 v26,v38,v21\n ")
 
 typedef void (*kern_t)(unsigned long long*, double*, int);
 struct Case { const char* name; kern_t k; int per_iter; };
@@ -105,6 +140,9 @@ int main(int argc, char** argv) {
       C(mov_b64, 32), C(ds_read_b64, 32), C(ds_write_b64, 32), C(cndmask_vcc, 32), C(cndmask_sgpr, 32), C(and_or_b32, 32),
       C(xor_b32, 32), C(alignbit_b32, 32), C(add_u32, 32), C(cmp_eq_u32_vcc, 32), C(cmp_eq_u32_sgpr, 32), C(bfi_b32, 32),
       C(cmp_then_cndmask, 32), C(cndmask_e64_vcc, 32), C(cmpvcc_cndmask_e32, 32), C(cmpvcc_2cndmask_e32, 32), C(cndmask_e32_mix, 32),
+      C(dep_add_f64, 32), C(dep2_add_f64, 32), C(dep4_add_f64, 32), C(dep_xor_b32, 32), C(dep_and_or_b32, 32), C(dep_cndmask_sgpr, 32),
+      C(dep_cmp_cnd_andor, 24), C(add_f64_samebank, 32), C(add_f64_diffbank, 32), C(cnd_e32_samebank, 32), C(cnd_e32_diffbank, 32),
+      C(andor_samebank, 32), C(andor_diffbank, 32), C(mix_f64_vop2, 32), C(mix_f64_vop3, 32), C(mix_pass2_edge, 64),
   };
   printf("%-20s %8s %8s %8s %8s   cycles per wave64 instruction per SIMD at W waves/SIMD\n", "op", "W=1", "W=2", "W=3", "W=4");
   for (auto& c : cases) {
