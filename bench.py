@@ -319,7 +319,14 @@ def main():
                                  "HBM fraction is small by construction; its real bound is VALU issue (see valu_issue)",
                          "edge_visits_per_s": ev_s,
                          "valu_issue": {"bound": "valu", "cycles_per_wave_edge_visit": cyc, "bound_edge_visits_per_s": valu_bound,
-                                        "frac": ev_s / valu_bound}},
+                                        "frac": ev_s / valu_bound,
+                                        "all_instructions": None if not f64 else {
+                                            "instr_per_wave_edge_visit": 23.7, "cycles_per_instr": 3.0,
+                                            "frac": ev_s / (1024 * 64 * 2.4e9 / (23.7 * 3.0)),
+                                            "note": "every instruction of the loop (VALU 19.4, LDS 1.9, waits/nops 1.5, scalar 0.9 per "
+                                                    "edge-visit) at the ~3.0 cycles a float64/VOP3-carrying stream issues at with three "
+                                                    "waves per SIMD (profiles/r2_f64_issue_rates.txt); timing ablations without LDS "
+                                                    "instructions and without barriers are not faster (DESIGN 4.1c)"}}},
             "env": {k: v for k, v in os.environ.items() if k.startswith('NRX_')},
         }
         if not args.stub and world == 1 and not args.no_fast and f64:
