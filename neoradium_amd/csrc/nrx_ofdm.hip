@@ -7,6 +7,13 @@
 #include "nrx_fft.h"
 #include "nrx_rng.h"
 
+// Threads of a symbol-parallel modulator workgroup.  The radix-16 passes of a 4096-point transform occupy 256 of them;
+// the others double the loads / stores in flight of the fill and write-out phases, which is where this kernel's time goes
+// (two 68 KB workgroups per CU: 8 waves cannot cover the HBM latency of the gathers, 16 do better).
+#ifndef NRX_MOD_THREADS
+#define NRX_MOD_THREADS 512
+#endif
+
 namespace {
 using nrx::cx;
 
@@ -100,7 +107,7 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
 
 // One FFT per (item, antenna, symbol); workgroups loop over tasks so the twiddle table is built once.
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256)   // (512 threads as in the modulator need <= 128 VGPRs here: spills, 0.96 -> 1.01 ms)
 ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t wave_len,
                   const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
                   cx<T>* __restrict__ grid, int n_tasks, const cx<double>* __restrict__ tw,
@@ -145,7 +152,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
 // place and parks its windowed tail in `tails`; ofdm_tail_add_kernel then adds tail l onto head l+1 (head + tail, the
 // order of the sequential kernel, so both produce identical samples).
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(NRX_MOD_THREADS)
 ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
                     cx<T>* __restrict__ wave, int64_t wave_stride, const cx<T>* __restrict__ f, int64_t f_stride, int nl,
                     int ports, const cx<double>* __restrict__ tw, cx<T>* __restrict__ tails, int xcd_pairs) {
@@ -277,7 +284,7 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
     // precoded: XCD-aware placement of the ports of an (item, symbol) pair (see the kernel)
     const int pairs = f ? (n_rows / ports) * n_sym : 0;
     const int n_wg = f ? ((pairs + 7) / 8) * 8 * ports : n_rows * n_sym;
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NRX_MOD_THREADS), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
                        ilog2(nfft), g, window_len, slot_len, (cx<T>*)wave, wave_stride, (const cx<T>*)f, f_stride, nl,
                        ports, tw, (cx<T>*)tails, pairs);
     if (window_len > 0) {
