@@ -184,13 +184,16 @@ int32_t nrx_qam_map_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t*
  * item's bit stream (the INVERSE of the layer/RE map nrx_qam_map_* scatters through; requires every data RE of the
  * allocation to be covered by this one bit stream, i.e. one codeword); re_inv[e] < 0: templ[templ_sel[b]][e] (DMRS, empty
  * REs; templ (n_templ, elems), templ_sel (n_batch,) int64 = slot number in frame).  Same values as copying the template
- * and calling nrx_qam_map_*. */
+ * and calling nrx_qam_map_*.  planes (0 or 1: nothing assumed): a promise about the map, checked by the caller -- the grid is
+ * `planes` layers of elems/planes elements and wherever re_inv[e] >= 0 in the first plane, plane p holds symbol
+ * re_inv[e] + p at the same position (the layer mapping of TS 38.211 7.3.1.3, pdsch.py:528-551), negative entries
+ * coinciding; lets one thread fetch the contiguous bits of all layers of an RE. */
 int32_t nrx_pdsch_populate_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv,
                                const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch,
-                               void* stream);
+                               int32_t planes, void* stream);
 int32_t nrx_pdsch_populate_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv,
                                const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch,
-                               void* stream);
+                               int32_t planes, void* stream);
 
 /* modulation.py:159-204 getLLRsFromSymbols fused with pdsch.py:935-1005 getLLRsFromGrid (gather at re_index,
  * noise floor, descrambling pdsch.py:611-616, llrScale weighting).  exact=0: max-log (useMax=True), 1: log-sum-exp.

@@ -55,7 +55,7 @@ _i32p = C.POINTER(i32)
 for _t in ('f32', 'f64'):
     SIGNATURES.update({
         'nrx_qam_map_' + _t: (i32, [vp, i64, vp, i32, vp, i32, vp, i64, i32, vp]),
-        'nrx_pdsch_populate_' + _t: (i32, [vp, i64, vp, i32, vp, vp, vp, i64, vp, i32, vp]),
+        'nrx_pdsch_populate_' + _t: (i32, [vp, i64, vp, i32, vp, vp, vp, i64, vp, i32, i32, vp]),
         'nrx_precode_' + _t: (i32, [vp, vp, i64, i32, i32, i32, vp, i32, vp]),
         'nrx_apply_channel_fd_' + _t: (i32, [vp, vp, i64, i32, i32, i32, vp, i32, vp]),
         'nrx_mmse_equalize_' + _t: (i32, [vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, i32, vp]),

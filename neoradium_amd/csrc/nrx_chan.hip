@@ -57,6 +57,7 @@ cir_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff, int n
     const int l = (int)(g - row * cl);
     const cd* gr = gains + (size_t)row * n_p;
     cd acc(0, 0);
+#pragma unroll 8      // (eight (gain, coefficient) pairs in flight: the serial load-use chain was this kernel's time)
     for (int p = 0; p < n_p; ++p) {
       const double c = coeff[(size_t)p * cl + l];
       acc.re += gr[p].re * c;
@@ -78,9 +79,20 @@ chan_offset_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int nr, in
   for (int l = threadIdx.x; l < cl; l += blockDim.x) {
     double tot = 0;
     for (int r = 0; r < nr; ++r) {
+      // (same left-to-right sum as before; the loads of a whole instant are issued together -- one dependent load per
+      //  term made this one-workgroup-per-item kernel pure latency, 0.29 ms per 256 slots)
       cd s(0, 0);
-      for (int c = 0; c < nc; ++c)
-        for (int t = 0; t < nt; ++t) s = s + base[(((size_t)c * nr + r) * nt + t) * cl + l];
+#pragma unroll 2
+      for (int c = 0; c < nc; ++c) {
+        const cd* row = base + (((size_t)c * nr + r) * nt) * cl + l;
+        cd v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = t < nt ? row[(size_t)t * cl] : cd(0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t < nt) s = s + v[t];
+        for (int t = 8; t < nt; ++t) s = s + row[(size_t)t * cl];
+      }
       tot += hypot(s.re, s.im);
     }
     if (tot > bv) { bv = tot; bi = l; }
@@ -483,6 +495,7 @@ chan_matrix_sub_kernel(const cd* __restrict__ cir, int n_t_total, int nc, int n_
     const int o = off[b];
     const int use = cl < nfft ? cl : nfft;
     cd acc(0, 0);
+#pragma unroll 4      // (four taps and their twiddles in flight; one wave per impulse response with a cross-lane sum was slower)
     for (int l = 0; l < use; ++l) {
       const int pos = (l - o + nfft) & (nfft - 1);
       const int ph = (int)(((int64_t)bin * pos) & (nfft - 1));

@@ -134,6 +134,50 @@ pdsch_populate_q_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, c
   }
 }
 
+// ... and with the layer structure of the map known (TS 38.211 7.3.1.3: symbol i goes to layer i mod P, so the P planes of
+// the grid hold symbols i, i+1, .., i+P-1 at the same (symbol, subcarrier)): one thread per RE position fetches the
+// P*QM contiguous bit bytes once (aligned 16-bit words, neighbouring threads read neighbouring bytes) and writes its P
+// planes -- the per-element form gathers QM bytes out of every P*QM.  `planes` is checked against the map by the caller.
+template <typename T, int QM, int PL>
+__global__ void __launch_bounds__(256)
+pdsch_populate_qp_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, const uint8_t* __restrict__ scr, double scale,
+                         const int32_t* __restrict__ re_inv, const cx<T>* __restrict__ templ,
+                         const int64_t* __restrict__ templ_sel, int64_t elems, cx<T>* __restrict__ out, int n_batch) {
+  constexpr int h = QM / 2;
+  const int b = blockIdx.y;
+  const int lk = (int)(elems / PL);                      // elements of one plane
+  const cx<T>* tb = templ + (size_t)templ_sel[b] * elems;
+  const uint8_t* bb = bits + (size_t)b * bits_stride;
+  cx<T>* ob = out + (size_t)b * elems;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < lk; e += gridDim.x * blockDim.x) {
+    const int i = re_inv[e];
+    if (i < 0) {
+#pragma unroll
+      for (int p = 0; p < PL; ++p) ob[(size_t)p * lk + e] = tb[(size_t)p * lk + e];
+      continue;
+    }
+    const uint16_t* src = (const uint16_t*)(bb + (size_t)i * QM);
+    const uint16_t* sc = scr ? (const uint16_t*)(scr + (size_t)i * QM) : nullptr;
+    uint32_t w[PL * h];
+#pragma unroll
+    for (int k = 0; k < PL * h; ++k) w[k] = src[k];
+    if (sc) {
+#pragma unroll
+      for (int k = 0; k < PL * h; ++k) w[k] ^= sc[k];     // pdsch.py:603-608
+    }
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+      uint32_t rb = 0, ib = 0;
+#pragma unroll
+      for (int k = 0; k < h; ++k) {
+        rb = (rb << 1) | (w[p * h + k] & 1u);
+        ib = (ib << 1) | ((w[p * h + k] >> 8) & 1u);
+      }
+      ob[(size_t)p * lk + e] = cx<T>((T)((double)pam_level(rb, h) * scale), (T)((double)pam_level(ib, h) * scale));
+    }
+  }
+}
+
 // Max-log LLRs (useMax=True, the reference default).  The exhaustive max over the 2^qm points of
 // -|y-s|^2/s2 separates per axis for square QAM: bits on the real axis only see (Re y - a)^2 because the
 // imaginary-axis minimum is common to both hypotheses and cancels in the difference.
@@ -296,7 +340,8 @@ int32_t map_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, 
 
 template <typename T>
 int32_t populate_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv,
-                       const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) {
+                       const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, int32_t planes,
+                       void* stream) {
   NRX_REQUIRE(bits && re_inv && templ && templ_sel && out, NRX_E_ARG, "nrx_pdsch_populate: NULL buffer");
   NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_pdsch_populate: unsupported modulation order %d", qm);
   NRX_REQUIRE(elems >= 0 && elems < (1ll << 31) && n_batch >= 0 && n_batch < 65536 && bits_stride >= 0, NRX_E_SHAPE, "nrx_pdsch_populate: bad sizes");
@@ -304,6 +349,20 @@ int32_t populate_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* 
   int gx = (int)((elems + 255) / 256);
   if (gx > 64) gx = 64;
   const bool aligned = (((uintptr_t)bits | (uintptr_t)scr | (uintptr_t)bits_stride) & 1) == 0;
+  NRX_REQUIRE(planes >= 0 && (planes <= 1 || elems % planes == 0), NRX_E_ARG, "nrx_pdsch_populate: %d planes do not divide the grid", planes);
+  if (aligned && qm == 6 && (planes == 2 || planes == 4)) {     // the layer-vector form (built where it is used: 64-QAM)
+    const int lk = (int)(elems / planes);
+    int gp = (lk + 255) / 256;
+    if (gp > 64) gp = 64;
+    if (planes == 4)
+      hipLaunchKernelGGL((pdsch_populate_qp_kernel<T, 6, 4>), dim3(gp, n_batch), dim3(256), 0, (hipStream_t)stream, bits,
+                         bits_stride, scr, qam_scale(6), re_inv, (const cx<T>*)templ, templ_sel, elems, (cx<T>*)out, n_batch);
+    else
+      hipLaunchKernelGGL((pdsch_populate_qp_kernel<T, 6, 2>), dim3(gp, n_batch), dim3(256), 0, (hipStream_t)stream, bits,
+                         bits_stride, scr, qam_scale(6), re_inv, (const cx<T>*)templ, templ_sel, elems, (cx<T>*)out, n_batch);
+    NRX_CHECK_LAUNCH("nrx_pdsch_populate");
+    return NRX_OK;
+  }
 #define NRX_POP_CASE(Q)                                                                                                    \
   case Q:                                                                                                                  \
     hipLaunchKernelGGL((pdsch_populate_q_kernel<T, Q>), dim3(gx, n_batch), dim3(256), 0, (hipStream_t)stream, bits,        \
@@ -405,5 +464,5 @@ NRX_DEMAP_CB(nrx_qam_demap_cb_f32, float, float)
 NRX_DEMAP_CB(nrx_qam_demap_cb_f64, double, double)
 NRX_DEMAP_CB(nrx_qam_demap_cb_f64o32, double, float)
 
-extern "C" int32_t nrx_pdsch_populate_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) { return populate_entry<float>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, stream); }
-extern "C" int32_t nrx_pdsch_populate_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, void* stream) { return populate_entry<double>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, stream); }
+extern "C" int32_t nrx_pdsch_populate_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, int32_t planes, void* stream) { return populate_entry<float>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, planes, stream); }
+extern "C" int32_t nrx_pdsch_populate_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, int32_t planes, void* stream) { return populate_entry<double>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, planes, stream); }
