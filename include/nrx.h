@@ -466,8 +466,9 @@ int32_t nrx_effective_channel_prg_f64(const void* H, const void* F, int64_t f_st
                                       void* stream);
 
 /* nrx_chest_ls_f64 + nrx_mmse_equalize_f64 in one call without materialising the (L, K, Nr, P) estimate (at most two
- * DMRS time groups): hk_ws is caller-owned scratch of n_batch * (n_ds/l_cdm) * K * nr * P complex128; eq (n,P,L,K)
- * complex128, scale (n,P,L,K) float64.  Results are identical to the two separate calls. */
+ * DMRS time groups): hk_ws is caller-owned scratch of n_batch * (n_ds/l_cdm) * (K + n_k/k_cdm) * nr * P complex128 (the
+ * estimates at the DMRS time groups, then the CDM-group means they are interpolated from); eq (n,P,L,K) complex128,
+ * scale (n,P,L,K) float64.  Results are identical to the two separate calls. */
 int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
                               const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
                               int32_t K, int32_t nr, int32_t P, const double* noise_var, int32_t nv_stride, void* hk_ws,

@@ -23,7 +23,10 @@ struct ChestGeom {
 // POLAR: the CDM-group estimates come as (unwrapped angle, magnitude) pairs from chest_polar_prep_kernel +
 // chest_unwrap_kernel (`pol`, [row = ((b*n_g + tg)*nr + r)*P + p][j][2]); angle and magnitude are inter/extrapolated
 // separately along the subcarriers (utils.py:38-42 polarInterpolate), the symbol axis stays complex-linear.
-template <typename T, bool POLAR>
+// MEANS: the CDM-group means come precomputed from chest_polar_prep_kernel<false> (`pol`, same row layout, (re, im) pairs)
+// instead of being re-derived by every lane -- each mean is used by the ~2*k_cdm*spacing subcarriers around it and costs
+// l_cdm*k_cdm complex divisions; same operations in the same order, so the estimate is bit-identical.
+template <typename T, bool POLAR, bool MEANS = false>
 __global__ void __launch_bounds__(256)
 chest_ls_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ pilots, const int32_t* __restrict__ pil_set,
                 const int32_t* __restrict__ port_ks, ChestGeom g, cx<T>* __restrict__ hest, int n_batch, int hk_only,
@@ -60,6 +63,10 @@ chest_ls_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ pilots, 
     cd hk[4];  // estimate at subcarrier k for each time group (n_g <= 4)
     for (int tg = 0; tg < n_g; ++tg) {
       auto group_mean = [&](int jj) {  // LS estimates rx/pilot averaged over the CDM group (grid.py:775-793)
+        if constexpr (MEANS) {
+          const double* q = pol + (((((size_t)b * n_g + tg) * g.nr + r) * g.P + p) * (size_t)n_j + jj) * 2;
+          return cd(q[0], q[1]);
+        }
         cd s(0, 0);
         for (int ll = 0; ll < g.l_cdm; ++ll) {
           const int di = tg * g.l_cdm + ll;
@@ -411,11 +418,17 @@ extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, con
   g.l_cdm = l_cdm; g.k_cdm = k_cdm; g.n_k = n_k; g.L = L; g.K = K; g.nr = nr; g.P = P;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid2(nrx::stream_grid((long)n_batch * K, 128));
+  // the CDM-group means live behind the per-time-group estimates in the workspace (see the header for its size)
+  const int n_j = n_k / k_cdm;
+  const int64_t mrows = (int64_t)n_batch * (n_ds / l_cdm) * nr * P;
+  double* means = (double*)((cd*)hk_ws + (size_t)n_batch * (n_ds / l_cdm) * K * nr * P);
 #define NRX_CM_CASE(NR, NL)                                                                                              \
   if (nr == NR && P == NL) {                                                                                             \
-    hipLaunchKernelGGL((chest_ls_kernel<double, false>), dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)),        \
+    hipLaunchKernelGGL(chest_polar_prep_kernel<false>, dim3(nrx::stream_grid(mrows * n_j, 256)), dim3(256), 0, st,        \
+                       (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, means, n_batch);                           \
+    hipLaunchKernelGGL((chest_ls_kernel<double, false, true>), dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)),  \
                        dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (cd*)hk_ws, n_batch, 1,  \
-                       (cd*)nullptr, (const double*)nullptr);                                                           \
+                       (cd*)nullptr, (const double*)means);                                                             \
     hipLaunchKernelGGL((mmse_interp_kernel<NR, NL>), grid2, dim3(128), 0, st, (const cd*)rx, (const cd*)hk_ws, g,        \
                        noise_var, nv_stride, (cd*)eq, scale, n_batch);                                                   \
     NRX_CHECK_LAUNCH("nrx_chest_ls_mmse");                                                                               \

@@ -786,7 +786,7 @@ def chest_ls_mmse(rx, pilots, port_ks, dmrs_syms, noise_var, l_cdm=1, k_cdm=2, p
     sets, P, nds, nk = pilots.shape
     n_g = nds // l_cdm
     nv = torch.as_tensor(noise_var, dtype=torch.float64, device=dev).reshape(-1).contiguous()
-    hk = torch.empty((n, n_g, K, nr, P), dtype=torch.complex128, device=dev)
+    hk = torch.empty((n * n_g * (K + nk // k_cdm) * nr * P,), dtype=torch.complex128, device=dev)   # estimates + CDM-group means
     eq = torch.empty((n, P, L, K), dtype=torch.complex128, device=dev)
     sc = torch.empty((n, P, L, K), dtype=torch.float64, device=dev)
     check(lib().nrx_chest_ls_mmse_f64(ptr(rx), ptr(pilots), ptr(pil_set), ptr(port_ks), _host_i32(dmrs_syms), nds, l_cdm,
