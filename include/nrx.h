@@ -77,8 +77,10 @@ int32_t nrx_ldpc_cb_lens(int32_t G, int32_t C, int32_t nl, int32_t qm, int32_t* 
 int32_t nrx_ldpc_segment(const uint8_t* tb, int32_t n_tb, int32_t A, int32_t add_tb_crc, const nrx_ldpc_cfg* cfg,
                          uint8_t* cbs, void* stream);
 
-/* ldpc.py:1033-1090 encode.  cbs: n_cb x K.  coded: n_cb x N (puncture!=0) or n_cb x (N+2Zc). */
-int32_t nrx_ldpc_encode(const uint8_t* cbs, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t puncture,
+/* ldpc.py:1033-1090 encode.  cbs: n_cb x K.  coded: n_cb x N (puncture!=0) or n_cb x (N+2Zc).
+ * n_rows: 0 = all; otherwise only the parity of the first n_rows (>= 4) base-graph rows is computed and written -- the
+ * columns from 22 + n_rows (BG1) / 10 + n_rows (BG2) on stay untouched: for a caller whose rate matching (rv 0) ends before them. */
+int32_t nrx_ldpc_encode(const uint8_t* cbs, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t puncture, int32_t n_rows,
                         uint8_t* coded, void* stream);
 
 /* ldpc.py:1093-1159 rateMatch (bit selection from the filler-free circular buffer at k0(rv), bit interleave,

@@ -35,7 +35,7 @@ SIGNATURES = {
     'nrx_ldpc_config': (i32, [i32, i32, _cfgp]),
     'nrx_ldpc_cb_lens': (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
     'nrx_ldpc_segment': (i32, [vp, i32, i32, i32, _cfgp, vp, vp]),
-    'nrx_ldpc_encode': (i32, [vp, i32, _cfgp, i32, vp, vp]),
+    'nrx_ldpc_encode': (i32, [vp, i32, _cfgp, i32, i32, vp, vp]),
     'nrx_ldpc_rate_match': (i32, [vp, i32, _cfgp, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_ldpc_rate_match_harq': (i32, [vp, i32, _cfgp, i32, i32, i32, vp, i32, vp, vp]),
     'nrx_ldpc_rate_recover_harq_f32': (i32, [vp, i32, i32, _cfgp, i32, i32, vp, vp, i32, vp, vp, vp]),

@@ -179,7 +179,7 @@ struct EncTab {
 
 template <int BG>
 __global__ void __launch_bounds__(ZMAX)
-encode_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __restrict__ coded, const EncTab tab) {
+encode_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __restrict__ coded, const EncTab tab, int n_rows) {
   constexpr int ROWS = BG == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
   constexpr int KB = BG == 1 ? 22 : 10;
   const int16_t* rs = BG == 1 ? kBg1RowStart : kBg2RowStart;
@@ -233,7 +233,7 @@ encode_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __
     for (int q = 0; q < 4; ++q) out[(KB + q - skip) * zc + z] = w[(KB + q) * ZMAX + z];
   // extension parities: ldpc.py:1083-1084
   if (act)
-    for (int r = 4; r < ROWS; ++r) {
+    for (int r = 4; r < n_rows; ++r) {
       uint8_t v = 0;
       for (int e = rs[r]; e < rs[r + 1]; ++e) {
         const int c = cl[e];
@@ -249,7 +249,8 @@ encode_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __
 // only part that touches memory: bytes -> words with wave ballots, words -> bytes with a 4-bits-per-store expansion.
 template <int BG>
 __global__ void __launch_bounds__(64)
-encode_packed_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __restrict__ coded, const EncTab tab) {
+encode_packed_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint8_t* __restrict__ coded, const EncTab tab,
+                     int n_rows) {   // parity of base-graph rows < n_rows only (the others are not transmitted at this rate)
   constexpr int ROWS = BG == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
   constexpr int KB = BG == 1 ? 22 : 10;
   constexpr int NWMAX = ZMAX / 32;
@@ -319,7 +320,7 @@ encode_packed_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint
     __syncthreads();
   }
   // ---- extension parities (ldpc.py:1083-1084): items (row, word) over the wave
-  for (int it = lane; it < (ROWS - 4) * nw; it += 64) {
+  for (int it = lane; it < (n_rows - 4) * nw; it += 64) {
     const int r = 4 + it / nw, j = it - (r - 4) * nw;
     uint32_t v = 0;
     for (int e = rs[r]; e < rs[r + 1]; ++e) {
@@ -331,7 +332,7 @@ encode_packed_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint
   __syncthreads();
   // ---- unpack: 4 bits -> 4 bytes per store (nibble * 0x00204081 puts bit k at bit 8k)
   const int quads = zc >> 2;                                // 4-byte stores per column
-  for (int it = lane; it < (ncols - skip) * quads; it += 64) {
+  for (int it = lane; it < (KB + n_rows - skip) * quads; it += 64) {
     const int c = it / quads + skip, qd = it - (c - skip) * quads;
     const uint32_t nib = (W[c * NWMAX + (qd >> 3)] >> ((qd & 7) * 4)) & 15u;
     *reinterpret_cast<uint32_t*>(out + (size_t)(c - skip) * zc + 4 * qd) = (nib * 0x00204081u) & 0x01010101u;
@@ -614,11 +615,14 @@ extern "C" int32_t nrx_ldpc_segment(const uint8_t* tb, int32_t n_tb, int32_t A, 
 }
 
 extern "C" int32_t nrx_ldpc_encode(const uint8_t* cbs, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t puncture,
-                                   uint8_t* coded, void* stream) {
+                                   int32_t n_rows, uint8_t* coded, void* stream) {
   NRX_REQUIRE(cbs && cfg && coded, NRX_E_ARG, "nrx_ldpc_encode: NULL buffer");
   NRX_REQUIRE(cfg->bg == 1 || cfg->bg == 2, NRX_E_ARG, "nrx_ldpc_encode: bg must be 1|2");
   NRX_REQUIRE(cfg->Zc >= 2 && cfg->Zc <= ZMAX && cfg->iLS >= 0 && cfg->iLS < 8, NRX_E_ARG, "nrx_ldpc_encode: bad Zc/iLS");
   NRX_REQUIRE(n_cb >= 0, NRX_E_ARG, "nrx_ldpc_encode: negative count");
+  const int rows_all = cfg->bg == 1 ? NRX_BG1_ROWS : NRX_BG2_ROWS;
+  NRX_REQUIRE(n_rows == 0 || (n_rows >= 4 && n_rows <= rows_all), NRX_E_ARG, "nrx_ldpc_encode: n_rows must be 0 (all) or 4..%d", rows_all);
+  if (n_rows == 0) n_rows = rows_all;
   if (n_cb == 0) return NRX_OK;
   EncTab tab;
   memset(&tab, 0, sizeof(tab));
@@ -629,16 +633,16 @@ extern "C" int32_t nrx_ldpc_encode(const uint8_t* cbs, int32_t n_cb, const nrx_l
   // output rows are (N or N+2Zc) bytes apart: 4-byte stores need that, and the buffer itself, 4-byte aligned
   if (cfg->Zc % 32 == 0 && ((uintptr_t)coded & 3u) == 0) {
     if (cfg->bg == 1)
-      hipLaunchKernelGGL(encode_packed_kernel<1>, dim3(n_cb), dim3(64), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+      hipLaunchKernelGGL(encode_packed_kernel<1>, dim3(n_cb), dim3(64), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab, n_rows);
     else
-      hipLaunchKernelGGL(encode_packed_kernel<2>, dim3(n_cb), dim3(64), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+      hipLaunchKernelGGL(encode_packed_kernel<2>, dim3(n_cb), dim3(64), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab, n_rows);
     NRX_CHECK_LAUNCH("nrx_ldpc_encode");
     return NRX_OK;
   }
   if (cfg->bg == 1)
-    hipLaunchKernelGGL(encode_kernel<1>, dim3(n_cb), dim3(threads), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+    hipLaunchKernelGGL(encode_kernel<1>, dim3(n_cb), dim3(threads), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab, n_rows);
   else
-    hipLaunchKernelGGL(encode_kernel<2>, dim3(n_cb), dim3(threads), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab);
+    hipLaunchKernelGGL(encode_kernel<2>, dim3(n_cb), dim3(threads), 0, (hipStream_t)stream, cbs, cfg->Zc, puncture, coded, tab, n_rows);
   NRX_CHECK_LAUNCH("nrx_ldpc_encode");
   return NRX_OK;
 }

@@ -283,7 +283,8 @@ class PdschLink:
             else:
                 tb = (tb_bits[q] if self.numCW > 1 else tb_bits).to(dev).to(torch.uint8).contiguous()
             tbs_in.append(tb)
-            coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'])
+            # (first transmissions send nothing beyond the columns of the active rows: their parity is not computed)
+            coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'], rows=cw['rows'] if harq is None else None)
             bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[0])
             if grid is None:    # one codeword: template + scramble + modulate + layer/RE map in one pass over the grid
                 grid = ops.pdsch_populate(bits, cw['qm'], cw['scr'], self.re_inv, self.templates, sif)

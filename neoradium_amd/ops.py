@@ -55,14 +55,16 @@ def ldpc_segment(tb, cfg, add_tb_crc=True):
     return cbs
 
 
-def ldpc_encode(cbs, cfg, puncture=True):
-    """ldpc.py:1033-1090 encode: (n_cb, K) -> (n_cb, N) (or N+2Zc without puncturing)."""
+def ldpc_encode(cbs, cfg, puncture=True, rows=None):
+    """ldpc.py:1033-1090 encode: (n_cb, K) -> (n_cb, N) (or N+2Zc without puncturing).  ``rows``: only the parity of the
+    first ``rows`` base-graph rows is produced (columns >= 22 + rows (BG1) / 10 + rows (BG2) of the output stay unwritten): for a
+    caller that rate-matches rv 0 into fewer bits than that (``ldpc_active_rows``)."""
     cbs = _u8(cbs)
     if cbs.dim() != 2 or cbs.shape[1] != cfg.K:
         raise ValueError(f"code blocks must be (n_cb, K={cfg.K}), got {tuple(cbs.shape)}")
     width = cfg.N if puncture else cfg.N + 2 * cfg.Zc
     out = torch.empty((cbs.shape[0], width), dtype=torch.uint8, device=_dev(cbs))
-    check(lib().nrx_ldpc_encode(ptr(cbs), cbs.shape[0], C.byref(cfg), 1 if puncture else 0, ptr(out), stream()))
+    check(lib().nrx_ldpc_encode(ptr(cbs), cbs.shape[0], C.byref(cfg), 1 if puncture else 0, int(rows or 0), ptr(out), stream()))
     return out
 
 
