@@ -51,19 +51,20 @@ cdl_gains_kernel(const cd* __restrict__ A, const double* __restrict__ nu, const 
 __global__ void __launch_bounds__(256)
 cir_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff, int n_p, int cl, int64_t n_rows,
            cd* __restrict__ cir) {
-  const int64_t total = n_rows * cl;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = g / cl;
-    const int l = (int)(g - row * cl);
+  // one workgroup per (item, instant, rx, tx) row at a time: no 64-bit division per element, the row's gains are
+  // wave-uniform loads
+  for (int64_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
     const cd* gr = gains + (size_t)row * n_p;
-    cd acc(0, 0);
+    for (int l = threadIdx.x; l < cl; l += blockDim.x) {
+      cd acc(0, 0);
 #pragma unroll 8      // (eight (gain, coefficient) pairs in flight: the serial load-use chain was this kernel's time)
-    for (int p = 0; p < n_p; ++p) {
-      const double c = coeff[(size_t)p * cl + l];
-      acc.re += gr[p].re * c;
-      acc.im += gr[p].im * c;
+      for (int p = 0; p < n_p; ++p) {
+        const double c = coeff[(size_t)p * cl + l];
+        acc.re += gr[p].re * c;
+        acc.im += gr[p].im * c;
+      }
+      cir[(size_t)row * cl + l] = acc;
     }
-    cir[g] = acc;
   }
 }
 
@@ -402,7 +403,7 @@ extern "C" int32_t nrx_cir_f64(const void* gains, const double* coeff, int32_t n
   if (n_items == 0) return NRX_OK;
   const int64_t rows = (int64_t)n_items * n_t * n_rx * n_tx;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(cir_kernel, dim3(nrx::stream_grid(rows * cl, 256)), dim3(256), 0, st, (const cd*)gains, coeff,
+  hipLaunchKernelGGL(cir_kernel, dim3((unsigned)(rows < (1 << 20) ? rows : (1 << 20))), dim3(256), 0, st, (const cd*)gains, coeff,
                      n_paths, cl, rows, (cd*)cir);
   if (chan_offset)
     hipLaunchKernelGGL(chan_offset_kernel, dim3(n_items), dim3(256), 0, st, (const cd*)cir, n_t, nc, n_rx, n_tx, cl,
