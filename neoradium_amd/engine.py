@@ -97,14 +97,15 @@ def gain_times(tables, slots):
 
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
-                 decoder="f32", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
+                 decoder="f64", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
                  skipPuncturedRows=True):
         if pdsch.dmrs is None:
             raise ValueError("PdschLink: the PDSCH needs a DMRS configuration (pdsch.setDMRS)")
         if chanEst not in ("LS", "Perfect"):
             raise ValueError("chanEst must be 'LS' or 'Perfect'")
         if decoder not in ("f32", "f64"):
-            raise ValueError("decoder must be 'f32' (throughput) or 'f64' (bit-exact with the reference arithmetic)")
+            raise ValueError("decoder must be 'f64' (the reference's arithmetic, default) or 'f32' (float32 LLRs and decoder: faster, "
+                             "CRC verdicts differ from the float64 chain on about 1 block in 1e3 at the waterfall)")
         self.dev = _device() if dev is None else dev
         self.pdsch, self.channel = pdsch, channel
         self.bwp = bwp = pdsch.bwp
