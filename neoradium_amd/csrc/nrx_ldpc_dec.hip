@@ -130,15 +130,21 @@ template <typename T> struct ExactWs {
   static constexpr size_t off_sg(int rows, int L) { return (size_t)3 * rows * ZMAX * sizeof(T) + (size_t)L * ZMAX * sizeof(uint32_t); }
 };
 
+// f64 (EXACT): the state lives in the workspace and TWO code blocks share a workgroup (LDS 2 x 80 KB, 12 waves = 3 per
+// SIMD).  As two 6-wave workgroups the second one is never co-scheduled -- the first lands 2,2,1,1 on the SIMDs and at
+// 168 VGPRs the dispatcher finds no room for another 2,2,1,1 (tools/ubench/occ_test.hip) -- so the kernel ran with half
+// the waves it was written for.
 template <typename T, int BG, bool EXACT>
-__global__ void __launch_bounds__(ZMAX, EXACT ? 3 : 1)   // f64: state in the workspace, two code blocks per CU (LDS 2 x 80 KB)
+__global__ void __launch_bounds__((EXACT ? 2 : 1) * ZMAX, EXACT ? 3 : 1)
 ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out_cols, int n_cols_in,
                 uint8_t* __restrict__ hard, T* __restrict__ belief, char* __restrict__ ws, int tab_off, int n_rows) {
   using G = BgT<BG>;
+  constexpr int NS = EXACT ? 2 : 1;                       // code blocks per workgroup (slots of whole waves)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* P = (T*)smem;  // [CORE][ZMAX]
-  const int z = threadIdx.x;
-  const bool active = z < zc;
+  const int tslot = (int)blockDim.x / NS;
+  const int slot = NS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / tslot);
+  T* P = (T*)smem + (size_t)slot * G::CORE * ZMAX;  // [CORE][ZMAX] per slot
+  const int z = (int)threadIdx.x - slot * tslot;
   const int N = n_cols_in * zc;  // (COLS-2)*zc
 
   // register-resident check-node state (f32 variant)
@@ -147,7 +153,7 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
   uint32_t sg[G::ROWS];   // (f64 too: 46 registers fit beside the 3-waves-per-SIMD budget and save 8 B per lane-layer)
   T ech[EXACT ? 1 : G::ROWS];  // channel LLR of the layer's degree-1 extension column, at (z+shift) mod Zc
   using W = ExactWs<T>;
-  char* const wsb = EXACT ? ws + (size_t)blockIdx.x * W::bytes(G::ROWS) : nullptr;   // this workgroup's workspace
+  char* const wsb = EXACT ? ws + ((size_t)blockIdx.x * NS + slot) * W::bytes(G::ROWS) : nullptr;   // this slot's workspace
   constexpr int R = G::ROWS;
   // explicit global address space: after the opaque copy of the base the compiler no longer infers it and would emit
   // FLAT accesses (both counters, waits of zero)
@@ -165,8 +171,10 @@ ldpc_dec_kernel(const T* __restrict__ llr, int n_cb, int zc, int n_iter, int out
     return (gT)(b + (size_t)lane_off);
   };
 
-  for (int cb = blockIdx.x; cb < n_cb; cb += gridDim.x) {
-    const T* in = llr + (size_t)cb * N;
+  for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
+    const int cb = cb0 + slot;
+    const bool active = z < zc && cb < n_cb;                // (a slot without a code block only keeps the barriers company)
+    const T* in = llr + (size_t)(cb < n_cb ? cb : 0) * N;
     // ---- load: clip, prepend the two punctured columns as zeros (ldpc.py:1536-1538)
     if (active) {
       static_for<G::CORE>([&](auto cc) __attribute__((always_inline)) {
@@ -376,16 +384,18 @@ template <typename T, int BG, bool EXACT>
 int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int out_cols, uint8_t* hard, T* belief,
                void* ws, size_t ws_bytes, hipStream_t st, int tab_off, int n_rows) {
   using G = BgT<BG>;
-  const int threads = ((cfg->Zc + 63) / 64) * 64;
-  int grid = n_cb < 512 ? n_cb : 512;
+  constexpr int NS = EXACT ? 2 : 1;
+  const int threads = NS * ((cfg->Zc + 63) / 64) * 64;
+  const int n_wg = (n_cb + NS - 1) / NS;
+  int grid = n_wg < 512 / NS ? n_wg : 512 / NS;
   if (EXACT) {
     const size_t per = ExactWs<T>::bytes(G::ROWS);
-    NRX_REQUIRE(ws != nullptr && ws_bytes >= per, NRX_E_ARG,
-                "nrx_ldpc_decode_f64: workspace of >= %zu bytes required", per);
-    const size_t fit = ws_bytes / per;
+    NRX_REQUIRE(ws != nullptr && ws_bytes >= NS * per, NRX_E_ARG,
+                "nrx_ldpc_decode_f64: workspace of >= %zu bytes required", NS * per);
+    const size_t fit = ws_bytes / (NS * per);
     if ((size_t)grid > fit) grid = (int)fit;
   }
-  const size_t lds = (size_t)G::CORE * ZMAX * sizeof(T);
+  const size_t lds = (size_t)NS * G::CORE * ZMAX * sizeof(T);
   auto kern = ldpc_dec_kernel<T, BG, EXACT>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // per device: every launch
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, llr, n_cb, cfg->Zc, n_iter, out_cols, G::COLS - 2,
