@@ -219,8 +219,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=256, help="slots per step per GPU (15 GB of device buffers at 256)")
     ap.add_argument('--snr', type=float, default=31.0)
     ap.add_argument('--decoder', default='f64', choices=['f32', 'f64'],
