@@ -59,6 +59,25 @@ __device__ __forceinline__ uint32_t dbl(uint32_t w) {   // w + w as an add the o
   return r;
 }
 
+#ifdef NRX_DEC3_PROBE
+// Developer build only (tools/probe_dec3.sh): s_memtime stamps at the phase boundaries of every layer, accumulated per
+// wave in SGPRs and summed here.  [0..3] wide layers (degree > 10), [4..7] narrow layers: pass 1 (LDS reads + t = r - m),
+// min-sum, pass 2 (+ write drain + next layer's mask loads), barrier; [8] waves, [9] layers stamped.
+__device__ unsigned long long g_probe[10];
+#define PROBE_STAMP(K)                                                                   \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    unsigned long long pt_;                                                              \
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pt_)::"memory");          \
+    const uint32_t lo_ = (uint32_t)pt_;                                                  \
+    if ((K) >= 0) pk_acc[(K)] += lo_ - pk_prev;                                          \
+    pk_prev = lo_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  } while (0)
+#else
+#define PROBE_STAMP(K) do {} while (0)
+#endif
+
 template <int BG> constexpr bool ext_shifts_are_zero() {
   using B = G<BG>;
   for (int ils = 0; ils < 8; ++ils)
@@ -163,6 +182,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
   uint32_t sgn[(Y::n_narrow() + 1) / 2];                   // two 16-bit fields per word
 
+#ifdef NRX_DEC3_PROBE
+  uint32_t pk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0;
+#endif
   for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
     const int cb = cb0 + slot;
     int one = 1;
@@ -233,6 +255,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       wcur[decltype(jc)::value] = wm[B::row_start(0) + decltype(jc)::value];
     });
 
+    PROBE_STAMP(-1);
     for (int it = 0; it < n_iter; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -249,6 +272,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         const uint32_t zb = zbo, zbw = zbo - zc8, zbh = zbo + HI, zbwh = zbo - zc8 + HI;
         if (__builtin_expect(live, 1)) {
           double t[D];
+#ifdef NRX_DEC3_PROBE
+          PROBE_STAMP((Y::wide((L + B::ROWS - 1) % B::ROWS) ? 3 : 7));   // barrier of the previous layer
+          pk_layers += 1;
+#endif
           // ---- pass 1a: issue every LDS read of the layer (last edge first: the order pass 1b consumes them in)
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = DC - 1 - decltype(jc)::value;
@@ -296,6 +323,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               wrun = wnext;
             });
           });
+          PROBE_STAMP(WIDE ? 0 : 4);
           // ---- min-sum (ldpc.py:1556-1564): two smallest magnitudes by min/max, sign parity by XOR of the sign words
           double a1 = __builtin_fabs(t[0]);
           double a2 = 3.0e38;
@@ -324,6 +352,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           const double nm1 = a1 * 0.75, nm2 = a2 * 0.75;     // ldpc.py:1573 (the scale commutes with the sign)
           m1[L] = nm1;
           m2[L] = nm2;
+          PROBE_STAMP(WIDE ? 1 : 5);
           // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written back to the element it was read from.  An entry
           // equal to min1 gets min2 (with ties min2 == min1, so every tied entry may take it); first such index = argmin.
           uint32_t nsg = 0, idx = 0;
@@ -368,6 +397,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
             wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
           });
+          PROBE_STAMP(WIDE ? 2 : 6);
         }
         if constexpr (Y::barrier_in_before((L + 1) % B::ROWS)) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);   // nothing migrates between layers (register pressure)
@@ -423,6 +453,13 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     }
     __syncthreads();
   }
+#ifdef NRX_DEC3_PROBE
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_probe[k], (unsigned long long)pk_acc[k]);
+    atomicAdd(&g_probe[8], 1ull);
+    atomicAdd(&g_probe[9], (unsigned long long)pk_layers);
+  }
+#endif
 }
 
 __constant__ WrapTab kWrap1_384_r13 = make_wrap<1, zindex_c(384), 13>();
@@ -523,3 +560,14 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t 
   NRX_CHECK_LAUNCH("nrx_ldpc_recover_decode_merge_f64");
   return NRX_OK;
 }
+
+#ifdef NRX_DEC3_PROBE
+extern "C" int32_t nrx_debug_dec3_probe(unsigned long long* out10, int32_t reset) {
+  if (out10 && hipMemcpyFromSymbol(out10, HIP_SYMBOL(nrx_dec3::g_probe), sizeof(unsigned long long) * 10) != hipSuccess) return NRX_E_HIP;
+  if (reset) {
+    const unsigned long long z[10] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(nrx_dec3::g_probe), z, sizeof(z)) != hipSuccess) return NRX_E_HIP;
+  }
+  return NRX_OK;
+}
+#endif

@@ -20,8 +20,8 @@
 
 // BODY runs `iters` times; registers v20..v51 hold finite doubles / small integers set up in front.
 #define DEF_FIXED(NAME, BODY)                                                                                   \
-  __global__ void k_##NAME(unsigned long long* cyc, unsigned* hwid, double* sink, int iters) {                  \
-    unsigned long long t0, t1;                                                                                  \
+  __global__ void k_##NAME(unsigned long long* cyc, unsigned long long* rt, unsigned* hwid, double* sink, int iters) {                  \
+    unsigned long long t0, t1, q0, q1;                                                                          \
     unsigned lane = threadIdx.x & 63u;                                                                          \
     asm volatile("v_and_b32 v48, 7, %0\n v_mov_b32 v49, 3\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0x3ff00000\n"    \
                  "v_cvt_f64_u32 v[20:21], %0\n v_cvt_f64_u32 v[22:23], %0\n v_cvt_f64_u32 v[24:25], %0\n"      \
@@ -31,14 +31,15 @@
                  "v_cvt_f64_u32 v[44:45], %0\n v_cvt_f64_u32 v[46:47], %0\n"                                   \
                  "s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x33333333\n s_mov_b64 s[24:25], 0\n s_mov_b64 s[26:27], 1\n" \
                  "s_mov_b32 s28, 0x80000000\n" ::"v"(lane) : CLOB);                                             \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");                                 \
+    asm volatile("s_memrealtime %1\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(q0)::"memory");   \
     for (int i = 0; i < iters; ++i) asm volatile(BODY ::: CLOB);                                                \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");         \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(q1)::"memory"); \
     unsigned hw, xcc;                                                                                           \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc)); \
     sink[blockIdx.x * blockDim.x + threadIdx.x] = 0.0;                                                          \
     if ((threadIdx.x & 63) == 0) {                                                                              \
       cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;                                         \
+      rt[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = q1 - q0;                                          \
       hwid[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = (hw & 0xffffffu) | (xcc << 24);                 \
     }                                                                                                           \
   }
@@ -108,6 +109,36 @@ DEF_FIXED(f64_salu2, ".rept 4\n" AS2("v[20:21]") AS2("v[22:23]") AS2("v[24:25]")
 // a masked v_mov_b32 (VOP1) and v_bcnt / v_lshl_or (per-row bookkeeping of the new scheme)
 DEF_FIXED(mov_b32, ".rept 4\n v_mov_b32 v20, 5\n v_mov_b32 v21, 5\n v_mov_b32 v22, 5\n v_mov_b32 v23, 5\n v_mov_b32 v24, 5\n v_mov_b32 v25, 5\n v_mov_b32 v26, 5\n v_mov_b32 v27, 5\n .endr\n")
 
+
+// ---- 4. straight-line (512 x 8 instructions, no loop bias) streams of ONE class, and two-class alternations
+#define SL(NAME, A8) DEF_FIXED(NAME, ".rept 512\n" A8 ".endr\n")
+SL(sl_fma64, FMA8)
+SL(sl_add64, "v_add_f64 v[20:21],v[20:21],v[40:41]\n v_add_f64 v[22:23],v[22:23],v[40:41]\n v_add_f64 v[24:25],v[24:25],v[40:41]\n v_add_f64 v[26:27],v[26:27],v[40:41]\n"
+             "v_add_f64 v[28:29],v[28:29],v[40:41]\n v_add_f64 v[30:31],v[30:31],v[40:41]\n v_add_f64 v[32:33],v[32:33],v[40:41]\n v_add_f64 v[34:35],v[34:35],v[40:41]\n")
+SL(sl_min64, "v_min_f64 v[20:21],v[20:21],v[40:41]\n v_max_f64 v[22:23],v[22:23],v[40:41]\n v_min_f64 v[24:25],v[24:25],v[40:41]\n v_max_f64 v[26:27],v[26:27],v[40:41]\n"
+             "v_min_f64 v[28:29],v[28:29],v[40:41]\n v_max_f64 v[30:31],v[30:31],v[40:41]\n v_min_f64 v[32:33],v[32:33],v[40:41]\n v_max_f64 v[34:35],v[34:35],v[40:41]\n")
+SL(sl_andor, "v_and_or_b32 v20,v36,v41,v42\n v_and_or_b32 v21,v36,v41,v42\n v_and_or_b32 v22,v36,v41,v42\n v_and_or_b32 v23,v36,v41,v42\n"
+             "v_and_or_b32 v24,v36,v41,v42\n v_and_or_b32 v25,v36,v41,v42\n v_and_or_b32 v26,v36,v41,v42\n v_and_or_b32 v27,v36,v41,v42\n")
+SL(sl_cnd64, "v_cndmask_b32_e64 v20,v37,v38,s[20:21]\n v_cndmask_b32_e64 v21,v37,v38,s[20:21]\n v_cndmask_b32_e64 v22,v37,v38,s[20:21]\n v_cndmask_b32_e64 v23,v37,v38,s[20:21]\n"
+             "v_cndmask_b32_e64 v24,v37,v38,s[20:21]\n v_cndmask_b32_e64 v25,v37,v38,s[20:21]\n v_cndmask_b32_e64 v26,v37,v38,s[20:21]\n v_cndmask_b32_e64 v27,v37,v38,s[20:21]\n")
+SL(sl_cmp64, "v_cmp_eq_f64 s[22:23],|v[20:21]|,v[40:41]\n v_cmp_eq_f64 s[24:25],|v[22:23]|,v[40:41]\n v_cmp_eq_f64 s[22:23],|v[24:25]|,v[40:41]\n v_cmp_eq_f64 s[24:25],|v[26:27]|,v[40:41]\n"
+             "v_cmp_eq_f64 s[22:23],|v[28:29]|,v[40:41]\n v_cmp_eq_f64 s[24:25],|v[30:31]|,v[40:41]\n v_cmp_eq_f64 s[22:23],|v[32:33]|,v[40:41]\n v_cmp_eq_f64 s[24:25],|v[34:35]|,v[40:41]\n")
+SL(sl_xor_add64, "v_xor_b32 v20,v20,v40\n v_add_f64 v[22:23],v[22:23],v[40:41]\n v_xor_b32 v21,v21,v40\n v_add_f64 v[24:25],v[24:25],v[40:41]\n"
+                 "v_xor_b32 v26,v26,v40\n v_add_f64 v[28:29],v[28:29],v[40:41]\n v_xor_b32 v27,v27,v40\n v_add_f64 v[30:31],v[30:31],v[40:41]\n")
+SL(sl_xor3_add64, "v_xor_b32 v20,v20,v40\n v_xor_b32 v21,v21,v40\n v_xor_b32 v26,v26,v40\n v_add_f64 v[22:23],v[22:23],v[40:41]\n"
+                  "v_xor_b32 v27,v27,v40\n v_xor_b32 v32,v32,v40\n v_xor_b32 v33,v33,v40\n v_add_f64 v[28:29],v[28:29],v[40:41]\n")
+SL(sl_add64_salu, "v_add_f64 v[20:21],v[20:21],v[40:41]\n s_or_b64 s[24:25], s[24:25], s[26:27]\n v_add_f64 v[22:23],v[22:23],v[40:41]\n s_or_b64 s[24:25], s[24:25], s[26:27]\n"
+                  "v_add_f64 v[24:25],v[24:25],v[40:41]\n s_or_b64 s[24:25], s[24:25], s[26:27]\n v_add_f64 v[26:27],v[26:27],v[40:41]\n s_or_b64 s[24:25], s[24:25], s[26:27]\n")
+SL(sl_add64_nop, "v_add_f64 v[20:21],v[20:21],v[40:41]\n s_nop 0\n v_add_f64 v[22:23],v[22:23],v[40:41]\n s_nop 0\n"
+                 "v_add_f64 v[24:25],v[24:25],v[40:41]\n s_nop 0\n v_add_f64 v[26:27],v[26:27],v[40:41]\n s_nop 0\n")
+SL(sl_dep_add64, "v_add_f64 v[20:21],v[20:21],v[40:41]\n v_add_f64 v[20:21],v[20:21],v[40:41]\n v_add_f64 v[20:21],v[20:21],v[40:41]\n v_add_f64 v[20:21],v[20:21],v[40:41]\n"
+                 "v_add_f64 v[20:21],v[20:21],v[40:41]\n v_add_f64 v[20:21],v[20:21],v[40:41]\n v_add_f64 v[20:21],v[20:21],v[40:41]\n v_add_f64 v[20:21],v[20:21],v[40:41]\n")
+SL(sl_dep_chain, "v_cndmask_b32_e64 v44,v40,v42,s[20:21]\n v_cndmask_b32_e64 v45,v41,v43,s[20:21]\n v_and_or_b32 v45,v32,s28,v45\n v_add_f64 v[20:21],v[20:21],v[44:45]\n"
+                 "v_cndmask_b32_e64 v46,v40,v42,s[20:21]\n v_cndmask_b32_e64 v47,v41,v43,s[20:21]\n v_and_or_b32 v47,v33,s28,v47\n v_add_f64 v[22:23],v[22:23],v[46:47]\n")
+SL(sl_hi_regs, "v_add_f64 v[20:21],v[24:25],v[30:31]\n v_and_or_b32 v32,v36,v41,v42\n v_min_f64 v[22:23],v[26:27],v[28:29]\n"
+               "v_alignbit_b32 v33,v37,v42,31\n v_max_f64 v[34:35],v[38:39],v[40:41]\n v_and_or_b32 v43,v44,v45,v46\n"
+               "v_add_f64 v[46:47],v[24:25],v[28:29]\n v_cndmask_b32_e64 v36,v37,v38,s[20:21]\n")
+
 // clock check: s_memtime against s_memrealtime (100 MHz)
 __global__ void k_clock(unsigned long long* out, int iters) {
   unsigned long long t0, t1, r0, r1;
@@ -119,7 +150,7 @@ __global__ void k_clock(unsigned long long* out, int iters) {
   if (a == 12345.678) out[2] = 1;
 }
 
-typedef void (*kern_t)(unsigned long long*, unsigned*, double*, int);
+typedef void (*kern_t)(unsigned long long*, unsigned long long*, unsigned*, double*, int);
 struct Case { const char* name; kern_t k; int per_iter; int unit; const char* what; };
 
 int main(int argc, char** argv) {
@@ -129,9 +160,11 @@ int main(int argc, char** argv) {
   printf("device %s, %d CUs, clock %d kHz\n", p.name, ncu, p.clockRate);
   unsigned long long* cyc;
   unsigned* hwid;
+  unsigned long long* rt;
   double* sink;
   hipMalloc(&cyc, sizeof(unsigned long long) * ncu * 64);
   hipMalloc(&hwid, sizeof(unsigned) * ncu * 64);
+  hipMalloc(&rt, sizeof(unsigned long long) * ncu * 64);
   hipMalloc(&sink, sizeof(double) * ncu * 1024);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -153,19 +186,24 @@ int main(int argc, char** argv) {
       C(sel_cnd, 8, 8, "per edge: cmp + unit + 2 cndmask + add_f64"), C(sel_exec, 8, 8, "per edge: cmp + unit + 2 fma under EXEC/~EXEC"),
       C(sel_exec2, 8, 8, "per edge: cmp + unit + fma + masked fma + mov_b64"), C(sel_exec3, 8, 8, "per edge: 8 cmps batched + unit + 2 masked fma"),
       C(f64_salu0, 32, 1, "add_f64"), C(f64_salu1, 32, 1, "add_f64 + 1 SALU"), C(f64_salu2, 32, 1, "add_f64 + 2 SALU"), C(mov_b32, 32, 1, "v_mov_b32 imm"),
+      C(sl_fma64, 4096, 1, "straight-line v_fma_f64"), C(sl_add64, 4096, 1, "straight-line v_add_f64"), C(sl_min64, 4096, 1, "straight-line v_min/max_f64"),
+      C(sl_andor, 4096, 1, "straight-line v_and_or_b32"), C(sl_cnd64, 4096, 1, "straight-line v_cndmask_e64 sgpr"), C(sl_cmp64, 4096, 1, "straight-line v_cmp_eq_f64 -> sgpr"),
+      C(sl_xor_add64, 4096, 1, "straight-line xor / add_f64 alternating"), C(sl_xor3_add64, 4096, 1, "straight-line 3 xor : 1 add_f64"),
+      C(sl_add64_salu, 4096, 1, "straight-line add_f64 / s_or alternating (per instruction)"), C(sl_add64_nop, 4096, 1, "straight-line add_f64 / s_nop alternating"),
+      C(sl_dep_add64, 4096, 1, "straight-line dependent add_f64 chain"), C(sl_dep_chain, 4096, 1, "straight-line 2cnd->and_or->add_f64 chains"),
   };
   printf("%-12s %8s %8s %8s %8s   cycles (s_memtime) per unit per SIMD at W waves/SIMD | wall-clock at W=3\n", "case", "W=1", "W=2", "W=3", "W=4");
   for (auto& c : cases) {
     printf("%-12s", c.name);
-    double wall3 = 0;
+    double wall3 = 0, mhz3 = 0;
     size_t ncu_seen = 0;
     const long total = 4L * 1024 * 1024;                 // instructions (units) per wave
     const int iters = (int)(total / c.per_iter / (c.unit == 8 ? 6 : 1));   // (an 'edge' unit is ~6 instructions)
     for (int W = 1; W <= 4; ++W) {
       const int threads = 256 * W;
-      hipLaunchKernelGGL(c.k, dim3(ncu), dim3(threads), 0, 0, cyc, hwid, sink, 2);
+      hipLaunchKernelGGL(c.k, dim3(ncu), dim3(threads), 0, 0, cyc, rt, hwid, sink, 2);
       hipEventRecord(e0, 0);
-      hipLaunchKernelGGL(c.k, dim3(ncu), dim3(threads), 0, 0, cyc, hwid, sink, iters);
+      hipLaunchKernelGGL(c.k, dim3(ncu), dim3(threads), 0, 0, cyc, rt, hwid, sink, iters);
       hipEventRecord(e1, 0);
       hipDeviceSynchronize();
       float ms = 0;
@@ -174,10 +212,24 @@ int main(int argc, char** argv) {
       std::vector<unsigned> hw(ncu * 4 * W);
       hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
       hipMemcpy(hw.data(), hwid, hw.size() * 4, hipMemcpyDeviceToHost);
+      if (!strcmp(c.name, "sl_add64") || !strcmp(c.name, "sl_xor_add64")) {      // per-wave view: is the issue bandwidth shared evenly?
+        fprintf(stderr, "%s W=%d, workgroup 0: cycles per instruction of each wave [simd.waveslot]:", c.name, W);
+        for (int i = 0; i < 4 * W; ++i)
+          fprintf(stderr, " %u.%u:%.2f", (hw[i] >> 4) & 3u, hw[i] & 15u, (double)h[i] / ((double)iters * c.per_iter));
+        std::vector<unsigned long long> hs(h);
+        std::sort(hs.begin(), hs.end());
+        fprintf(stderr, "   | all waves: min %.2f  p25 %.2f  median %.2f  p75 %.2f  max %.2f\n", (double)hs[0] / ((double)iters * c.per_iter),
+                (double)hs[hs.size() / 4] / ((double)iters * c.per_iter), (double)hs[hs.size() / 2] / ((double)iters * c.per_iter),
+                (double)hs[3 * hs.size() / 4] / ((double)iters * c.per_iter), (double)hs.back() / ((double)iters * c.per_iter));
+      }
       std::sort(h.begin(), h.end());
       const double med = (double)h[h.size() / 2];
       printf(" %8.2f", med / ((double)iters * c.per_iter * W));
       if (W == 3) {
+        std::vector<unsigned long long> hr(ncu * 4 * W);
+        hipMemcpy(hr.data(), rt, hr.size() * 8, hipMemcpyDeviceToHost);
+        std::sort(hr.begin(), hr.end());
+        mhz3 = med / ((double)hr[hr.size() / 2] / 100.0);
         wall3 = ms;
         std::set<unsigned> cus;
         for (unsigned x : hw) cus.insert(((x >> 8) & 0xffu) | ((x >> 24) << 8));   // cu_id, sh_id, se_id + xcc_id
@@ -185,10 +237,30 @@ int main(int argc, char** argv) {
       }
     }
     const double units = (double)iters * c.per_iter * 12.0 * ncu;       // wave-level units executed at W=3
-    printf("   | %.3f ms, %.3f ns per unit per SIMD", wall3, wall3 * 1e6 / ((double)iters * c.per_iter * 3));
+    printf("   | %.3f ms, s_memtime/s_memrealtime = %.0f MHz", wall3, mhz3);
     if (!strcmp(c.name, "fma_f64")) printf(", %.1f TFLOP/s (datasheet vector f64: 78.6)", units * 64 * 2 / (wall3 * 1e-3) * 1e-12);
     if (!strcmp(c.name, "add_f32")) printf(", %.1f T lane-add/s", units * 64 / (wall3 * 1e-3) * 1e-12);
     printf("  [%zu distinct (xcc,se,sh,cu)]  %s\n", ncu_seen, c.what);
+  }
+  // sustained float64 FMA rate of the whole chip by wall clock (a quarter of a second per point: past the clock ramp)
+  for (int W = 2; W <= 4; ++W) {
+    const int iters = 20000, threads = 256 * W;
+    hipLaunchKernelGGL(k_sl_fma64, dim3(ncu), dim3(threads), 0, 0, cyc, rt, hwid, sink, 200);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_sl_fma64, dim3(ncu), dim3(threads), 0, 0, cyc, rt, hwid, sink, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(ncu * 4 * W), hr(ncu * 4 * W);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hr.data(), rt, hr.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    std::sort(hr.begin(), hr.end());
+    const double instr = (double)iters * 4096 * 4 * W * ncu;
+    printf("sustained v_fma_f64, %d waves/SIMD on %d CUs: %.1f ms wall clock => %.1f TFLOP/s (datasheet vector f64 78.6); %.2f s_memtime cycles per "
+           "instruction per SIMD; s_memtime/s_memrealtime = %.0f MHz under this load\n", W, ncu, ms, instr * 128 / (ms * 1e-3) * 1e-12,
+           (double)h[h.size() / 2] / ((double)iters * 4096 * W), (double)h[h.size() / 2] / ((double)hr[hr.size() / 2] / 100.0));
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) printf("HIP error: %s\n", hipGetErrorString(e));
