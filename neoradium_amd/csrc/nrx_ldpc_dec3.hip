@@ -50,13 +50,112 @@ __device__ __forceinline__ double clip10(double x) {
   return x < -c ? -c : (x > c ? c : x);
 }
 __device__ __forceinline__ uint32_t hi32(double x) { return (uint32_t)__double2hiint(x); }
-__device__ __forceinline__ double sign_from(uint32_t signsrc, double mag) {  // mag >= 0; sign taken from bit 31 of signsrc
-  return __hiloint2double((int)((signsrc & 0x80000000u) | hi32(mag)), __double2loint(mag));
-}
 __device__ __forceinline__ uint32_t dbl(uint32_t w) {   // w + w as an add the optimiser cannot turn into a shift
   uint32_t r;
   asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(w));
   return r;
+}
+
+// ---- Messages as  unit * pm,  selected by EXEC (round 3).
+// A check-to-variable message is  sign_j * 0.75 * (j == argmin ? min2 : min1)  with sign_j = parity ^ sign(t_j)
+// (ldpc.py:1556-1573).  The row keeps pm1 / pm2 = the two scaled minima WITH THE ROW PARITY AS THEIR SIGN, and the sign of
+// t_j becomes a unit u_j = +-2^-7 (pm carries the 2^7), so
+//     r_j = t_j + msg_j = fma( u_j, pm, t_j)          t_j = r_j - msg_j = fma(-u_j, pm, r_j)
+// u_j * pm is exact, so the fused operation rounds exactly like the reference's add / subtract of the signed message.
+// Which of pm1 / pm2 a lane takes is decided by EXEC: every lane takes pm1, then a v_cmpx puts the argmin lanes into
+// EXEC and they redo the operation with pm2 -- 3 VALU + 1 SALU instructions where two 64-bit selects (4 v_cndmask), a
+// sign insert and an add were 6.  Why instruction count is the currency: the SIMD issues ONE VALU instruction per 4 cycles
+// whatever the mix (float64, VOP3, VOP2 in a mixed stream) and, among its ready waves, always the oldest
+// (tools/ubench/issue_probe.hip, profiles/r3_issue_probe*.txt); scalar instructions, s_nop and waits issue beside the vector pipe.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// +-2^-7 with the sign of bit 31 of signsrc.  uv.x stays 0: only the high word of the register pair is rewritten.  The high
+// word of 2^-7 is 0x3f800000 = the inline constant 1.0f, so ONE v_and_or_b32 with the sign mask in an SGPR builds it (VOP3
+// reads a single scalar operand on gfx9; the high word of 1.0, 0x3ff00000, would have to sit in a VGPR).  Scaling by a
+// power of two commutes with rounding: 2^-7 * fl(96 * min) = fl(0.75 * min) exactly (short of 0.75 * min < 2^-1022, which a
+// clipped LLR cannot produce other than as an exact zero).
+__device__ __forceinline__ double unit_of(u32x2& uv, uint32_t signsrc) {
+  uint32_t h;
+  asm("v_and_or_b32 %0, %1, %2, 1.0" : "=v"(h) : "v"(signsrc), "s"(0x80000000u));
+  uv.y = h;
+  return __builtin_bit_cast(double, uv);
+}
+// +-96.0 = +-0.75 * 2^7, negative for an odd number of set sign bits
+__device__ __forceinline__ double c96_of(u32x2& uv, uint32_t signbits) {
+  uint32_t h;
+  asm("v_lshl_or_b32 %0, %1, 31, %2" : "=v"(h) : "v"((uint32_t)__builtin_popcount(signbits)), "s"(0x40580000u));
+  uv.y = h;
+  return __builtin_bit_cast(double, uv);
+}
+// min / max written out: after an inline-asm producer the compiler cannot prove its inputs canonical and puts a
+// v_max_f64 x, x, x in front of every llvm.minnum / maxnum (one extra VALU instruction per edge); no NaN reaches this code
+// (the LLRs are clipped to +-1e10 on the way in, ldpc.py:1536)
+__device__ __forceinline__ double vmin_abs(double a, double t) {
+  double r;
+  asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
+__device__ __forceinline__ double vmax_abs(double a, double t) {
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
+__device__ __forceinline__ double vmin_abs2(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax_abs2(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// lanes where |t| == a, as a mask in SGPRs (cold path only)
+__device__ __forceinline__ uint64_t cmp_abs_eq(double t, double a) {
+  uint64_t m;
+  asm("v_cmp_eq_f64 %0, |%1|, %2" : "=s"(m) : "v"(t), "v"(a));
+  return m;
+}
+// fma(-u, oidx == J ? p2 : p1, x)   (all 64 lanes are live: EXEC is -1 around the block)
+template <int J>
+__device__ __forceinline__ double sel_fnma_x(double x, uint32_t oidx, double u, double p1, double p2) {
+  double y;
+  asm("v_fma_f64 %[y], -%[u], %[p1], %[x]\n\t"
+      "v_cmpx_eq_u32_e32 vcc, %[j], %[oidx]\n\t"
+      "v_fma_f64 %[y], -%[u], %[p2], %[x]\n\t"
+      "s_mov_b64 exec, -1"
+      : [y] "=&v"(y) : [x] "v"(x), [j] "n"(J), [oidx] "v"(oidx), [u] "v"(u), [p1] "v"(p1), [p2] "v"(p2) : "vcc");
+  return y;
+}
+// fma(u, |x| == a ? p2 : p1, x); idx <- J where |x| == a.  EVERY entry equal to the minimum takes p2: with a tie min2 == min1,
+// so p2 == p1 bit for bit -- unless the +1e5 quirk has moved min2 under a tie, which the caller's cold path handles.
+template <int J>
+__device__ __forceinline__ double sel_fma_x(double x, uint32_t& idx, double a, double u, double p1, double p2) {
+  double y;
+  asm("v_fma_f64 %[y], %[u], %[p1], %[x]\n\t"
+      "v_cmpx_eq_f64_e64 vcc, |%[x]|, %[a]\n\t"
+      "v_fma_f64 %[y], %[u], %[p2], %[x]\n\t"
+      "v_mov_b32 %[idx], %[j]\n\t"
+      "s_mov_b64 exec, -1"
+      : [y] "=&v"(y), [idx] "+v"(idx) : [x] "v"(x), [a] "v"(a), [j] "n"(J), [u] "v"(u), [p1] "v"(p1), [p2] "v"(p2) : "vcc");
+  return y;
+}
+// Cold path: x <- fma(u, p2 or p1, x) with p2 for the lanes of im that are not in seen yet -- the FIRST minimum of a lane only,
+// np.argmin's index (ldpc.py:1558-1570) -- and idx <- J there; seen |= im
+template <int J>
+__device__ __forceinline__ void sel_fma_first(double& x, uint32_t& idx, uint64_t& seen, uint64_t im, double u, double p1, double p2) {
+  asm volatile("s_andn2_b64 exec, %[im], %[seen]\n\t"
+               "s_or_b64 %[seen], %[seen], %[im]\n\t"
+               "v_fma_f64 %[x], %[u], %[p2], %[x]\n\t"
+               "v_mov_b32 %[idx], %[j]\n\t"
+               "s_not_b64 exec, exec\n\t"
+               "v_fma_f64 %[x], %[u], %[p1], %[x]\n\t"
+               "s_mov_b64 exec, -1"
+               : [x] "+v"(x), [idx] "+v"(idx), [seen] "+s"(seen) : [im] "s"(im), [u] "v"(u), [p1] "v"(p1), [p2] "v"(p2), [j] "n"(J) : "scc");
 }
 
 #ifdef NRX_DEC3_PROBE
@@ -76,6 +175,22 @@ __device__ unsigned long long g_probe[10];
   } while (0)
 #else
 #define PROBE_STAMP(K) do {} while (0)
+#endif
+
+// Wave priority by progress inside a layer.  The SIMD issues one VALU instruction per 4 cycles and, among ready waves of
+// equal priority, always picks the oldest (tools/ubench/issue_probe: three waves of one stream finish at T, 2T, 3T).  With a
+// barrier per layer that leaves the youngest wave to run the end of every layer alone, at its own serial speed.  Lowering
+// a wave's priority as it advances through the layer (3 -> 0) lets the waves that are behind go first, so the three waves
+// of a SIMD reach the barrier together.
+#ifndef NRX_DEC3_PRIO
+#define NRX_DEC3_PRIO 1
+#endif
+#if NRX_DEC3_PRIO == 1
+#define LAYER_PRIO(Q) __builtin_amdgcn_s_setprio(3 - (Q))
+#elif NRX_DEC3_PRIO == 2
+#define LAYER_PRIO(Q) __builtin_amdgcn_s_setprio(Q)
+#else
+#define LAYER_PRIO(Q) do {} while (0)
 #endif
 
 template <int BG> constexpr bool ext_shifts_are_zero() {
@@ -181,6 +296,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   double rext[NEXT];                                       // posterior of each layer's extension column, element z
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
   uint32_t sgn[(Y::n_narrow() + 1) / 2];                   // two 16-bit fields per word
+  u32x2 uv = {0u, 0u};                                     // register pair of the +-1.0 / +-0.75 units: low word stays 0
 
 #ifdef NRX_DEC3_PROBE
   uint32_t pk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0;
@@ -276,9 +392,12 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           PROBE_STAMP((Y::wide((L + B::ROWS - 1) % B::ROWS) ? 3 : 7));   // barrier of the previous layer
           pk_layers += 1;
 #endif
-          // ---- pass 1a: issue every LDS read of the layer (last edge first: the order pass 1b consumes them in)
+          // priority steps at about a quarter, a half and three quarters of the layer's VALU work (5 + 4 + 5 per edge)
+          constexpr int PQ1 = (7 * D) / 10 < D - 1 ? (7 * D) / 10 : D - 1, PQ2 = D / 2 < 2 ? 2 : D / 2, PQ3 = (3 * D) / 10 < 1 ? 1 : (3 * D) / 10;
+          LAYER_PRIO(0);
+          // ---- pass 1a: issue every LDS read of the layer, first edge first (the order pass 1b consumes them in)
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = DC - 1 - decltype(jc)::value;
+            constexpr int j = decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
             constexpr uint32_t off = 8u * (uint32_t)(col * ZS + B::shift(ILS, E0 + j) % ZC);
             const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
@@ -286,10 +405,11 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             else t[j] = *(const double*)((const char*)Praw + (wraps ? zbwh : zbh) + (off - HI));
           });
           __builtin_amdgcn_sched_barrier(0);
-          // ---- old state (sign/argmin word: argmin in the low bits of its field, sign of edge j above it)
+          // ---- old state: pm1 / pm2 (scaled minima carrying the row parity), and the sign / argmin word: argmin in the low
+          // bits of its field, above it the signs of the t_j of the previous iteration, edge 0 highest
           const double om1 = m1[L], om2 = m2[L];
           uint32_t word, oidx;
-          int top;   // left shift that brings the sign of edge 0 to bit 31
+          int top;   // left shift that brings the highest sign bit of the field to bit 31
           if constexpr (WIDE) {
             word = sgw[Y::wide_idx(L)];
             oidx = word & 31u;
@@ -300,43 +420,34 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             oidx = (ni & 1) ? ((word >> 16) & 15u) : (word & 15u);
             top = (ni & 1) ? (31 - 20) : (31 - 4);
           }
-          // ---- pass 1b: t_j = r_j - msg_old_j  (ldpc.py:1550-1553); the extension column's r comes from its register
+          // ---- pass 1b: t_j = r_j - msg_old_j = fma(-u_j, argmin ? pm2 : pm1, r_j)  (ldpc.py:1550-1553); the extension
+          // column's r comes from its register
           if constexpr (EXT) t[D - 1] = rext[Y::ext_idx(L)];
-          // (the "was edge j the minimum" tests go into SGPR pairs a few edges ahead of their use: a VALU-written mask
-          //  needs wait states before v_cndmask may read it; all D at once would hold 19 SGPR pairs and the allocator
-          //  then re-issues compares instead)
-          constexpr int CH = 19;      // (5 left 2-8 scratch accesses per iteration in the layer loop, 19 = the whole layer none)
-          uint32_t wrun = word << (top - (D - 1));           // sign of edge D-1 at bit 31; doubled per edge
-          static_for<(D + CH - 1) / CH>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int hi = D - 1 - decltype(kc)::value * CH;            // edges hi, hi-1, ... of this chunk
-            constexpr int n = hi + 1 < CH ? hi + 1 : CH;
-            bool was_min[CH];
-            static_for<n>([&](auto jc) __attribute__((always_inline)) {
-              was_min[decltype(jc)::value] = oidx == (uint32_t)(hi - decltype(jc)::value);
-            });
-            static_for<n>([&](auto jc) __attribute__((always_inline)) {
-              constexpr int j = hi - decltype(jc)::value;
-              uint32_t wnext = 0;
-              if constexpr (j > 0) wnext = dbl(wrun);
-              const double mag = was_min[decltype(jc)::value] ? om2 : om1;
-              t[j] = t[j] - sign_from(wrun, mag);
-              wrun = wnext;
-            });
+          uint32_t wrun = word << (top - (D - 1));           // sign of edge 0 at bit 31; doubled per edge
+          static_for<D>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const double u = unit_of(uv, wrun);
+            if constexpr (j < D - 1) wrun = dbl(wrun);
+            if constexpr (j == PQ1) LAYER_PRIO(1);
+            t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
           });
           PROBE_STAMP(WIDE ? 0 : 4);
-          // ---- min-sum (ldpc.py:1556-1564): two smallest magnitudes by min/max, sign parity by XOR of the sign words
-          double a1 = __builtin_fabs(t[0]);
-          double a2 = 3.0e38;
-          uint32_t px = hi32(t[0]);
-          static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value + 1;
-            const double a = __builtin_fabs(t[j]);
-            a2 = __builtin_fmin(a2, __builtin_fmax(a1, a));
-            a1 = __builtin_fmin(a1, a);
-            px ^= hi32(t[j]);
+          // ---- min-sum (ldpc.py:1556-1564): two smallest magnitudes by min/max; the signs of the t_j are collected (edge 0
+          // ends highest) and their parity is a population count
+          static_assert(D >= 2, "a check row has at least two edges");
+          double a1 = vmin_abs2(t[0], t[1]);
+          double a2 = vmax_abs2(t[0], t[1]);
+          uint32_t nsg = __builtin_amdgcn_alignbit(hi32(t[0]) >> 31, hi32(t[1]), 31);
+          static_for<D - 2>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value + 2;
+            if constexpr (j == PQ2) LAYER_PRIO(2);
+            a2 = vmin(a2, vmax_abs(a1, t[j]));
+            a1 = vmin_abs(a1, t[j]);
+            nsg = __builtin_amdgcn_alignbit(nsg, hi32(t[j]), 31);      // (nsg << 1) | sign(t_j)
           });
           // QUIRK ldpc.py:1563: min2 = min(min2, |v_argmin + 1e5|) with the SIGNED argmin entry; it can only win where
           // min2 > 5e4 (filler / saturated LLRs): wave-uniform cold path.
+          bool tie_quirk = false;     // wave-uniform: some lane has min2 moved UNDER a tied minimum (see below)
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(a2 > 5.0e4) != 0, 0)) {
             double v = t[D - 1];
             static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
@@ -347,41 +458,52 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               v = (__double_as_longlong(t[j]) & 0x7fffffffffffffffll) == __double_as_longlong(a1) ? t[j] : v;   // ends at the first index holding the minimum
             });
             const double q = __builtin_fabs(v + 100000.0);
+            // With several entries AT the minimum (min2 == min1) and a negative first one, q < min1: the reference then gives
+            // min2 = q to np.argmin's entry ALONE and min1 to the other tied ones (ldpc.py:1566-1570).  The hot write pass gives
+            // pm2 to every tied entry (identical while min2 == min1), so such a layer takes the first-only write pass below.
+            tie_quirk = __builtin_amdgcn_ballot_w64(q < a2 && a2 == a1) != 0;
             a2 = q < a2 ? q : a2;
           }
-          const double nm1 = a1 * 0.75, nm2 = a2 * 0.75;     // ldpc.py:1573 (the scale commutes with the sign)
+          // 0.75 * min (ldpc.py:1573; the scale commutes with the sign) times 2^7 (see unit_of), with the row parity as its
+          // sign: +-96 is built from the population count of the collected signs
+          const double c96 = c96_of(uv, nsg);
+          const double nm1 = a1 * c96, nm2 = a2 * c96;
           m1[L] = nm1;
           m2[L] = nm2;
           PROBE_STAMP(WIDE ? 1 : 5);
-          // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written back to the element it was read from.  An entry
-          // equal to min1 gets min2 (with ties min2 == min1, so every tied entry may take it); first such index = argmin.
-          uint32_t nsg = 0, idx = 0;
-          static_for<(D + CH - 1) / CH>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int hi = D - 1 - decltype(kc)::value * CH;
-            constexpr int n = hi + 1 < CH ? hi + 1 : CH;
-            bool is_min[CH];
-            static_for<n>([&](auto jc) __attribute__((always_inline)) {
-              is_min[decltype(jc)::value] = __builtin_fabs(t[hi - decltype(jc)::value]) == a1;
+          // ---- pass 2: r_j = t_j + msg_new_j = fma(u_j, first argmin ? pm2 : pm1, t_j), written back to the element it was
+          // read from.  The FIRST entry equal to min1 gets min2 (np.argmin, ldpc.py:1558-1570).
+          uint32_t idx = 0;
+          auto put = [&](auto jc2) __attribute__((always_inline)) {      // r_j back to its column element / extension register
+            constexpr int j = decltype(jc2)::value;
+            constexpr int col = B::col(E0 + j);
+            if constexpr (col < B::CORE) {
+              constexpr uint32_t off = 8u * (uint32_t)(col * ZS + B::shift(ILS, E0 + j) % ZC);
+              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
+              if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
+              else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
+            } else {
+              rext[Y::ext_idx(L)] = t[j];
+            }
+          };
+          if (__builtin_expect(!tie_quirk, 1)) {
+            static_for<D>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = D - 1 - decltype(jc)::value;      // last edge first: idx ends at the first index holding the minimum
+              if constexpr (decltype(jc)::value == PQ3) LAYER_PRIO(3);
+              const double u = unit_of(uv, hi32(t[j]));
+              t[j] = sel_fma_x<j>(t[j], idx, a1, u, nm1, nm2);
+              put(std::integral_constant<int, j>{});
             });
-            static_for<n>([&](auto jc) __attribute__((always_inline)) {
-              constexpr int j = hi - decltype(jc)::value;
-              constexpr int col = B::col(E0 + j);
-              const bool im = is_min[decltype(jc)::value];
-              const uint32_t sx = px ^ hi32(t[j]);              // bit 31 = parity ^ sign(t_j)
-              nsg = __builtin_amdgcn_alignbit(nsg, sx, 31);     // (nsg << 1) | (sx >> 31): edge j ends at bit j
-              idx = im ? (uint32_t)j : idx;
-              const double mag = im ? nm2 : nm1;
-              const double r = t[j] + sign_from(sx, mag);
-              if constexpr (col < B::CORE) {
-                constexpr uint32_t off = 8u * (uint32_t)(col * ZS + B::shift(ILS, E0 + j) % ZC);
-                const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
-                if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = r;
-                else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = r;
-              } else {
-                rext[Y::ext_idx(L)] = r;
-              }
+          } else {
+            uint64_t seen = 0;
+            static_for<D>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = decltype(jc)::value;
+              const uint64_t is_min = cmp_abs_eq(t[j], a1);
+              const double u = unit_of(uv, hi32(t[j]));
+              sel_fma_first<j>(t[j], idx, seen, is_min, u, nm1, nm2);
+              put(std::integral_constant<int, j>{});
             });
-          });
+          }
           if constexpr (WIDE) {
             sgw[Y::wide_idx(L)] = idx | (nsg << 5);           // argmin [4:0], signs [5+D-1:5]
           } else {

@@ -354,3 +354,36 @@ def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_e
     for E in lens:
         assert np.array_equal(dei[:, off:off + E], std[:, off:off + E].reshape(2, E // qm, qm).transpose(0, 2, 1).reshape(2, E))
         off += E
+
+
+@pytest.mark.parametrize("bg,zc,n_tx_cols,all_rows", [(1, 384, 35, False), (1, 384, 35, True), (1, 352, 40, True), (2, 64, 20, True)])
+def test_tied_minimum_under_the_1e5_quirk(dev, bg, zc, n_tx_cols, all_rows):
+    """ldpc.py:1563-1570 with SEVERAL entries at the row minimum, all above 5e4, the first of them negative: the reference adds
+    1e5 to np.argmin's entry, min2 drops BELOW min1, and only that first entry receives min2 -- the other tied entries keep
+    min1.  Saturated LLRs of one magnitude (6e4) produce exactly that within the first iteration (a punctured column that has
+    outgrown its neighbours leaves D-1 tied entries as the minimum).  float64 decoders (on-chip kernel for Zc 384 / 15 rows,
+    workspace kernel otherwise) against the oracle: beliefs of every column where they are returned, hard bits always."""
+    import torch
+    from neoradium_amd import ops, _lib
+    kb, core, rows_all, ncols = (22, 26, 46, 68) if bg == 1 else (10, 14, 42, 52)
+    ils = next(i for i, b in enumerate((2, 3, 5, 7, 9, 11, 13, 15)) if zc % b == 0 and (zc // b) & (zc // b - 1) == 0)
+    cfg = _lib.LdpcCfg()
+    cfg.bg, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F, cfg.C, cfg.B, cfg.cb_len = bg, zc, ils, kb * zc, (ncols - 2) * zc, 0, 1, 0, 0
+    rng = np.random.default_rng(zc + n_tx_cols + all_rows)
+    n_cb = 4
+    llr = np.full((n_cb, cfg.N), -6.0e4)
+    llr[1] *= rng.choice([-1.0, 1.0], cfg.N)                    # random signs
+    llr[2, rng.random(cfg.N) < 0.3] = 6.0e4                     # mostly negative
+    llr[3] = np.where(rng.random(cfg.N) < 0.5, -6.0e4, -1.0e10)  # two saturated levels (1e10 = the clipping level)
+    e_max = n_tx_cols * zc
+    llr[:, e_max:] = 0.0
+    rows = None if all_rows else ops.ldpc_active_rows(cfg, e_max)
+    n_it = 6
+    ref = oc.decode(llr, bg, ils, zc, num_iter=n_it, only_info=False, belief=True, rows=rows)
+    # the corner is actually reached: a decoder that hands min2 to every tied entry differs from the reference here
+    x = torch.from_numpy(llr).to(dev)
+    hard = ops.ldpc_decode(x, cfg, n_it, rows=rows).cpu().numpy()
+    assert np.array_equal(hard, (ref[:, :kb * zc] < 0).astype(np.uint8))
+    if all_rows:
+        bel = ops.ldpc_decode(x, cfg, n_it, only_info=False, belief=True).cpu().numpy()
+        assert np.array_equal(bel, ref), f"max diff {np.abs(bel - ref).max()}"
