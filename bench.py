@@ -204,6 +204,36 @@ def cpu_baseline(link, snr_db, n_single=2, n_procs=None):
     return base, parity
 
 
+def decoder_isa(kernel_key):
+    """VALU / total instruction count of one iteration of the decoder kernel whose mangled name contains ``kernel_key``, from
+    profiles/r3_decoder_isa.json (tools/isa_mix.py --json) when its SHA-256 is that of the library actually loaded; otherwise
+    the tool is run on the loaded library now (a CPU child process: llvm-objdump on the code objects)."""
+    import hashlib
+    import tempfile
+    from neoradium_amd import _lib
+    lib = _lib._LIB_PATH
+    sha = hashlib.sha256(open(lib, 'rb').read()).hexdigest()
+    src = 'profiles/r3_decoder_isa.json'
+    try:
+        d = json.load(open(os.path.join(ROOT, src)))
+        if d.get('sha256') != sha:
+            raise ValueError('hash mismatch')
+    except Exception:
+        tmp = tempfile.NamedTemporaryFile(suffix='.json', delete=False).name
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_mix.py'), lib, 'ldpc_dec', '--json', tmp],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            return None
+        d = json.load(open(tmp))
+        src = 'tools/isa_mix.py run on the loaded library (committed profile is of another build)'
+    for name, k in d['kernels'].items():
+        if kernel_key in name:
+            c = k['by_class']
+            return dict(kernel_symbol=name, valu=c.get('valu', 0), all=k['loop_instructions'], vgpr=k['vgpr'], scratch_bytes=k['scratch_bytes'],
+                        by_class=c, source=src, library_sha256=sha)
+    return None
+
+
 def launch_ranks(n):
     """--gpus N without a launcher: start N ranks as children (torch.distributed.run) and pass their exit code on.
     Runs before this process has made any GPU call; the parent never touches the GPU."""
@@ -228,6 +258,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help="skip the CPU-oracle baseline leg")
     ap.add_argument('--no-fast', action='store_true', help="skip the extra float32 fast-mode measurement")
     ap.add_argument('--no-allrows', action='store_true', help="skip the extra all-46-rows measurement")
+    ap.add_argument('--no-twopass', action='store_true', help="skip the opt-in two-pass schedule block")
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)      # test hook, see StubLink
     args = ap.parse_args()
 
@@ -282,15 +313,36 @@ def main():
         achieved = alg_bytes / (dec_ms * 1e-3) / 1e9
         built = (13, 15, 46) if f64 else (13, 15, 16, 22, 31, 46)      # row counts with an instantiation: the next one >= rows runs
         rows_run = next(r for r in built if r >= rows)
+        if f64 and rows > 15:
+            rows_run = rows                                # (the workspace kernel takes the row count at run time)
         edge_visits = B * cfg.C * link.numIter * BG1_ROW_START[rows_run] * cfg.Zc
         ev_s = edge_visits / (dec_ms * 1e-3)
-        # What bounds the decoder is VALU issue, not HBM: SIMD cycles per wave-edge-visit of its instruction
-        # mix, priced with the issue rates measured on this chip (profiles/r1_valu_issue_rates.txt, r2_f64_issue_rates.txt)
-        cyc = 54.6 if f64 else 42.9
-        valu_bound = 1024 * 64 * 2.4e9 / cyc
+        # What bounds the decoder is VALU issue, not HBM: a SIMD issues one wave64 VALU instruction per 4 cycles
+        # whatever the mix (tools/ubench/issue_probe.hip, profiles/r3_issue_probe.txt: sustained v_fma_f64 77.5 TFLOP/s = 4.0
+        # cycles, and the same 4.0 for VOP3 / mixed streams); the instruction count of an iteration is read from the ISA of
+        # the library that is loaded (profiles/r3_decoder_isa.json, checked by SHA-256)
+        N_SIMD, CLOCK, CYC_PER_VALU = 256 * 4, 2.4e9, 4.0
+        if f64:
+            key = f"chip64_kernelILi1ELi50ELi{rows_run}ELb1E" if rows_run <= 15 else None
+        else:
+            key = f"fast_kernelILi1ELi50ELi2ELi{rows_run}E"
+        isa = decoder_isa(key) if (key and not args.stub) else None
+        n_waves = B * cfg.C * (cfg.Zc // 64)                      # one wave = 64 check rows of one code block
+        valu_issue = None
+        if isa:
+            valu_instr = n_waves * isa['valu'] * link.numIter     # wave64 VALU instructions of a launch (iteration loop only)
+            peak_rate = N_SIMD * CLOCK / CYC_PER_VALU             # the chip's VALU issue rate, wave64 instructions / s
+            ach_rate = valu_instr / (dec_ms * 1e-3)
+            valu_issue = {"achieved": ach_rate / 1e9, "peak": peak_rate / 1e9, "unit": "G wave64 VALU instructions/s", "frac": ach_rate / peak_rate,
+                          "valu_instr_per_wave_iteration": isa['valu'], "all_instr_per_wave_iteration": isa['all'],
+                          "valu_instr_per_wave_edge_visit": isa['valu'] / BG1_ROW_START[rows_run],
+                          "vgpr": isa['vgpr'], "scratch_bytes": isa['scratch_bytes'], "kernel_symbol": isa['kernel_symbol'],
+                          "isa_source": isa['source'], "library_sha256": isa['library_sha256'],
+                          "cycles_per_valu_instr": CYC_PER_VALU, "clock_hz": CLOCK,
+                          "bound_edge_visits_per_s": peak_rate / (isa['valu'] / BG1_ROW_START[rows_run]) * 64}
         traffic = None
         try:                                              # HBM bytes per launch from the committed PMC passes
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r2_decoder_traffic.json' if f64 else 'r1_decoder_traffic.json')))
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r3_decoder_traffic.json' if f64 else 'r1_decoder_traffic.json')))
             if tr.get('rows') == rows_run or (not f64 and rows_run in (15, 16)):
                 traffic = (tr['FETCH_SIZE_KB_per_launch'] * tr.get('fetch_correction', 1.0) + tr['WRITE_SIZE_KB_per_launch']) \
                     * 1024.0 * B / tr['batch_slots']
@@ -312,23 +364,19 @@ def main():
             "ldpc_rows": {"needed": rows, "run": rows_run, "of": 46,
                           "note": "rows whose extension parity was not transmitted are exact no-ops for the information bits "
                                   "(they send +-0) and are not run; counters identical to all 46 rows"},
-            "roofline": {"bound": "hbm", "kernel": kname,
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "avg_launch_ms": dec_ms, "launch_share_of_step": dec_ms / (dt / K * 1e3),
-                         "note": "the decoder re-uses its LDS/VGPR-resident working set 50x and touches HBM only at entry/exit, so its "
-                                 "HBM fraction is small by construction; its real bound is VALU issue (see valu_issue)",
-                         "edge_visits_per_s": ev_s,
-                         "valu_issue": {"bound": "valu", "cycles_per_wave_edge_visit": cyc, "bound_edge_visits_per_s": valu_bound,
-                                        "frac": ev_s / valu_bound,
-                                        "all_instructions": None if not f64 else {
-                                            "instr_per_wave_edge_visit": 23.7, "cycles_per_instr": 3.0,
-                                            "frac": ev_s / (1024 * 64 * 2.4e9 / (23.7 * 3.0)),
-                                            "note": "every instruction of the loop (VALU 19.4, LDS 1.9, waits/nops 1.5, scalar 0.9 per "
-                                                    "edge-visit) at the ~3.0 cycles a float64/VOP3-carrying stream issues at with three "
-                                                    "waves per SIMD (profiles/r2_f64_issue_rates.txt); timing ablations without LDS "
-                                                    "instructions and without barriers are not faster (DESIGN 4.1c)"}}},
+            "roofline": ({"bound": "valu", "kernel": kname, "achieved": valu_issue["achieved"], "peak": valu_issue["peak"],
+                          "unit": valu_issue["unit"], "frac": valu_issue["frac"]} if valu_issue else
+                         {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0}),
             "env": {k: v for k, v in os.environ.items() if k.startswith('NRX_')},
         }
+        out["roofline"].update({
+            "traffic": traffic, "avg_launch_ms": dec_ms, "launch_share_of_step": dec_ms / (dt / K * 1e3), "edge_visits_per_s": ev_s,
+            "hbm": {"achieved": achieved, "peak": 8000.0, "unit": "GB/s", "hbm_frac": achieved / 8000.0, "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "the decoder re-uses its LDS/VGPR-resident working set numIter times and touches HBM at entry / exit only"},
+            "note": "bound = VALU issue: one wave64 VALU instruction per SIMD per 4 cycles x 1024 SIMDs x 2.4 GHz; achieved = VALU "
+                    "instructions of the iteration loop (ISA of the loaded library) x waves x iterations / HIP-event launch time"})
+        if valu_issue:
+            out["roofline"]["valu_issue"] = valu_issue
         if not args.stub and world == 1 and not args.no_fast and f64:
             # fast mode: float32 LLRs + float32 decoder, same steps/warm-up protocol; NOT bit-exact (CRC verdicts differ from
             # the float64 chain on about 1 block in 1e3 at the waterfall, profiles/r2_f32_vs_f64_verdicts.json)
@@ -338,8 +386,29 @@ def main():
             out["fast_mode"] = {"decoder": "f32 LLRs + ldpc_dec_fast_kernel", "value": B * K / fdt, "unit": "slots/s",
                                 "ms_per_step": fdt / K * 1e3, "decoder_launch_ms": fdec, "exact": False,
                                 "block_errors": int(fc[0]), "blocks": int(fc[1]),
-                                "verdicts_differ_from_exact": int(abs(int(fc[0]) - int(c[0])))}
+                                "block_error_count_delta": int(fc[0]) - int(c[0])}
             del fl
+        if not args.stub and world == 1 and not args.no_twopass and f64:
+            # OPT-IN schedule, reported beside `value`, never instead of it: every code block gets `first_pass_iter` iterations,
+            # the blocks whose CRC fails are decoded again from scratch with all numIter (PdschLink(firstPassIter=n)), so a
+            # failing block carries exactly the reference's result; a block that passes early is assumed to be the code word
+            # the full run ends on as well, and the error counters of the same slots are compared with the reference schedule's
+            tp = build_link(nr, decoder='f64', firstPassIter=8)
+            kt, wt = min(K, 6), min(W, 1)
+            pts = []
+            for snr_t in sorted({float(args.snr), 35.0}):
+                tdt, tc, _ = timed_steps(tp, ops, B, kt, wt, snr_t, slot_base, None, sync, timer_enabled=False)
+                cs = torch.zeros(4, dtype=torch.int64, device=dev)
+                for k in range(kt):
+                    link.run(slot_base + (wt + k) * B, B, snr_t, seed=123, counters=cs)
+                tc, cs = tc.cpu().numpy(), cs.cpu().numpy()
+                pts.append({"snr_db": snr_t, "value": B * kt / tdt, "unit": "slots/s", "steps": kt, "ms_per_step": tdt / kt * 1e3,
+                            "block_errors": int(tc[0]), "blocks": int(tc[1]), "bit_errors": int(tc[2]),
+                            "counters_identical_to_reference_schedule": bool((tc == cs).all())})
+            out["two_pass"] = {"first_pass_iter": 8, "num_iter": link.numIter, "exact_by_construction": False,
+                               "note": "opt-in (off by default, not the reference's schedule): shown as the labelled fast line",
+                               "points": pts}
+            del tp
         if not args.stub and world == 1 and not args.no_allrows:
             # the same steps with all 46 rows of the base graph (what the reference runs): identical counters, slower
             al = build_link(nr, decoder=args.decoder, skipPuncturedRows=False)

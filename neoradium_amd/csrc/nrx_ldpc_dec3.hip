@@ -240,6 +240,8 @@ template <uint32_t K> __device__ __forceinline__ uint32_t gf2_mulc24(uint32_t a)
 // (ldpc.py:1584-1619) are done by the tail.  Geometry as nrx_ldpc_enc.hip's RmGeom.
 struct FuseGeom {
   int C, e_small, n_small, f, qm, sys_len, F, llr_len, cb_len, payload;
+  int rows_live;   // unfused entry: the caller's row count (<= RA of the instantiation that runs): the extension LLRs of the
+                   // rows beyond it are taken as zero, which makes those rows the no-ops the workspace kernel does not run at all
 };
 struct FuseArgs {
   FuseGeom g;
@@ -309,6 +311,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     const int cbq = live ? cb : n_cb - 1;                   // (a wave without a code block loads an existing one)
     const double* in = FUSED ? llr : llr + (size_t)cbq * N;
     int fE = 0, foff = 0;                                  // FUSED: E_r and the offset of the block in the LLR stream
+    int rows_live = B::ROWS;
+    if constexpr (!FUSED) rows_live = fuse_args()->g.rows_live;
     FuseGeom fg{};
     if constexpr (FUSED) {
       const fargs_t fa = fuse_args();
@@ -359,7 +363,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       constexpr int L = decltype(lc)::value;
       m1[L] = 0.0;
       m2[L] = 0.0;
-      if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC);
+      if constexpr (Y::has_ext(L)) {
+        rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC);
+        if constexpr (!FUSED) rext[Y::ext_idx(L)] = L < rows_live ? rext[Y::ext_idx(L)] : 0.0;      // (wave-uniform)
+      }
     });
     static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
     static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
@@ -610,7 +617,7 @@ int32_t wrap_table(int n_rows, const uint64_t** out) {
 }
 
 bool chip64_covers(const nrx_ldpc_cfg* cfg, int n_rows) {
-  static const bool off = getenv("NRX_LDPC_NOCHIP64") != nullptr;      // developer switch: always the workspace kernel
+  const bool off = getenv("NRX_LDPC_NOCHIP64") != nullptr;      // developer switch (read at every call): always the workspace kernel
   return !off && cfg->bg == 1 && cfg->Zc == 384 && cfg->iLS == 1 && n_rows <= 15;
 }
 
@@ -628,7 +635,8 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
   const int n_wg = (n_cb + 1) / 2;
   const int grid = n_wg < 1024 ? n_wg : 1024;
   constexpr int ZI384 = zindex_c(384);
-  const FuseArgs fa{};
+  FuseArgs fa{};
+  fa.g.rows_live = n_rows;
   if (n_rows <= 13)
     hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 13, false>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard, (mtab_t)wt, fa);
   else
@@ -656,6 +664,7 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t 
   fg.n_small = cfg->C - gb % cfg->C;
   fg.sys_len = cfg->K - 2 * cfg->Zc - cfg->F;
   fg.payload = cfg->cb_len - 24;
+  fg.rows_live = 46;
   const int e_max = fg.e_small + (fg.n_small < cfg->C ? f : 0);
   // the rows that can matter for e_max received bits (as ops.ldpc_active_rows): never fewer than the caller asks for
   const int last = e_max - 1 + (e_max > fg.sys_len ? cfg->F : 0);

@@ -158,6 +158,7 @@ class PdschLink:
                                  "reference's layer mapping, pdsch.py:619-639, write some REs twice)")
             inv[ri] = np.arange(len(ri), dtype=np.int32)
             self.re_inv = D(inv)
+            self.re_planes = None         # ops.layer_planes(self.re_inv): asked once, on first use (a device reduction)
         c0 = self.cw[0]     # (single-codeword attribute names kept: bench.py, the oracle harness and the tests use them)
         self.G, self.re_index, self.scr, self.cfg = c0['G'], c0['re_index'], c0['scr'], c0['cfg']
         self.first_prb = int(pdsch.prbSet[0])
@@ -238,6 +239,9 @@ class PdschLink:
         Parity mode: pass ``tb_bits`` (n_slots, TBS) -- a list of two such tensors for a two-codeword PDSCH -- and
         ``noise`` (standard-normal complex pairs, shape of the noisy signal) to reproduce a host NumPy PCG64 stream."""
         dev = self.dev
+        if not (details is False or details is True or details is None or (isinstance(details, str) and details == "verdicts")):
+            raise ValueError('details must be False, True or "verdicts"')
+        details = details or False
         if counters is None:
             counters = torch.zeros(4, dtype=torch.int64, device=dev)
         slots = np.arange(slot0, slot0 + n_slots)
@@ -288,7 +292,9 @@ class PdschLink:
             coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'], rows=cw['rows'] if harq is None else None)
             bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[0])
             if grid is None:    # one codeword: template + scramble + modulate + layer/RE map in one pass over the grid
-                grid = ops.pdsch_populate(bits, cw['qm'], cw['scr'], self.re_inv, self.templates, sif)
+                if self.re_planes is None:
+                    self.re_planes = ops.layer_planes(self.re_inv, self.templates.shape[1])
+                grid = ops.pdsch_populate(bits, cw['qm'], cw['scr'], self.re_inv, self.templates, sif, planes=self.re_planes)
             else:
                 ops.qam_map(bits, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], out=grid)
         tb = tbs_in[0]

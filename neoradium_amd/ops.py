@@ -300,28 +300,24 @@ def qam_map(bits, qm, scr=None, re_index=None, out=None, out_elems=None, dtype=t
     return out
 
 
-_planes_ok = {}
+def layer_planes(re_inv, planes):
+    """Does the inverse RE map have the layer structure nrx_pdsch_populate's ``planes`` promises (plane p of a data RE holds
+    symbol number i + p where plane 0 holds i)?  One device reduction + host read: callers that reuse a map (PdschLink) ask
+    once and pass the answer to :func:`pdsch_populate` as ``planes``."""
+    ok = planes > 1 and re_inv.numel() % planes == 0
+    if ok:
+        m = re_inv.reshape(planes, -1).to(torch.int64)
+        want = torch.where(m[0:1] >= 0, m[0:1] + torch.arange(planes, device=m.device)[:, None], m[0:1].clamp(max=-1))
+        ok = bool(((m == want) | ((m < 0) & (want < 0))).all().item())
+    return planes if ok else 0
 
 
-def _layer_planes(re_inv, planes):
-    """Does the inverse RE map have the layer structure nrx_pdsch_populate's ``planes`` promises?  (Checked once per map.)"""
-    key = (re_inv.data_ptr(), re_inv.numel(), planes)
-    if key not in _planes_ok:
-        if len(_planes_ok) > 64:
-            _planes_ok.clear()
-        ok = planes > 1 and re_inv.numel() % planes == 0
-        if ok:
-            m = re_inv.reshape(planes, -1).to(torch.int64)
-            want = torch.where(m[0:1] >= 0, m[0:1] + torch.arange(planes, device=m.device)[:, None], m[0:1].clamp(max=-1))
-            ok = bool(((m == want) | ((m < 0) & (want < 0))).all().item())
-        _planes_ok[key] = ok
-    return _planes_ok[key]
-
-
-def pdsch_populate(bits, qm, scr, re_inv, templates, templ_sel):
+def pdsch_populate(bits, qm, scr, re_inv, templates, templ_sel, planes=None):
     """getGrid + populateGrid in one pass (nrx_pdsch_populate_*): (n, G) bits -> (n, *templates.shape[1:]) grid; data REs
     from the bit stream through the inverse RE map ``re_inv`` (int32, one entry per grid element, -1 = not a data RE),
-    everything else from ``templates[templ_sel[b]]``."""
+    everything else from ``templates[templ_sel[b]]``.  ``planes`` = :func:`layer_planes` of this map (0: no layer structure);
+    None: it is worked out here, on every call (the verdict is a property of the map's CONTENTS, so it is not cached by
+    address)."""
     bits = _u8(bits)
     n, nb = bits.shape
     dev = _dev(bits)
@@ -338,7 +334,10 @@ def pdsch_populate(bits, qm, scr, re_inv, templates, templ_sel):
     out = torch.empty((n,) + tuple(templates.shape[1:]), dtype=templates.dtype, device=dev)
     fn = getattr(lib(), 'nrx_pdsch_populate_' + sfx)
     re_inv = re_inv.contiguous()
-    planes = templates.shape[1] if templates.dim() == 4 and _layer_planes(re_inv, templates.shape[1]) else 0
+    if planes is None:
+        planes = layer_planes(re_inv, templates.shape[1]) if templates.dim() == 4 else 0
+    elif planes not in (0, templates.shape[1] if templates.dim() == 4 else 0):
+        raise ValueError("planes must be 0 or the number of layer planes of the templates")
     check(fn(ptr(bits), nb, ptr(scr_t), qm, ptr(re_inv), ptr(templates), ptr(templ_sel.contiguous()), elems,
              ptr(out), n, planes, stream()))
     return out

@@ -387,3 +387,19 @@ def test_tied_minimum_under_the_1e5_quirk(dev, bg, zc, n_tx_cols, all_rows):
     if all_rows:
         bel = ops.ldpc_decode(x, cfg, n_it, only_info=False, belief=True).cpu().numpy()
         assert np.array_equal(bel, ref), f"max diff {np.abs(bel - ref).max()}"
+
+
+def test_onchip_decoder_runs_exactly_the_rows_asked_for(dev):
+    """nrx_ldpc_decode_f64 with n_rows below the row count of the on-chip instantiation that serves it (13 or 15 rows at Zc 384):
+    the rows beyond n_rows must not see their extension LLRs even when the caller left something other than zero there -- the
+    workspace kernel (every other lifting size) runs exactly n_rows rows, and so must this one."""
+    import torch
+    from neoradium_amd import ops, _lib
+    cfg = _lib.LdpcCfg()
+    cfg.bg, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F, cfg.C, cfg.B, cfg.cb_len = 1, 384, 1, 22 * 384, 66 * 384, 0, 1, 0, 0
+    rng = np.random.default_rng(11)
+    llr = 2 / 0.9 ** 2 + (2 / 0.9) * rng.standard_normal((4, cfg.N))        # NOTHING punctured: every extension column is live
+    for rows in (6, 11, 14):
+        ref = oc.decode(llr, 1, 1, 384, num_iter=7, rows=rows)
+        got = ops.ldpc_decode(torch.from_numpy(llr).to(dev), cfg, 7, rows=rows).cpu().numpy()
+        assert np.array_equal(got, ref.astype(np.uint8)), rows

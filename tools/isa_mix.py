@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
 """Developer tool: instruction mix of the iteration loop of a decoder kernel in a compiled object / shared library.
 
-    python tools/isa_mix.py <file.o|libnrx.so> <kernel-name-substring>
+    python tools/isa_mix.py <file.o|libnrx.so> <kernel-name-substring> [--json out.json]
+
+--json writes, for every matching kernel, the register metadata and the loop's instruction counts by issue class (VALU / SALU /
+LDS / waits) together with the SHA-256 of the inspected file: bench.py prices the decoder's VALU-issue bound from
+profiles/r3_decoder_isa.json and checks that hash against the library it actually loaded.
 
 Prints register / scratch metadata, the opcode histogram of the innermost long backward-branch loop, and the number of
 back-to-back VOP2 v_cndmask_b32 pairs in it (each costs the issuing wave ~19 cycles on gfx950)."""
 import collections
+import hashlib
+import json
 import re
 import subprocess
 import sys
@@ -25,8 +31,24 @@ def code_objects(path):
         yield f.name
 
 
+def classify(op):
+    if op.startswith('v_'):
+        return 'valu'
+    if op.startswith('ds_'):
+        return 'lds'
+    if op in ('s_waitcnt', 's_nop'):
+        return 'wait'
+    if op.startswith('s_load') or op.startswith('s_store') or op.startswith('s_buffer') or op in ('s_memtime', 's_memrealtime'):
+        return 'smem'
+    if op.startswith('s_'):
+        return 'salu'
+    return 'vmem'
+
+
 def main():
     path, want = sys.argv[1], sys.argv[2]
+    out_json = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
+    report = {'file': path, 'sha256': hashlib.sha256(open(path, 'rb').read()).hexdigest(), 'kernels': {}}
     for co in code_objects(path):
         sym = subprocess.run([LLVM + 'llvm-readelf', '-s', co], capture_output=True, text=True).stdout
         if want not in sym:
@@ -65,6 +87,14 @@ def main():
                 scr = sum(n for op, n in c.items() if op.startswith('scratch_') or op.startswith('buffer_'))
                 print(f"  loop of {len(body)} instructions; back-to-back VOP2 cndmask pairs {pairs}; scratch/buffer ops {scr}")
                 print("  " + ", ".join(f"{op} {n}" for op, n in c.most_common(24)))
+                cls = collections.Counter()
+                for op, n in c.items():
+                    cls[classify(op)] += n
+                report['kernels'][name] = {'scratch_bytes': int(meta.group(1)) if meta else None, 'sgpr': int(meta.group(2)) if meta else None,
+                                           'vgpr': int(meta.group(3)) if meta else None, 'loop_instructions': len(body),
+                                           'by_class': dict(cls), 'scratch_ops_in_loop': scr, 'by_opcode': dict(c.most_common())}
+    if out_json:
+        json.dump(report, open(out_json, 'w'), indent=1)
 
 
 if __name__ == '__main__':
