@@ -249,21 +249,22 @@ constexpr int TDP_TILE = 128;  // threads per antenna group -> 512 output sample
 constexpr int TDP_GROUPS = 4;
 constexpr int TDP_FLEN = 16;   // channelmodel.py:249-289: 16-tap fractional-delay filters
 
-// One (tx antenna, path) term for the 4 samples of a thread.  U0 = (first window sample) mod 4 is a template
-// parameter so that the transposed-tile addresses are four base pointers + compile-time offsets.
-template <int NR, int U0>
-__device__ __forceinline__ void tdp4_term(const cd* __restrict__ p0, const cd* __restrict__ p1, const cd* __restrict__ p2,
-                                          const cd* __restrict__ p3, const double* __restrict__ c,
+// One (tx antenna, path) term for the 4 samples of a thread.  q0..q3 are the thread's addresses of window elements 0..3 in
+// the transposed tile: element m sits in sub-array (u + m) & 3, i.e. in the sub-array of element m & 3, (m >> 2) cells further
+// on -- so the four alignments u & 3 of a window share ONE body whose LDS offsets are immediates, and the alignment only
+// enters the four base addresses (4 VALU additions per term; the merged four-case body the compiler built before spent 109
+// address additions per 192 FMAs, and this kernel is VALU-issue bound: one wave64 instruction per SIMD per 4 cycles).
+template <int NR>
+__device__ __forceinline__ void tdp4_term(const char* __restrict__ q0, const char* __restrict__ q1, const char* __restrict__ q2,
+                                          const char* __restrict__ q3, const double* __restrict__ c,
                                           const cd* __restrict__ gv, int gstride, double (&ar)[NR][TDP_R],
                                           double (&ai)[NR][TDP_R]) {
   constexpr int R = TDP_R, W = TDP_FLEN + R - 1;
   double wr[W], wi[W];
 #pragma unroll
   for (int m = 0; m < W; ++m) {
-    constexpr int dummy = 0;
-    const int cc = (U0 + m) & (R - 1), qo = (U0 + m) >> 2;
-    const cd* pc = cc == 0 ? p0 : (cc == 1 ? p1 : (cc == 2 ? p2 : p3));
-    const cd v = pc[qo + dummy];
+    const char* qk = (m & 3) == 0 ? q0 : ((m & 3) == 1 ? q1 : ((m & 3) == 2 ? q2 : q3));
+    const cd v = *(const cd*)(qk + (m >> 2) * (int)sizeof(cd));
     wr[m] = v.re;
     wi[m] = v.im;
   }
@@ -312,7 +313,8 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
   }
   __syncthreads();
   // the workgroup's waves split the transmit antennas between them (same staged tile, twice the waves per CU)
-  const int ts = (int)threadIdx.x % TDP_TILE, grp = (int)threadIdx.x / TDP_TILE;
+  const int ts = (int)threadIdx.x % TDP_TILE;
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / TDP_TILE);      // whole waves: taps / gains addresses are scalar
   const int n = n0 + R * ts;
   double ar[NR][R], ai[NR][R];
 #pragma unroll
@@ -321,19 +323,18 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
     for (int j = 0; j < R; ++j) ar[r][j] = ai[r][j] = 0.0;
   const cd* gb = gains1 + ((size_t)b * g.n_sets + set) * NR * nt * n_paths;
   if (n < n_end) {
+    const char* xl = (const char*)(xs + ts);          // the thread's cell of sub-array 0 of antenna 0
     for (int t = grp; t < nt; t += TDP_GROUPS) {
       for (int p = 0; p < n_paths; ++p) {
         const int u = hist - tap_off[p] - (TDP_FLEN - 1);   // window element m is sample  R*ts + u + m  of the tile
         const double* c = taps + (size_t)p * TDP_FLEN;
-        const cd* base = xs + (size_t)t * R * Q + (u >> 2) + ts;
-        const cd *p0 = base, *p1 = base + Q, *p2 = base + 2 * Q, *p3 = base + 3 * Q;
+        // byte offsets (wave-uniform) of window elements 0..3: sub-array (u + k) & 3, cell (u + k) >> 2
+        const int o0 = ((t * R + ((u + 0) & 3)) * Q + ((u + 0) >> 2)) * (int)sizeof(cd);
+        const int o1 = ((t * R + ((u + 1) & 3)) * Q + ((u + 1) >> 2)) * (int)sizeof(cd);
+        const int o2 = ((t * R + ((u + 2) & 3)) * Q + ((u + 2) >> 2)) * (int)sizeof(cd);
+        const int o3 = ((t * R + ((u + 3) & 3)) * Q + ((u + 3) >> 2)) * (int)sizeof(cd);
         const cd* gv = gb + (size_t)t * n_paths + p;
-        switch (u & 3) {   // wave-uniform
-          case 0: tdp4_term<NR, 0>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
-          case 1: tdp4_term<NR, 1>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
-          case 2: tdp4_term<NR, 2>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
-          default: tdp4_term<NR, 3>(p0, p1, p2, p3, c, gv, nt * n_paths, ar, ai); break;
-        }
+        tdp4_term<NR>(xl + o0, xl + o1, xl + o2, xl + o3, c, gv, nt * n_paths, ar, ai);
       }
     }
   }

@@ -265,8 +265,8 @@ class PdschLink:
         return (counters, det) if details else counters
 
     def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details, harq=None):
-        """One batch of slots with identical geometry.  ``harq`` = (rv, circ, reset): per-slot redundancy versions
-        (int32 device tensor), the resident soft buffers and the restart flags of a batched HARQ round."""
+        """One batch of slots with identical geometry.  ``harq`` = one (rv, circ, reset) per codeword: per-slot redundancy
+        versions (int32 device tensor), the resident soft buffers and the restart flags of a batched HARQ round."""
         dev, cfg = self.dev, self.cfg
         n = len(slots)
         sis = int(slots[0]) % self.bwp.slotsPerSubFrame
@@ -278,10 +278,8 @@ class PdschLink:
             if np.isscalar(snr_db) else D(10.0 ** (np.float64(snr_db) / 10.0))
 
         # ---- Tx
-        if self.numCW > 1 and harq is not None:
-            raise NotImplementedError("run_harq: two-codeword PDSCH is not built")
         grid = None if self.numCW == 1 else self.templates.index_select(0, sif)   # DMRS-filled (n, Nl, L, K)
-        tbs_in = []
+        tbs_in, tx_bits = [], []
         for q, cw in enumerate(self.cw):
             if tb_bits is None:     # stream ids: 1 = first codeword (as before), 3 = second; 2 is the noise
                 tb = ops.random_bits(n, cw['tbs'], seed, dev, stream_id=1 + 2 * q, batch_offset=int(slots[0]), item_ids=ids)
@@ -290,7 +288,8 @@ class PdschLink:
             tbs_in.append(tb)
             # (first transmissions send nothing beyond the columns of the active rows: their parity is not computed)
             coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'], rows=cw['rows'] if harq is None else None)
-            bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[0])
+            bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[q][0])
+            tx_bits.append(bits)
             if grid is None:    # one codeword: template + scramble + modulate + layer/RE map in one pass over the grid
                 if self.re_planes is None:
                     self.re_planes = ops.layer_planes(self.re_inv, self.templates.shape[1])
@@ -373,13 +372,13 @@ class PdschLink:
             if harq is None:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'])
             else:
-                rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'], rv=harq[0], circ=harq[1], reset=harq[2])
+                rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'], rv=harq[q][0], circ=harq[q][1], reset=harq[q][2])
             rows = cw['rows'] if harq is None else None        # HARQ soft buffers fill other columns: all rows
             if harq is not None and self.firstPassIter is None and cw['rows'] is not None:
                 # ... of the retransmissions.  A process that starts a new block holds rv 0 alone in a fresh buffer, which is
                 # the single-shot case: the rows whose parity is punctured are exact no-ops there as well, and the truncated
                 # graph has the on-chip float64 instantiation.  One small host read per round (n_proc flags) splits the batch.
-                fresh = harq[2].to(torch.bool).cpu()
+                fresh = harq[q][2].to(torch.bool).cpu()
                 cbs = torch.arange(rr.shape[0], device=rr.device).reshape(-1, ccfg.C)
                 i_new, i_re = cbs[fresh].reshape(-1), cbs[~fresh].reshape(-1)
                 dec = None
@@ -409,71 +408,133 @@ class PdschLink:
                 ops.count_errors(cb_ok, tb_out, tbs_in[q], counters)
             per_cw.append(dict(tb=tbs_in[q], cb_ok=cb_ok, tb_out=tb_out, llr=llr))
         cb_ok = per_cw[0]['cb_ok']
-        if details == "verdicts":       # per-code-block CRC verdicts only (nothing extra is materialised)
-            return dict(cb_ok=cb_ok) if self.numCW == 1 else dict(cb_ok=cb_ok, cw=[dict(cb_ok=c['cb_ok']) for c in per_cw])
+        if details == "verdicts":       # per-code-block CRC verdicts + decoded transport blocks (nothing extra is materialised)
+            d = dict(cb_ok=cb_ok, tb_out=per_cw[0]['tb_out'])
+            if self.numCW > 1:
+                d['cw'] = [dict(cb_ok=c['cb_ok'], tb_out=c['tb_out']) for c in per_cw]
+            return d
         if details:
             d = dict(per_cw[0], eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv, sigma=sigma, grid=grid)
             if self.numCW > 1:
                 d['cw'] = per_cw
             return d
-        return dict(cb_ok=cb_ok) if harq is not None else None
+        if harq is not None:
+            return dict(cw=[dict(cb_ok=c['cb_ok'], tb_out=c['tb_out'], llr=c['llr'], bits=tx_bits[q]) for q, c in enumerate(per_cw)])
+        return None
 
     # ----------------------------------------------------------------------------------------------- HARQ
     def run_harq(self, n_proc, n_rounds, snr_db, seed=0, rvSequence=(0, 2, 3, 1), maxTries=4, harqType="IR", slot0=0,
-                 state=None):
+                 state=None, tb_bits=None, noise=None, trace=None):
         """Batched HARQ (reference harq.py + Playground/HARQ/Harq.ipynb loop) for ``n_proc`` HARQ processes.
 
         Round k transmits slots slot0 + k*n_proc + p, p = 0..n_proc-1, one per process -- the reference's round-robin
-        (harq.py:626-631) -- in one batch.  Per process the state is what ``HarqCW`` keeps (harq.py:145-202): the
-        transport block being sent, the try counter, and the soft buffer the decoder accumulates into; all of it stays
+        (harq.py:626-631) -- in one batch.  Per process and codeword the state is what ``HarqCW`` keeps (harq.py:145-202):
+        the transport block being sent, the try counter, and the soft buffer the decoder accumulates into; all of it stays
         on the GPU (soft buffers: n_proc*C x (Ncb-F) LLRs resident in HBM), and the retransmission decision is taken
         on the device; the one host read per round is the n_proc "new block" flags that let the decoder run first
-        transmissions on the truncated graph (they are the single-shot case).  A process whose block decodes (every
-        code-block CRC passes) or times out after ``maxTries`` starts a new block in its next round.
+        transmissions on the truncated graph (they are the single-shot case).  A codeword whose block decodes (every
+        code-block CRC passes) or times out after ``maxTries`` starts a new block in its next round.  A PDSCH with more
+        than 4 layers carries two codewords per process, each with its own try counter, redundancy version and buffer
+        (harq.py:477); the statistics add them up like ``HarqEntity`` does.
+
+        Parity mode: ``tb_bits`` (n_rounds, n_proc, TBS) -- a list of two such tensors for two codewords -- are the NEW
+        transport blocks offered to the processes in each round (taken by the codewords that start a new block, like
+        ``random.bits`` in the notebook loop) and ``noise`` (n_rounds, n_proc, Nr, samples) the standard-normal complex noise
+        of every slot; ``trace`` (a list) receives one dict per round: rv / new flags / LLRs / CRC verdicts per codeword and a
+        copy of the soft buffers after the round.
 
         Returns (stats, state): stats with the fields of ``HarqEntity`` (txBlocks/rxBlocks/txBits/rxBits per try,
         numTimeouts, throughput and BLER in percent, meanTries); pass ``state`` back in to continue the run."""
-        dev, cfg = self.dev, self.cfg
-        if len({tuple(v) for v in self.sym_lens}) != 1:
-            raise NotImplementedError("run_harq: slots of one round must share their symbol geometry (mu <= 1)")
+        dev = self.dev
         if harqType not in ("IR", "CC"):
             raise ValueError("harqType must be 'IR' or 'CC'")
         rvs = torch.tensor(list(rvSequence) if harqType == "IR" else [0], dtype=torch.int32, device=dev)
+        ncw = self.numCW
         if state is None:
             ft = torch.float32 if self.decoder == "f32" else torch.float64
-            state = dict(tb=torch.zeros((n_proc, self.tbs), dtype=torch.uint8, device=dev),
-                         tries=torch.zeros(n_proc, dtype=torch.int64, device=dev),
-                         circ=torch.zeros((n_proc * cfg.C, cfg.N - cfg.F), dtype=ft, device=dev),
-                         tx=torch.zeros(maxTries, dtype=torch.int64, device=dev),
-                         rx=torch.zeros(maxTries, dtype=torch.int64, device=dev),
+            state = dict(tb=[torch.zeros((n_proc, c['tbs']), dtype=torch.uint8, device=dev) for c in self.cw],
+                         tries=[torch.zeros(n_proc, dtype=torch.int64, device=dev) for _ in self.cw],
+                         circ=[torch.zeros((n_proc * c['cfg'].C, c['cfg'].N - c['cfg'].F), dtype=ft, device=dev) for c in self.cw],
+                         tx=torch.zeros(maxTries, dtype=torch.int64, device=dev), rx=torch.zeros(maxTries, dtype=torch.int64, device=dev),
+                         tx_bits=torch.zeros(maxTries, dtype=torch.int64, device=dev),
+                         rx_bits=torch.zeros(maxTries, dtype=torch.int64, device=dev),
                          timeouts=torch.zeros(1, dtype=torch.int64, device=dev), next_slot=int(slot0))
-        elif state['tb'].shape[0] != n_proc or state['tx'].numel() != maxTries:
-            raise ValueError("state does not belong to this (n_proc, maxTries) configuration")
+        elif state['tb'][0].shape[0] != n_proc or state['tx'].numel() != maxTries or len(state['tb']) != ncw:
+            raise ValueError("state does not belong to this (n_proc, maxTries, codewords) configuration")
+        if tb_bits is not None and not isinstance(tb_bits, (list, tuple)):
+            tb_bits = [tb_bits]
+        if tb_bits is not None and (len(tb_bits) != ncw or any(t.shape[0] < n_rounds or t.shape[1] != n_proc for t in tb_bits)):
+            raise ValueError("tb_bits: one (n_rounds, n_proc, TBS) tensor per codeword")
+        if noise is not None and (noise.shape[0] < n_rounds or noise.shape[1] != n_proc):
+            raise ValueError("noise: (n_rounds, n_proc, Nr, samples)")
         ones = torch.ones(n_proc, dtype=torch.int64, device=dev)
-        for _ in range(n_rounds):
+        spsf = self.bwp.slotsPerSubFrame
+        for k in range(n_rounds):
             s0 = state['next_slot']
             slots = np.arange(s0, s0 + n_proc)
-            tries = state['tries']
-            new = tries == 0
-            fresh = ops.random_bits(n_proc, self.tbs, seed, dev, stream_id=1, batch_offset=s0)
-            state['tb'] = torch.where(new[:, None], fresh, state['tb'])
-            # a new block always starts at rv 0 (HarqCW.reset, harq.py:119); rvSequence is consulted for retransmissions only
-            # (harq.py:199, 580-583)
-            rv = torch.where(new, torch.zeros_like(rvs[0]), rvs[tries % rvs.numel()]).contiguous()
-            out = self._run_group(slots, snr_db, seed, state['tb'], None, None, False,
-                                  harq=(rv, state['circ'], new.to(torch.uint8)))
-            ok = out['cb_ok'].reshape(n_proc, cfg.C).to(torch.bool).all(1)
-            state['tx'].index_add_(0, tries, ones)                                  # harq.py:185-186
-            state['rx'].index_add_(0, tries, ok.to(torch.int64))                    # harq.py:187-190
-            nxt = tries + 1
-            timeout = (~ok) & (nxt == maxTries)                                     # harq.py:196-199
-            state['timeouts'] += timeout.sum()
-            state['tries'] = torch.where(ok | timeout, torch.zeros_like(nxt), nxt)
+            new, rv = [], []
+            for q, c in enumerate(self.cw):
+                tries = state['tries'][q]
+                nq = tries == 0
+                if tb_bits is None:     # (stream ids as in run(): 1 = first codeword, 3 = second)
+                    fresh = ops.random_bits(n_proc, c['tbs'], seed, dev, stream_id=1 + 2 * q, batch_offset=s0)
+                else:
+                    fresh = tb_bits[q][k].to(dev).to(torch.uint8)
+                state['tb'][q] = torch.where(nq[:, None], fresh, state['tb'][q])
+                # a new block always starts at rv 0 (HarqCW.reset, harq.py:119); rvSequence is consulted for retransmissions only
+                # (harq.py:199, 580-583)
+                rv.append(torch.where(nq, torch.zeros_like(rvs[0]), rvs[tries % rvs.numel()]).contiguous())
+                new.append(nq)
+            # one sub-batch per slot geometry (a single one for mu <= 1): the soft buffers of a sub-batch's processes are
+            # gathered, combined into, and written back
+            geoms = {}
+            for i, n in enumerate(slots):
+                geoms.setdefault(tuple(self.sym_lens[n % spsf]), []).append(i)
+            oks = [torch.zeros(n_proc, dtype=torch.bool, device=dev) for _ in self.cw]
+            outs = {}
+            for _, sel in geoms.items():
+                whole = len(sel) == n_proc
+                sel_t = torch.as_tensor(sel, dtype=torch.int64, device=dev)
+                hq, rows_of = [], []
+                for q, c in enumerate(self.cw):
+                    C = c['cfg'].C
+                    if whole:
+                        circ_q, rws = state['circ'][q], None
+                    else:
+                        rws = (sel_t[:, None] * C + torch.arange(C, device=dev)[None, :]).reshape(-1)
+                        circ_q = state['circ'][q].index_select(0, rws)
+                    rows_of.append(rws)
+                    hq.append((rv[q] if whole else rv[q][sel_t].contiguous(), circ_q,
+                               (new[q] if whole else new[q][sel_t]).to(torch.uint8).contiguous()))
+                tbs_sel = [t if whole else t[sel_t] for t in state['tb']]
+                out = self._run_group(slots[np.asarray(sel)], snr_db, seed, tbs_sel if ncw > 1 else tbs_sel[0],
+                                      None if noise is None else (noise[k] if whole else noise[k][sel_t.to(noise.device)]), None, False, harq=hq)
+                for q, c in enumerate(self.cw):
+                    if not whole:
+                        state['circ'][q].index_copy_(0, rows_of[q], hq[q][1])
+                    okq = out['cw'][q]['cb_ok'].reshape(len(sel), c['cfg'].C).to(torch.bool).all(1)
+                    oks[q] = okq if whole else oks[q].index_copy(0, sel_t, okq)
+                outs[tuple(sel)] = out
+            for q, c in enumerate(self.cw):
+                tries, ok = state['tries'][q], oks[q]
+                state['tx'].index_add_(0, tries, ones)                                  # harq.py:185-186
+                state['rx'].index_add_(0, tries, ok.to(torch.int64))                    # harq.py:187-190
+                state['tx_bits'].index_add_(0, tries, ones * c['tbs'])
+                state['rx_bits'].index_add_(0, tries, ok.to(torch.int64) * c['tbs'])
+                nxt = tries + 1
+                timeout = (~ok) & (nxt == maxTries)                                     # harq.py:196-199
+                state['timeouts'] += timeout.sum()
+                state['tries'][q] = torch.where(ok | timeout, torch.zeros_like(nxt), nxt)
+            if trace is not None:
+                trace.append(dict(slots=slots.copy(), rv=[r.clone() for r in rv], new=[n.clone() for n in new], ok=[o.clone() for o in oks],
+                                  groups={g: [dict(llr=c['llr'], cb_ok=c['cb_ok'], tb_out=c['tb_out'], bits=c['bits']) for c in o['cw']] for g, o in outs.items()},
+                                  circ=[c.clone() for c in state['circ']], tb=[t.clone() for t in state['tb']]))
             state['next_slot'] = s0 + n_proc
         tx, rx = state['tx'].cpu().numpy(), state['rx'].cpu().numpy()
+        txb, rxb = state['tx_bits'].cpu().numpy(), state['rx_bits'].cpu().numpy()
         nto = int(state['timeouts'].item())
-        stats = dict(txBlocks=tx, rxBlocks=rx, txBits=tx * self.tbs, rxBits=rx * self.tbs, numTimeouts=nto,
-                     throughput=100.0 * rx.sum() / max(tx.sum(), 1), bler=100.0 * (tx.sum() - rx.sum()) / max(tx.sum(), 1),
+        stats = dict(txBlocks=tx, rxBlocks=rx, txBits=txb, rxBits=rxb, numTimeouts=nto,
+                     throughput=100.0 * rxb.sum() / max(txb.sum(), 1), bler=100.0 * (tx.sum() - rx.sum()) / max(tx.sum(), 1),
                      meanTries=float(((rx * np.arange(maxTries)).sum() + nto * maxTries) / max(rx.sum() + nto, 1)))
         return stats, state
 
@@ -506,6 +567,6 @@ def run_sweep(link, snrs_db, n_slots, seed=0, batch=64, slot0=0):
             nb = min(int(batch), cnt - done)
             link.run(lo + done, nb, float(snr), seed=seed, counters=table[i])
             done += nb
-    if on and world > 1:
+    if on:      # (also with a single rank: the collective is the same code path whatever the world size)
         dist.all_reduce(table)
     return table.cpu().numpy()

@@ -125,3 +125,50 @@ def test_cfg3_link_at_273_prb(dev):
     ls = nr.PdschLink(p, ch, 0.75, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS", decoder="f64")
     lo = ls.run(0, 2, 60.0, seed=5).cpu().numpy()
     assert lo[0] == lo[1] == 2 * 113
+
+
+def test_headline_path_at_273_prb_against_separate_stages_and_oracle(dev):
+    """The path bench.py times -- float64 chain, demapper writing per code block (nrx_qam_demap_cb_f64), rate recovery + on-chip
+    decode + CRC/merge in one launch (nrx_ldpc_recover_decode_merge_f64), 50 iterations -- at the metric configuration, on host-
+    supplied transport blocks and noise (parity mode):
+      (i)  CRC verdicts and decoded transport-block bits identical to the separate stages (details=True: symbol-major demapper,
+           nrx_ldpc_rate_recover_f64, nrx_ldpc_decode_f64, nrx_ldpc_crc_merge) at a waterfall SNR where blocks fail;
+      (ii) at a clear-cut SNR the CRC vector equals oracle.link.run_slot's and the LLRs agree to 1e-9 of the slot's scale."""
+    import torch
+    import bench
+    import neoradium_amd as nr
+    from neoradium_amd._dev import D
+    from neoradium_amd import ops
+    from oracle import link as olink
+    link = bench.build_link(nr, decoder="f64", num_iter=50)
+    cw = link.cw[0]
+    assert ops.ldpc_fused_supported(cw['cfg'], cw['nl'], cw['qm'], cw['G'], cw['rows']) and cw['rows'] == 15
+    rng = np.random.default_rng(2026)
+    n = 2
+    tb = rng.integers(0, 2, (n, link.tbs)).astype(np.uint8)
+    z = rng.standard_normal((n, link.nr, link.slot_len[0] + link.max_delay, 2))
+    zc = z[..., 0] + 1j * z[..., 1]
+    tbt, zt = torch.from_numpy(tb), D(zc)
+    # (i) waterfall: some of the 144 blocks fail, non-converging blocks included
+    c_f, dv = link.run(5, n, 31.0, tb_bits=tbt, noise=zt, details="verdicts")
+    c_s, ds = link.run(5, n, 31.0, tb_bits=tbt, noise=zt, details=True)
+    v, s = dv[0][1], ds[0][1]
+    assert torch.equal(v['cb_ok'], s['cb_ok']) and torch.equal(v['tb_out'], s['tb_out']) and torch.equal(c_f, c_s)
+    n_ok = int(v['cb_ok'].sum())
+    assert 0 < n_ok < v['cb_ok'].numel(), f"want passing and failing blocks at 31 dB, got {n_ok}"
+    # (ii) clear-cut SNR against the CPU oracle (its own Tx chain, channel, estimator, equaliser, demapper, decoder)
+    _, dv = link.run(5, n, 38.0, tb_bits=tbt, noise=zt, details="verdicts")
+    _, ds = link.run(5, n, 38.0, tb_bits=tbt, noise=zt, details=True)
+    v, s = dv[0][1], ds[0][1]
+    assert torch.equal(v['cb_ok'], s['cb_ok']) and torch.equal(v['tb_out'], s['tb_out'])
+    st = olink.static_from_link(link, slots=range(5, 5 + n))
+    F = s['F'].cpu().numpy()
+    jobs = [(st, 5 + i, 38.0, tb[i].astype(np.int8), zc[i], F[i]) for i in range(n)]
+    refs = olink.run_slots_parallel(jobs, n)
+    for i, ref in enumerate(refs):
+        got = s['llr'][i].cpu().numpy()
+        scale = np.abs(ref['llr']).max()
+        assert np.abs(got - ref['llr']).max() <= 1e-9 * scale
+        assert np.array_equal(v['cb_ok'][i].cpu().numpy().astype(bool), ref['crc'])
+        nb = len(ref['tb_out'])
+        assert np.array_equal(v['tb_out'][i].cpu().numpy()[:nb], ref['tb_out'].astype(np.uint8))
