@@ -261,17 +261,19 @@ __device__ __forceinline__ fargs_t fuse_args() {
   return (fargs_t)(ka + offsetof(KernArgs, fa));
 }
 
-// NS = 2 code blocks per workgroup (2 x Zc/64 waves).  Lane z of a code block's waves = check row z of every layer.
+// NS code blocks per workgroup (NS x Zc/64 waves).  Lane z of a code block's waves = check row z of every layer.
+// NS = 2 (<= 168 VGPRs, three waves per SIMD) serves the truncated graphs.  (All 46 rows on chip was tried with NS = 1: their state,
+// ~330 registers per lane, does not fit -- a 6-wave workgroup puts two waves on two of the SIMDs, so a wave gets 256 of the 512
+// unified registers, the rest went to scratch and the kernel was slower than the workspace kernel, 146.6 against 137.5 ms.)
 // FUSED = false: llr = rate-recovered LLRs (n_cb, N), hard = (n_cb, K) hard decisions.
 // FUSED = true:  llr = demapper output (n_tb, llr_len), tb_out = (n_tb, C*payload) merged hard bits, cb_ok = (n_cb,).
-template <int BG, int ZI, int RA, bool FUSED>
-__global__ void __launch_bounds__(2 * kZ.z[ZI], 3)
+template <int BG, int ZI, int RA, bool FUSED, int NS = 2>
+__global__ void __launch_bounds__(NS * kZ.z[ZI], NS == 2 ? 3 : 1)
 ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint8_t* __restrict__ hard, mtab_t wtab,
                        FuseArgs /* read through fuse_args() */) {
   static_assert(ext_shifts_are_zero<BG>(), "extension columns are expected to be unshifted");
   using B = GR<BG, RA>;
   using Y = Lay<BG, RA>;
-  constexpr int NS = 2;
   constexpr int ZC = kZ.z[ZI];
   constexpr int ILS = kZ.ils[ZI];
   static_assert(ZC % 64 == 0, "whole waves only: a lane beyond Zc would write into a live element");
@@ -616,9 +618,9 @@ int32_t wrap_table(int n_rows, const uint64_t** out) {
   return NRX_OK;
 }
 
-bool chip64_covers(const nrx_ldpc_cfg* cfg, int n_rows) {
+bool chip64_covers(const nrx_ldpc_cfg* cfg, int n_rows, int max_rows = 15) {
   const bool off = getenv("NRX_LDPC_NOCHIP64") != nullptr;      // developer switch (read at every call): always the workspace kernel
-  return !off && cfg->bg == 1 && cfg->Zc == 384 && cfg->iLS == 1 && n_rows <= 15;
+  return !off && cfg->bg == 1 && cfg->Zc == 384 && cfg->iLS == 1 && n_rows <= max_rows;
 }
 
 }  // namespace nrx_dec3
@@ -632,11 +634,11 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
   const uint64_t* wt = nullptr;
   const int32_t rc = wrap_table(n_rows, &wt);
   if (rc) return rc;
-  const int n_wg = (n_cb + 1) / 2;
-  const int grid = n_wg < 1024 ? n_wg : 1024;
   constexpr int ZI384 = zindex_c(384);
   FuseArgs fa{};
   fa.g.rows_live = n_rows;
+  const int n_wg = (n_cb + 1) / 2;
+  const int grid = n_wg < 1024 ? n_wg : 1024;
   if (n_rows <= 13)
     hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 13, false>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard, (mtab_t)wt, fa);
   else

@@ -65,6 +65,8 @@ def ldpc_encode(cbs, cfg, puncture=True, rows=None):
     width = cfg.N if puncture else cfg.N + 2 * cfg.Zc
     out = torch.empty((cbs.shape[0], width), dtype=torch.uint8, device=_dev(cbs))
     check(lib().nrx_ldpc_encode(ptr(cbs), cbs.shape[0], C.byref(cfg), 1 if puncture else 0, int(rows or 0), ptr(out), stream()))
+    if rows:
+        out._nrx_rows = int(rows)          # the columns of the other rows are unwritten: ldpc_rate_match refuses to read them
     return out
 
 
@@ -84,6 +86,12 @@ def ldpc_rate_match(coded, cfg, G, nl, qm, rv=0, nref=0):
     f = nl * qm
     gout = ((G + f - 1) // f) * f
     dev = _dev(coded)
+    part = getattr(coded, '_nrx_rows', None)
+    if part is not None:       # a rows-truncated encode holds the parity of its first rows only: rv 0 without wrap-around may read it
+        need = ldpc_active_rows(cfg, max(_lib.ldpc_cb_lens(int(G), cfg.C, nl, qm))) if (not torch.is_tensor(rv) and rv == 0 and nref == 0) \
+            else (46 if cfg.bg == 1 else 42)
+        if need > part:
+            raise ValueError(f"ldpc_rate_match: the coded blocks hold the parity of {part} base-graph rows, this transmission reads {need}")
     out = torch.empty((n_tb, gout), dtype=torch.uint8, device=dev)
     if torch.is_tensor(rv):
         check(lib().nrx_ldpc_rate_match_harq(ptr(coded), n_tb, C.byref(cfg), int(G), nl, qm, ptr(_rv_array(rv, n_tb, dev)),
