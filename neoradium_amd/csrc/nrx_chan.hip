@@ -263,8 +263,13 @@ __device__ __forceinline__ void tdp4_term(const char* __restrict__ q0, const cha
   double wr[W], wi[W];
 #pragma unroll
   for (int m = 0; m < W; ++m) {
-    const char* qk = (m & 3) == 0 ? q0 : ((m & 3) == 1 ? q1 : ((m & 3) == 2 ? q2 : q3));
-    const cd v = *(const cd*)(qk + (m >> 2) * (int)sizeof(cd));
+#ifdef NRX_TD_ABLATE_LDS      // timing experiment (wrong results): half of the window reads
+    const int mm = m & ~1;
+#else
+    const int mm = m;
+#endif
+    const char* qk = (mm & 3) == 0 ? q0 : ((mm & 3) == 1 ? q1 : ((mm & 3) == 2 ? q2 : q3));
+    const cd v = *(const cd*)(qk + (mm >> 2) * (int)sizeof(cd));
     wr[m] = v.re;
     wi[m] = v.im;
   }
@@ -273,7 +278,11 @@ __device__ __forceinline__ void tdp4_term(const char* __restrict__ q0, const cha
   for (int j = 0; j < R; ++j) fr[j] = fi[j] = 0.0;
 #pragma unroll
   for (int k = 0; k < TDP_FLEN; ++k) {
+#ifdef NRX_TD_ABLATE_TAPS     // timing experiment (wrong results): no scalar tap loads
+    const double ck = 0.25 + k;
+#else
     const double ck = c[k];
+#endif
 #pragma unroll
     for (int j = 0; j < R; ++j) {   // x[n + j - off - k] = window element 15 + j - k
       fr[j] = fma(ck, wr[TDP_FLEN - 1 + j - k], fr[j]);

@@ -126,6 +126,68 @@ __device__ __forceinline__ uint32_t dbl(uint32_t w) {   // w + w as an add the o
   asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(w));
   return r;
 }
+// ---- round 3 (as nrx_ldpc_dec3.hip, section "Messages as unit x pm"): a row keeps pm1 / pm2 = 0.75*min1 / 0.75*min2 with the
+// row's sign parity as their sign; a message is u_j * pm with the unit u_j = +-1.0f carrying sign(t_j), applied by a fused
+// multiply-add (the product is exact, so it rounds like the add / subtract of the signed message); the argmin lanes are put
+// into EXEC by a v_cmpx and redo the operation with pm2.  Two VALU instructions per edge-visit fewer than select + sign insert
+// + parity xor + sign collect (the SIMD issues one VALU instruction per 4 cycles whatever the kind).
+__device__ __forceinline__ float unit_of(uint32_t signsrc) {   // +-1.0f with the sign of bit 31 of signsrc
+  uint32_t h;
+  asm("v_and_or_b32 %0, %1, %2, 1.0" : "=v"(h) : "v"(signsrc), "s"(0x80000000u));
+  return __uint_as_float(h);
+}
+__device__ __forceinline__ float c75_of(uint32_t signbits) {   // +-0.75f, negative for an odd number of set sign bits
+  uint32_t h;
+  asm("v_lshl_or_b32 %0, %1, 31, %2" : "=v"(h) : "v"((uint32_t)__builtin_popcount(signbits)), "s"(0x3f400000u));
+  return __uint_as_float(h);
+}
+// fma(-u, oidx == J ? p2 : p1, x)   (all 64 lanes are live: EXEC is -1 around the block)
+template <int J>
+__device__ __forceinline__ float sel_fnma_x(float x, uint32_t oidx, float u, float p1, float p2) {
+  float y;
+  asm("v_fma_f32 %[y], -%[u], %[p1], %[x]\n\t"
+      "v_cmpx_eq_u32_e32 vcc, %[j], %[oidx]\n\t"
+      "v_fma_f32 %[y], -%[u], %[p2], %[x]\n\t"
+      "s_mov_b64 exec, -1"
+      : [y] "=&v"(y) : [x] "v"(x), [j] "n"(J), [oidx] "v"(oidx), [u] "v"(u), [p1] "v"(p1), [p2] "v"(p2) : "vcc");
+  return y;
+}
+// fma(u, |x| == a ? p2 : p1, x); idx <- J where |x| == a (every entry equal to the minimum takes p2: with a tie min2 == min1)
+template <int J>
+__device__ __forceinline__ float sel_fma_x(float x, uint32_t& idx, float a, float u, float p1, float p2) {
+  float y;
+  asm("v_fma_f32 %[y], %[u], %[p1], %[x]\n\t"
+      "v_cmpx_eq_f32_e64 vcc, |%[x]|, %[a]\n\t"
+      "v_fma_f32 %[y], %[u], %[p2], %[x]\n\t"
+      "v_mov_b32 %[idx], %[j]\n\t"
+      "s_mov_b64 exec, -1"
+      : [y] "=&v"(y), [idx] "+v"(idx) : [x] "v"(x), [a] "v"(a), [j] "n"(J), [u] "v"(u), [p1] "v"(p1), [p2] "v"(p2) : "vcc");
+  return y;
+}
+// min / med3 written out: after an inline-asm producer the compiler cannot prove its inputs canonical and puts a v_max_f32 x, x, x
+// in front of every one (one extra VALU instruction per edge); no NaN reaches this code (LLRs are clipped on the way in)
+__device__ __forceinline__ float vmed3_abs(float a, float b, float t) {
+  float r;
+  asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+__device__ __forceinline__ float vmin_abs(float a, float t) {
+  float r;
+  asm("v_min_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
+// idx <- J where |x| == a (an extension edge: nothing is written back)
+template <int J>
+__device__ __forceinline__ void mark_min(float x, uint32_t& idx, float a) {
+  asm("v_cmpx_eq_f32_e64 vcc, |%[x]|, %[a]\n\t"
+      "v_mov_b32 %[idx], %[j]\n\t"
+      "s_mov_b64 exec, -1"
+      : [idx] "+v"(idx) : [x] "v"(x), [a] "v"(a), [j] "n"(J) : "vcc");
+}
+// wave priority falls with progress through a layer: the SIMD always serves its oldest ready wave, lowering a wave's priority as
+// it advances lets the waves that are behind go first and brings the waves of a SIMD to the layer's barrier together
+#define LAYER_PRIO(Q) __builtin_amdgcn_s_setprio(3 - (Q))
+
 __device__ __forceinline__ uint32_t wrap4(uint32_t a4, uint32_t zc4) {  // a4 in [0, 2*zc4)
   const uint32_t b = a4 - zc4;
   return a4 < b ? a4 : b;
@@ -272,6 +334,7 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
         float a1 = 0.0f, a2 = 0.0f;
         uint32_t px = 0, word = 0;
         if (__builtin_expect(live, 1)) {   // (wave-uniform; the per-layer branch also keeps each layer its own scheduling region)
+          LAYER_PRIO(0);
           // ---- pass 1a: issue every LDS read of the layer (last edge first: the order pass 1b consumes them in)
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = DC - 1 - decltype(jc)::value;
@@ -304,24 +367,15 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             oidx = (ni & 1) ? ((word >> 16) & 15u) : (word & 15u);
             top = (ni & 1) ? (31 - 20) : (31 - 4);
           }
-          // ---- pass 1b: t_j = r_j - msg_old_j.  All "was edge j the minimum" tests first, into SGPR pairs: a VALU
-          // write of VCC/SGPR needs two wait states before a v_cndmask may read it, batching avoids the s_nops.
-          bool was_min[DC > 0 ? DC : 1];
-          static_for<DC>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            was_min[j] = oidx == (uint32_t)j;
-          });
-          __builtin_amdgcn_sched_barrier(0);
-          // sign of edge j at bit 31 of a running word (last edge first, doubled per edge: an add issues at almost
-          // twice the rate of a shift on this chip, profiles/r1_valu_issue_rates.txt)
+          // ---- pass 1b: t_j = r_j - msg_old_j = fma(-u_j, argmin ? pm2 : pm1, r_j)  (ldpc.py:1550-1553)
+          // sign of t_j (previous iteration) at bit 31 of a running word (last edge first, doubled per edge)
           uint32_t wrun = word << (top - (DC > 0 ? DC - 1 : 0));
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = DC - 1 - decltype(jc)::value;
-            uint32_t wnext = 0;
-            if constexpr (j > 0) wnext = dbl(wrun);   // (issued ahead of its use: the word after an asm needs a wait state)
-            const float mag = was_min[j] ? om2 : om1;
-            t[j] = t[j] - sign_from(wrun, mag);
-            wrun = wnext;
+            const float u = unit_of(wrun);
+            if constexpr (j > 0) wrun = dbl(wrun);
+            if constexpr (decltype(jc)::value == (2 * DC) / 3) LAYER_PRIO(1);
+            t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
           });
           if constexpr (SPEC) {
             // every LDS read of this layer has been consumed: fetch the next layer's wrap masks (scalar loads share
@@ -339,16 +393,17 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
             // clip to +-1e10 (ldpc.py:1536); + 0.0f turns -0.0 into +0.0 (the reference's sign test is (v < 0))
             t[D - 1] = __builtin_amdgcn_fmed3f(epf[slot], -1e10f, 1e10f) + 0.0f;
           }
-          // ---- min-sum: two smallest magnitudes and the sign parity; no compares, no argmin here
-          a1 = __builtin_fabsf(t[0]);
+          // ---- min-sum: two smallest magnitudes; the signs of the t_j are collected (edge j ends at bit j), their parity is a
+          // population count; no compares, no argmin here
+          a1 = __builtin_fabsf(t[D - 1]);
           a2 = 3.0e38f;
-          px = __float_as_uint(t[0]);
+          px = __float_as_uint(t[D - 1]) >> 31;
           static_for<D - 1>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value + 1;
-            const float a = __builtin_fabsf(t[j]);
-            a2 = __builtin_amdgcn_fmed3f(a1, a2, a);                       // second minimum so far
-            a1 = __builtin_amdgcn_fmed3f(a1, a, -__builtin_inff());        // min(a1, a) without a canonicalising max
-            px ^= __float_as_uint(t[j]);
+            constexpr int j = D - 2 - decltype(jc)::value;
+            if constexpr (decltype(jc)::value == (D - 1) / 2) LAYER_PRIO(2);
+            a2 = vmed3_abs(a1, a2, t[j]);                                  // second minimum so far
+            a1 = vmin_abs(a1, t[j]);
+            px = __builtin_amdgcn_alignbit(px, __float_as_uint(t[j]), 31);  // (px << 1) | sign(t_j)
           });
           // QUIRK ldpc.py:1563 (second minimum taken after adding +100000 to the signed argmin entry): it can
           // only bite when every other entry exceeds ~5e4 (filler / saturated LLRs) -- wave-uniform cold path.
@@ -371,29 +426,21 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
           epf[Y::ext_idx(L) % PFN] = ext_load(Y::next_ext(L, PFN), z4);
         }
         if (__builtin_expect(live, 1)) {   // (second region: measured slightly faster than one region per layer)
-          const float nm1 = a1 * 0.75f, nm2 = a2 * 0.75f;
+          const float c75 = c75_of(px);                     // 0.75 (ldpc.py:1573) with the row parity as its sign
+          const float nm1 = a1 * c75, nm2 = a2 * c75;
           m1[L] = nm1;
           m2[L] = nm2;
-          // ---- pass 2 (last edge first): r_j = t_j + msg_new_j, written at the lane's own index of the column's
-          // other buffer (the column is now rotated by this layer's shift).  The minimum's position falls out of a
-          // magnitude test: an entry equal to min1 gets min2 (with ties min2 == min1, so every tied entry may take
-          // it); first such index = argmin.
-          bool is_min[D];
-          static_for<D>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            is_min[j] = __builtin_fabsf(t[j]) == a1;
-          });
-          __builtin_amdgcn_sched_barrier(0);
-          uint32_t nsg = 0, idx = 0;
+          // ---- pass 2 (last edge first): r_j = t_j + msg_new_j = fma(u_j, |t_j| == min1 ? pm2 : pm1, t_j), written at the lane's
+          // own index of the column's other buffer (the column is now rotated by this layer's shift).  An entry equal to min1
+          // gets min2 (with ties min2 == min1, so every tied entry may take it); first such index = argmin.
+          const uint32_t nsg = px;
+          uint32_t idx = 0;
           static_for<D>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = D - 1 - decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
-            const uint32_t sx = px ^ __float_as_uint(t[j]);   // bit 31 = parity ^ sign(t_j)
-            nsg = __builtin_amdgcn_alignbit(nsg, sx, 31);     // (nsg << 1) | (sx >> 31): edge j ends at bit j
-            idx = is_min[j] ? (uint32_t)j : idx;
+            if constexpr (decltype(jc)::value == (2 * D) / 3) LAYER_PRIO(3);
             if constexpr (col < B::CORE) {
-              const float mag = is_min[j] ? nm2 : nm1;
-              const float r = t[j] + sign_from(sx, mag);
+              const float r = sel_fma_x<j>(t[j], idx, a1, unit_of(__float_as_uint(t[j])), nm1, nm2);
               constexpr uint32_t wof = (uint32_t)(((Y::touch_par(L, col) ^ 1) * B::CORE + col) * ZS * 4);   // write buffer
               if constexpr (SPEC) {
                 if constexpr (wof < 65536) *(float*)((char*)Praw + zb + wof) = r;
@@ -401,6 +448,8 @@ ldpc_dec_fast_kernel(const float* __restrict__ llr, int n_cb, int zc_rt, int n_i
               } else {
                 *(float*)((char*)Ps + wof + z4) = r;
               }
+            } else {
+              mark_min<j>(t[j], idx, a1);
             }
           });
           if constexpr (WIDE) {

@@ -139,6 +139,11 @@ SL(sl_hi_regs, "v_add_f64 v[20:21],v[24:25],v[30:31]\n v_and_or_b32 v32,v36,v41,
                "v_alignbit_b32 v33,v37,v42,31\n v_max_f64 v[34:35],v[38:39],v[40:41]\n v_and_or_b32 v43,v44,v45,v46\n"
                "v_add_f64 v[46:47],v[24:25],v[28:29]\n v_cndmask_b32_e64 v36,v37,v38,s[20:21]\n")
 
+SL(sl_fmac64_sgpr, "v_fmac_f64_e32 v[20:21],s[20:21],v[40:41]\n v_fmac_f64_e32 v[22:23],s[20:21],v[42:43]\n v_fmac_f64_e32 v[24:25],s[24:25],v[40:41]\n v_fmac_f64_e32 v[26:27],s[24:25],v[42:43]\n"
+                     "v_fmac_f64_e32 v[28:29],s[20:21],v[44:45]\n v_fmac_f64_e32 v[30:31],s[20:21],v[46:47]\n v_fmac_f64_e32 v[32:33],s[24:25],v[44:45]\n v_fmac_f64_e32 v[34:35],s[24:25],v[46:47]\n")
+SL(sl_fmac64_vgpr, "v_fmac_f64_e32 v[20:21],v[36:37],v[40:41]\n v_fmac_f64_e32 v[22:23],v[36:37],v[42:43]\n v_fmac_f64_e32 v[24:25],v[38:39],v[40:41]\n v_fmac_f64_e32 v[26:27],v[38:39],v[42:43]\n"
+                     "v_fmac_f64_e32 v[28:29],v[36:37],v[44:45]\n v_fmac_f64_e32 v[30:31],v[36:37],v[46:47]\n v_fmac_f64_e32 v[32:33],v[38:39],v[44:45]\n v_fmac_f64_e32 v[34:35],v[38:39],v[46:47]\n")
+
 // clock check: s_memtime against s_memrealtime (100 MHz)
 __global__ void k_clock(unsigned long long* out, int iters) {
   unsigned long long t0, t1, r0, r1;
@@ -190,6 +195,7 @@ int main(int argc, char** argv) {
       C(sl_andor, 4096, 1, "straight-line v_and_or_b32"), C(sl_cnd64, 4096, 1, "straight-line v_cndmask_e64 sgpr"), C(sl_cmp64, 4096, 1, "straight-line v_cmp_eq_f64 -> sgpr"),
       C(sl_xor_add64, 4096, 1, "straight-line xor / add_f64 alternating"), C(sl_xor3_add64, 4096, 1, "straight-line 3 xor : 1 add_f64"),
       C(sl_add64_salu, 4096, 1, "straight-line add_f64 / s_or alternating (per instruction)"), C(sl_add64_nop, 4096, 1, "straight-line add_f64 / s_nop alternating"),
+      C(sl_fmac64_sgpr, 4096, 1, "straight-line v_fmac_f64 with an SGPR-pair multiplier"), C(sl_fmac64_vgpr, 4096, 1, "straight-line v_fmac_f64, all VGPR"),
       C(sl_dep_add64, 4096, 1, "straight-line dependent add_f64 chain"), C(sl_dep_chain, 4096, 1, "straight-line 2cnd->and_or->add_f64 chains"),
   };
   printf("%-12s %8s %8s %8s %8s   cycles (s_memtime) per unit per SIMD at W waves/SIMD | wall-clock at W=3\n", "case", "W=1", "W=2", "W=3", "W=4");
@@ -212,7 +218,7 @@ int main(int argc, char** argv) {
       std::vector<unsigned> hw(ncu * 4 * W);
       hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
       hipMemcpy(hw.data(), hwid, hw.size() * 4, hipMemcpyDeviceToHost);
-      if (!strcmp(c.name, "sl_add64") || !strcmp(c.name, "sl_xor_add64")) {      // per-wave view: is the issue bandwidth shared evenly?
+      if (!strcmp(c.name, "sl_add64") || !strcmp(c.name, "sl_xor_add64") || !strcmp(c.name, "sl_fmac64_sgpr") || !strcmp(c.name, "sl_fmac64_vgpr")) {      // per-wave view: is the issue bandwidth shared evenly?
         fprintf(stderr, "%s W=%d, workgroup 0: cycles per instruction of each wave [simd.waveslot]:", c.name, W);
         for (int i = 0; i < 4 * W; ++i)
           fprintf(stderr, " %u.%u:%.2f", (hw[i] >> 4) & 3u, hw[i] & 15u, (double)h[i] / ((double)iters * c.per_iter));
