@@ -1,10 +1,11 @@
 """Build libnrx.so (the C-ABI HIP library) in-tree for gfx950 with hipcc.
 
-    python -m neoradium_amd.build [--force]
+    python -m neoradium_amd.build [--force]          (NRX_FORCE_BUILD=1 does the same for __graft_entry__.build())
 
 One translation unit per csrc/*.hip, linked into neoradium_amd/libnrx.so.  No torch, no cmake: plain hipcc.
 `-ffp-contract=off` keeps float64 paths bit-identical to the NumPy reference (no FMA contraction).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libnrx.so')
+STAMP = os.path.join(HERE, 'libnrx.stamp')
 FLAGS = ['-std=c++20', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-mllvm', '-amdgpu-sdwa-peephole=0', '-fPIC', '-Wno-comment',
          '-Wno-unused-value']
 
@@ -26,11 +28,27 @@ def _newer(src, dst, deps):
     return any(os.path.getmtime(d) > t for d in [src] + deps)
 
 
+def source_hash():
+    """SHA-256 over the compile flags and every source / header the library is built from."""
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for f in sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.h'))
+                    + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
+    """Compile what is out of date (by modification time) and link.  `force` (or NRX_FORCE_BUILD=1 in the environment) recompiles
+    everything.  neoradium_amd/libnrx.stamp records the hash of the sources + flags the library was linked from: `stamp_ok()`
+    tells whether the library in the tree is the one these sources produce (a shipped binary can be checked against it)."""
+    force = force or os.environ.get('NRX_FORCE_BUILD', '') not in ('', '0')
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
     deps = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
+    if not force and stamp_ok():
+        return LIB          # the library in the tree was linked from exactly these sources and flags (objects may be absent: GPU box)
     jobs = []
     objs = []
     for s in srcs:
@@ -48,9 +66,14 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or not os.path.exists(LIB):
+    if jobs or force or not os.path.exists(LIB) or not stamp_ok():
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
+        open(STAMP, 'w').write(source_hash() + '\n')
     return LIB
+
+
+def stamp_ok():
+    return os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == source_hash()
 
 
 if __name__ == '__main__':
