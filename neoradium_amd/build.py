@@ -69,6 +69,11 @@ def build(force=False, verbose=True):
     if jobs or force or not os.path.exists(LIB) or not stamp_ok():
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
         open(STAMP, 'w').write(source_hash() + '\n')
+        # the decoder's instruction counts of THIS binary, for bench.py's VALU-issue roofline (best effort: needs llvm-objdump)
+        tool = os.path.join(HERE, '..', 'tools', 'isa_mix.py')
+        out = os.path.join(HERE, '..', 'profiles', 'r3_decoder_isa.json')
+        if os.path.exists(tool) and os.path.isdir(os.path.dirname(out)):
+            subprocess.run([sys.executable, tool, LIB, 'ldpc_dec', '--json', out], capture_output=True)
     return LIB
 
 
