@@ -300,6 +300,12 @@ __device__ __forceinline__ void tdp4_term(const char* __restrict__ q0, const cha
   }
 }
 
+#ifdef NRX_TD_CLOCK_PROBE
+__device__ unsigned long long g_td_probe[3];   // developer build: sum of s_memtime / s_memrealtime deltas over workgroups, count
+extern "C" int32_t nrx_debug_td_probe(unsigned long long* out3) {
+  return hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_td_probe), sizeof(unsigned long long) * 3) == hipSuccess ? 0 : -4;
+}
+#endif
 template <int NR>
 __global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS, 4)   // four waves per SIMD (two workgroups per CU): <= 128 VGPRs
 apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ gains1, int n_paths,
@@ -308,6 +314,10 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* xs = (cd*)smem;  // [nt][R][Q]
   constexpr int R = TDP_R;
+#ifdef NRX_TD_CLOCK_PROBE
+  unsigned long long pt0, pr0;
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(pt0), "=s"(pr0)::"memory");
+#endif
   const int b = blockIdx.y;
   const int set = blockIdx.x / g.tiles_per_set, tile = blockIdx.x % g.tiles_per_set;
   const int n0 = g.start[set] + tile * (TDP_TILE * R);
@@ -379,6 +389,15 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
       for (int j = 0; j < R; ++j)
         if (n + j < n_end) y[((size_t)b * NR + r) * ns + n + j] = cd(ar[r][j], ai[r][j]);
   }
+#ifdef NRX_TD_CLOCK_PROBE
+  unsigned long long pt1, pr1;
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(pt1), "=s"(pr1)::"memory");
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_td_probe[0], pt1 - pt0);
+    atomicAdd(&g_td_probe[1], pr1 - pr0);
+    atomicAdd(&g_td_probe[2], 1ull);
+  }
+#endif
 }
 
 int ilog2(int n) {

@@ -21,3 +21,10 @@ e0.record()
 for _ in range(5): y = f()
 e1.record(); torch.cuda.synchronize()
 print(f"apply_td_paths B={B} lib={os.environ.get('NRX_LIB','tree')}: {e0.elapsed_time(e1)/5:.3f} ms  checksum {float(y.abs().sum()):.6e}", flush=True)
+if os.environ.get('NRX_LIB') and 'probe' in os.environ['NRX_LIB']:
+    import ctypes
+    lib = ctypes.CDLL(os.environ['NRX_LIB'])
+    out = (ctypes.c_ulonglong * 3)()
+    lib.nrx_debug_td_probe(out)
+    t, r, n = [int(v) for v in out]
+    print(f"clock probe: {n} workgroups, mean lifetime {t / n:.0f} s_memtime cycles = {r / n / 100:.2f} us  =>  {t / (r / 100.0):.0f} MHz during the kernel")
