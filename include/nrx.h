@@ -353,6 +353,13 @@ int32_t nrx_channel_matrix_f64(const void* cir, int32_t n_items, int32_t n_t, in
 int32_t nrx_channel_matrix_sub_f64(const void* cir, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx,
                                    int32_t n_tx, int32_t cl, const int32_t* chan_offset, int32_t K, int32_t nfft,
                                    int32_t k0, int32_t n_k, void* H, void* stream);
+/* channelmodel.py:343-346 + :362-400 in one launch, without a CIR in memory (the time-domain link filters in path form and needs the
+ * CIR for nothing else): chan_offset (n_items) as nrx_cir_f64 computes it and H_sub (n_items,nc,n_k,n_rx,n_tx) as
+ * nrx_channel_matrix_sub_f64 does, bit-identical to that pair.  NRX_E_UNSUPPORTED unless n_k == 12, n_paths is 13, 14, 15, 23 or 24 (the CDL / TDL profiles) and the tap
+ * matrix + the (tap, subcarrier) twiddles fit 150 KB of LDS: the caller then runs the two separate entries. */
+int32_t nrx_chan_setup_f64(const void* gains, const double* coeff, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx,
+                           int32_t n_tx, int32_t n_paths, int32_t cl, int32_t K, int32_t nfft, int32_t k0, int32_t n_k,
+                           int32_t* chan_offset, void* H, void* stream);
 /* pdsch.py:1080-1131 getPrecodingMatrix (one precoding group): mean of the n_avg (n_rx x n_tx) matrices of each item,
  * SVD, F = V[:, :n_layers]/sqrt(n_layers) -> (n_items,n_tx,n_layers).  Column phases are implementation defined. */
 int32_t nrx_svd_precoder_f64(const void* H_block, int32_t n_items, int32_t n_avg, int32_t n_rx, int32_t n_tx,

@@ -75,6 +75,7 @@ for _t in ('f32', 'f64', 'f64o32'):
 SIGNATURES.update({
     'nrx_cdl_gains_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_cir_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'nrx_chan_setup_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_channel_matrix_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     'nrx_apply_td_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, _i32p, vp, vp]),
     'nrx_apply_td_paths_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, vp, vp, i32, i32, _i32p, vp, vp]),

@@ -779,6 +779,151 @@ extern "C" int32_t nrx_channel_matrix_sub_f64(const void* cir, int32_t n_items, 
   return NRX_OK;
 }
 
+namespace {
+// ------------------------------------------------------------------------------------ fused channel set-up (round 3)
+// chanOffset and the channel matrix at n_k subcarriers straight from the path gains: what cir_kernel + chan_offset_kernel +
+// chan_matrix_sub_kernel do in three launches through a (n, T, Nr, Nt, cl) CIR in HBM (1.3 MB per slot written and read twice;
+// latency-bound kernels: 0.80 ms per 256 slots), here in one workgroup per item with the tap matrix and the item's gains in LDS
+// and no CIR in memory.  The time-domain link needs the CIR for nothing else (the filter runs in path form).  Every value is
+// produced by the SAME expression in the same order as in the three kernels -- cir = sum_p gain*coeff left to right, the
+// offset's sums c outer / t inner, the matrix' sum over taps with nrx::cmac -- so offset and matrix are bit-identical.
+constexpr int CS_THREADS = 512;
+constexpr int CS_NK = 12;      // subcarriers (one PRB)
+typedef const cd __attribute__((address_space(4))) * cgain_t;      // read-only in this kernel: wave-uniform rows come by scalar loads
+template <int P>      // paths: a template parameter so that the per-tap / per-row register arrays are fully unrolled without guards
+__global__ void __launch_bounds__(CS_THREADS)
+chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff, int n_t_total, int nc, int nr, int nt,
+                  int cl, int K, int nfft, int k0, int32_t* __restrict__ off_out, cd* __restrict__ H,
+                  const cd* __restrict__ tw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* csT = (double*)smem;                              // [cl][P] tap matrix, transposed: a tap's coefficients are contiguous
+  cd* W = (cd*)(csT + (size_t)P * cl);                      // [use][12] twiddles of (tap, subcarrier) once chanOffset is known
+  __shared__ double bestv[CS_THREADS];
+  __shared__ int besti[CS_THREADS];
+  __shared__ int off_s;
+  const int b = blockIdx.x, tid = threadIdx.x, n_rt = nr * nt;
+  for (int i = tid; i < P * cl; i += CS_THREADS) {
+    const int p = i / cl, l = i - p * cl;
+    csT[(size_t)l * P + p] = coeff[i];
+  }
+  const cd* gb = gains + (size_t)b * n_t_total * n_rt * P;
+  __syncthreads();
+  // ---- chanOffset = argmax_l sum_r | sum_{c<nc, t} cir[c][r][t][l] |   (channelmodel.py:345-346; first max): one tap per thread,
+  // its coefficients in registers, the gains of a (c, r, t) row wave-uniform
+  double bv = -1.0;
+  int bi = 0;
+  for (int l = tid; l < cl; l += CS_THREADS) {
+    double cf[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) cf[p] = csT[(size_t)l * P + p];
+    double tot = 0;
+    for (int r = 0; r < nr; ++r) {
+      cd s(0, 0);
+      for (int c = 0; c < nc; ++c)
+        for (int t = 0; t < nt; ++t) {
+          const cgain_t gr = (cgain_t)(gb + ((size_t)c * n_rt + r * nt + t) * P);
+          cd acc(0, 0);
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            acc.re += gr[p].re * cf[p];
+            acc.im += gr[p].im * cf[p];
+          }
+          s = s + acc;
+        }
+      tot += hypot(s.re, s.im);
+    }
+    if (tot > bv) { bv = tot; bi = l; }
+  }
+  bestv[tid] = bv;
+  besti[tid] = bi;
+  __syncthreads();
+  if (tid == 0) {
+    double v = -1.0;
+    int idx = 0;
+    for (int i = 0; i < CS_THREADS; ++i)
+      if (bestv[i] > v || (bestv[i] == v && besti[i] < idx)) { v = bestv[i]; idx = besti[i]; }
+    off_out[b] = idx;
+    off_s = idx;
+  }
+  __syncthreads();
+  // ---- channel matrix at subcarriers k0 .. k0 + 11 (channelmodel.py:362-400 at those bins: direct DFT of the CIR placed
+  // circularly shifted by chanOffset).  The twiddle of (tap, bin) is the same for every row: tabulated once.
+  const int o = off_s;
+  const int tws = nrx::FFT_TW_N / nfft;
+  const int use = cl < nfft ? cl : nfft;
+  for (int i = tid; i < use * CS_NK; i += CS_THREADS) {
+    const int l = i / CS_NK, k = i - l * CS_NK;
+    const int bin = (k0 + k - K / 2 + nfft) & (nfft - 1);
+    const int pos = (l - o + nfft) & (nfft - 1);
+    const int ph = (int)(((int64_t)bin * pos) & (nfft - 1));
+    const int ti = ph * tws;
+    cd w = tw[ti & (nrx::FFT_TW_N / 2 - 1)];
+    if (ti >= nrx::FFT_TW_N / 2) w = cd(-w.re, -w.im);
+    W[i] = w;
+  }
+  __syncthreads();
+  // one (instant, rx, tx) row per thread: its gains in registers, the CIR value of a tap feeds the 12 bins
+  for (int row = tid; row < nc * n_rt; row += CS_THREADS) {
+    cd g[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) g[p] = gb[(size_t)row * P + p];
+    cd acc[CS_NK];
+#pragma unroll
+    for (int k = 0; k < CS_NK; ++k) acc[k] = cd(0, 0);
+    for (int l = 0; l < use; ++l) {
+      cd v(0, 0);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const double c = csT[(size_t)l * P + p];         // (same address in every lane: broadcast)
+        v.re += g[p].re * c;
+        v.im += g[p].im * c;
+      }
+#pragma unroll
+      for (int k = 0; k < CS_NK; ++k) nrx::cmac(acc[k], v, W[l * CS_NK + k]);
+    }
+    const int c = row / n_rt, rt = row - c * n_rt;
+#pragma unroll
+    for (int k = 0; k < CS_NK; ++k) H[(((size_t)b * nc + c) * CS_NK + k) * n_rt + rt] = acc[k];
+  }
+}
+}  // namespace
+
+extern "C" int32_t nrx_chan_setup_f64(const void* gains, const double* coeff, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx,
+                                      int32_t n_tx, int32_t n_paths, int32_t cl, int32_t K, int32_t nfft, int32_t k0, int32_t n_k,
+                                      int32_t* chan_offset, void* H, void* stream) {
+  NRX_REQUIRE(gains && coeff && chan_offset && H, NRX_E_ARG, "nrx_chan_setup: NULL buffer");
+  NRX_REQUIRE(n_t >= 1 && nc >= 1 && nc <= n_t && n_rx >= 1 && n_tx >= 1 && n_paths >= 1 && cl >= 1 && n_items >= 0,
+              NRX_E_ARG, "nrx_chan_setup: bad sizes");
+  NRX_REQUIRE(nfft >= 64 && (nfft & (nfft - 1)) == 0 && K > 0 && K <= nfft && k0 >= 0 && k0 + n_k <= K, NRX_E_ARG,
+              "nrx_chan_setup: bad nfft / K / subcarrier range");
+  const size_t lds = sizeof(double) * (size_t)n_paths * cl + sizeof(cd) * (size_t)(cl < nfft ? cl : nfft) * CS_NK;
+  const bool built = n_paths == 13 || n_paths == 14 || n_paths == 15 || n_paths == 23 || n_paths == 24;   // the CDL / TDL profiles
+  if (n_k != CS_NK || !built || nfft > nrx::FFT_TW_N || lds > 150 * 1024) {
+    ::nrx::set_error("nrx_chan_setup: built for %d subcarriers, 13/14/15/23/24 paths and <= 150 KB of tap matrix + twiddles (got n_k %d, %d paths, %zu B)",
+                     CS_NK, n_k, n_paths, lds);
+    return NRX_E_UNSUPPORTED;      // the caller runs nrx_cir_f64 + nrx_channel_matrix_sub_f64
+  }
+  if (n_items == 0) return NRX_OK;
+  const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
+  NRX_REQUIRE(tw, NRX_E_HIP, "nrx_chan_setup: FFT twiddle table unavailable");
+#define NRX_CS_CASE(PP)                                                                                                      \
+  case PP:                                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)chan_setup_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    hipLaunchKernelGGL(chan_setup_kernel<PP>, dim3(n_items), dim3(CS_THREADS), lds, (hipStream_t)stream, (const cd*)gains, coeff, \
+                       n_t, nc, n_rx, n_tx, cl, K, nfft, k0, chan_offset, (cd*)H, tw);                                       \
+    break;
+  switch (n_paths) {
+    NRX_CS_CASE(13)
+    NRX_CS_CASE(14)
+    NRX_CS_CASE(15)
+    NRX_CS_CASE(23)
+    NRX_CS_CASE(24)
+  }
+#undef NRX_CS_CASE
+  NRX_CHECK_LAUNCH("nrx_chan_setup");
+  return NRX_OK;
+}
+
 extern "C" int32_t nrx_svd_precoder_f64(const void* H_block, int32_t n_items, int32_t n_avg, int32_t n_rx, int32_t n_tx,
                                         int32_t n_layers, void* F, void* stream) {
   NRX_REQUIRE(H_block && F, NRX_E_ARG, "nrx_svd_precoder: NULL buffer");

@@ -301,9 +301,14 @@ class PdschLink:
         # ---- channel state of each slot
         times = D(self.gain_times(slots))
         gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
-        cir1, off = ops.cir(gains1, self.coeff, self.L)
-        H = None
-        if self.freqDomain or self.chanEst == "Perfect" or self.prg:
+        H = hsub = None
+        need_h = self.freqDomain or self.chanEst == "Perfect" or self.prg
+        fusedcs = None if need_h else ops.chan_setup(gains1, self.coeff, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+        if fusedcs is not None:     # time-domain link, estimated channel, wideband precoder: the CIR is needed for nothing else
+            hsub, off = fusedcs
+        else:
+            cir1, off = ops.cir(gains1, self.coeff, self.L)
+        if need_h:
             H = ops.channel_matrix(cir1, off, self.L, self.K, self.nfft)
         if self.prg:        # one SVD precoder per PRG: mean channel of the group -> right singular vectors
             hm = ops.group_mean(H, self.prg_k0, self.prg_nk)                    # (n, G, Nr, Nt)
@@ -311,7 +316,8 @@ class PdschLink:
             F = ops.svd_precoder(hm.reshape(n * G, 1, self.nr, self.nt), self.nl).reshape(n, G, self.nt, self.nl)
             grid = ops.precode_prg(grid, F, self.prg_k2g)                       # (n, Nt, L, K); F is applied from here on
         else:
-            hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+            if hsub is None:
+                hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
             F = ops.svd_precoder(hsub, self.nl)                                 # wideband SVD precoder (first PRB)
 
         if self.freqDomain:

@@ -607,6 +607,26 @@ def cir(gains, coeff, nc):
     return out, off
 
 
+def chan_setup(gains, coeff, nc, K, nfft, k0, n_k):
+    """chanOffset and the channel matrix at subcarriers [k0, k0 + n_k) straight from the path gains, in one launch and without a
+    CIR in memory (nrx_chan_setup_f64): returns (H_sub (n, nc, n_k, Nr, Nt), off (n,) int32) -- bit-identical to
+    ``cir`` + ``channel_matrix_sub`` -- or None when the configuration is outside what the fused kernel is built for."""
+    gains = gains.to(torch.complex128).contiguous()
+    n, T, nr, nt, P = gains.shape
+    dev = _dev(gains)
+    coeff = coeff.to(device=dev, dtype=torch.float64).contiguous()
+    if coeff.shape[0] != P:
+        raise ValueError("coefficient matrix / path count mismatch")
+    H = torch.empty((n, nc, n_k, nr, nt), dtype=torch.complex128, device=dev)
+    off = torch.empty((n,), dtype=torch.int32, device=dev)
+    rc = lib().nrx_chan_setup_f64(ptr(gains), ptr(coeff), n, T, nc, nr, nt, P, coeff.shape[1], K, nfft, k0, n_k, ptr(off), ptr(H),
+                                  stream())
+    if rc == -3:           # NRX_E_UNSUPPORTED: not an error, the caller takes the two separate entries
+        return None
+    check(rc)
+    return H, off
+
+
 def channel_matrix(cir_t, off, nc, K, nfft):
     """ChannelModel.getChannelMatrix: cir (n,T,Nr,Nt,cl) -> H (n,nc,K,Nr,Nt)."""
     cir_t = cir_t.contiguous()

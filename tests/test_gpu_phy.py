@@ -290,3 +290,30 @@ def test_chest_polar_and_noise_vs_reference(dev, name):
         assert abs(raw[b] - raw_ref) <= 1e-8 * raw_ref and num == sum(a.size for a in at_p)
     with pytest.raises(ValueError):
         grid.estimateChannelLS(p.dmrs, kernel='cubic')          # not one of the reference's kinds (tests/test_gpu_csirs.py)
+
+
+@pytest.mark.parametrize("profile,nr_,nt_,prbs,first", [('C', [1, 2], [1, 2], 273, 0), ('D', [1, 1], [1, 2], 51, 3), ('A', [1, 1], [1, 1], 24, 0)])
+def test_fused_channel_setup_equals_the_separate_entries(dev, profile, nr_, nt_, prbs, first):
+    """nrx_chan_setup_f64 (chanOffset + first-PRB channel matrix from the path gains in one launch, no CIR in memory) against
+    nrx_cir_f64 + nrx_channel_matrix_sub_f64: bit-identical offsets and matrices -- NLOS and LOS profiles, 4x4 / 2x4 / 2x2."""
+    import torch
+    import neoradium_amd as nr
+    from neoradium_amd import ops
+    from neoradium_amd._dev import D
+    nr.random.setSeed(11)
+    car = nr.Carrier(numRbs=prbs, spacing=30)
+    bwp = car.curBwp
+    ch = nr.CdlChannel(bwp, profile, delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                       txAntenna=nr.AntennaPanel(nt_, polarization="x"), rxAntenna=nr.AntennaPanel(nr_, polarization="x"))
+    p = nr.PDSCH(bwp, numLayers=2, nID=car.cellId, modulation='QPSK')
+    p.setDMRS(configType=1, additionalPos=1)
+    link = nr.PdschLink(p, ch, 0.5, numIter=2, decoder="f64")
+    n = 9
+    times = D(link.gain_times(np.arange(40, 40 + n)))
+    gains = ops.cdl_gains(link.A, link.nu, times, A_los=link.Alos, nu_los=link.nulos)
+    cir1, off = ops.cir(gains, link.coeff, link.L)
+    want = ops.channel_matrix_sub(cir1, off, link.L, link.K, link.nfft, 12 * first, 12)
+    got = ops.chan_setup(gains, link.coeff, link.L, link.K, link.nfft, 12 * first, 12)
+    assert got is not None
+    assert torch.equal(got[1], off) and torch.equal(got[0], want)
+    assert ops.chan_setup(gains, link.coeff, link.L, link.K, link.nfft, 12 * first, 24) is None      # two PRBs: the separate entries
