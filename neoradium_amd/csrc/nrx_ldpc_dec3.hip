@@ -5,10 +5,13 @@
 // 527 KB per code block cannot live on chip.  NR LDPC is raptor-like, though: at the code rates the link actually
 // runs, only the first RA rows have their extension parity transmitted and the others are exact no-ops for the
 // information bits (see nrx_ldpc_decode_rows_*).  For RA <= 16 everything fits:
-//   * LDS: the 26 core columns of TWO code blocks, float64, one buffer per column, stored UNROTATED:
-//     2 x 26 x 384 x 8 B = 156 KB.  Lane z (= check row z of every layer) reads element (z + shift) mod Zc and writes
-//     its result back to the same element, so nothing crosses lanes inside a layer and a workgroup barrier is only
-//     needed between layers that share a column (Lay::plan_in);
+//   * LDS: the core columns of TWO code blocks, float64, one buffer per column, stored UNROTATED:
+//     2 x 26 x 384 x 8 B = 156 KB.  A lane reads element (row + shift) mod Zc and writes its result back to the same element,
+//     so nothing crosses lanes inside a layer and a workgroup barrier is only needed between layers that share a column.
+//     Round 3: lane z of layer L handles row (z + sigma_L) mod Zc with sigma_L chosen so that it always meets element z of
+//     COLUMN 0 (which every row but one of the truncated graph touches): column 0 lives in a register, not in LDS, and no longer
+//     forces a barrier between layers that share nothing else; column 1 is handed from a layer to its successor in a register
+//     where that is their only link (Lay::sigma / fwd1 / plan_rot): 11 barriers per iteration instead of 15;
 //   * VGPRs (<= 168, three waves per SIMD): 0.75*min1 and 0.75*min2 of every layer (4 registers per layer), the packed
 //     sign/argmin words, and the posterior of every layer's degree-1 extension column (2 registers per layer; in
 //     float64 (r - m) + m' is not the channel LLR again, so it has to be carried);
@@ -32,15 +35,17 @@ struct WrapTab {
 };
 template <int BG, int ZI, int RA> constexpr WrapTab make_wrap() {
   WrapTab t{};
+  using Y = Lay<BG, RA>;
   const int zc = kZ.z[ZI], ils = kZ.ils[ZI];
   for (int w = 0; w < ZMAX / 64; ++w)
-    for (int e = 0; e < GR<BG, RA>::EDGES; ++e) {
-      const int s = G<BG>::shift(ils, e) % zc;
-      uint64_t m = 0;
-      for (int l = 0; l < 64; ++l)
-        if (64 * w + l + s >= zc) m |= 1ull << l;
-      t.m[w][e] = m;
-    }
+    for (int L = 0; L < RA; ++L)
+      for (int e = GR<BG, RA>::row_start(L); e < GR<BG, RA>::row_start(L + 1); ++e) {
+        const int s = Y::eff_shift(ils, zc, L, e);      // shift of the edge + the layer's row rotation (Lay::sigma)
+        uint64_t m = 0;
+        for (int l = 0; l < 64; ++l)
+          if (64 * w + l + s >= zc) m |= 1ull << l;
+        t.m[w][e] = m;
+      }
   return t;
 }
 typedef const uint64_t __attribute__((address_space(4))) * mtab_t;
@@ -293,7 +298,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   constexpr int N = (B::COLS - 2) * ZC, K = B::KB * ZC;
   constexpr uint32_t HI = 40960;                           // second DS base: immediates are 16 bit
   static_assert(8 * (BUF - 1) - (int)HI < 65536, "DS immediates out of range");
-  static_assert(Y::plan_in.ok, "barrier placement leaves a column hazard");
+  static_assert(Y::plan_rot.ok, "barrier placement leaves a column hazard");
   constexpr int NEXT = Y::n_ext() > 0 ? Y::n_ext() : 1;
 
   double m1[B::ROWS], m2[B::ROWS];
@@ -301,6 +306,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
   uint32_t sgn[(Y::n_narrow() + 1) / 2];                   // two 16-bit fields per word
   u32x2 uv = {0u, 0u};                                     // register pair of the +-1.0 / +-0.75 units: low word stays 0
+  double c0 = 0.0;                                         // element z of column 0 (Lay::sigma: every layer meets it in its own lane)
+  double f1 = 0.0;                                         // column 1 handed from a layer to its successor (Lay::fwd1)
 
 #ifdef NRX_DEC3_PROBE
   uint32_t pk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0;
@@ -334,9 +341,13 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     //  per-lane, per-column addresses and flags below -- invariant over the code-block loop -- are hoisted in front of it,
     //  35 of them, spilled to scratch there, and come back one dependent round trip at a time: ~100 serial memory round
     //  trips per code block)
-    int zl = z;
-    asm volatile("" : "+v"(zl));
-    auto fetch = [&](int p0) __attribute__((always_inline)) -> double {
+    int zl0 = z;
+    asm volatile("" : "+v"(zl0));
+    const int zl = zl0;
+    // rot: the element wanted is (z + rot) mod Zc (a layer's extension column under the layer's row rotation, Lay::sigma)
+    auto fetch = [&](int p0, int rot = 0) __attribute__((always_inline)) -> double {
+      int zl = zl0 + rot;
+      zl -= zl >= ZC ? ZC : 0;
       if constexpr (!FUSED) {
         return clip10(in[p0 + zl]) + 0.0;
       } else {
@@ -358,18 +369,19 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     // ---- load: prepend the two punctured columns as zeros (ldpc.py:1536-1538)
     static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value;
-      if constexpr (c < 2) Ps[c * ZS + zl] = 0.0;
-      else Ps[c * ZS + zl] = fetch((c - 2) * ZC);
+      if constexpr (c == 1) Ps[c * ZS + zl] = 0.0;
+      else if constexpr (c >= 2) Ps[c * ZS + zl] = fetch((c - 2) * ZC);
     });
     static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
       constexpr int L = decltype(lc)::value;
       m1[L] = 0.0;
       m2[L] = 0.0;
       if constexpr (Y::has_ext(L)) {
-        rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC);
+        rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L));      // element of row (z + sigma_L)
         if constexpr (!FUSED) rext[Y::ext_idx(L)] = L < rows_live ? rext[Y::ext_idx(L)] : 0.0;      // (wave-uniform)
       }
     });
+    c0 = 0.0;                                              // punctured column (ldpc.py:1536-1538)
     static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
     static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
     __syncthreads();
@@ -404,14 +416,21 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // priority steps at about a quarter, a half and three quarters of the layer's VALU work (5 + 4 + 5 per edge)
           constexpr int PQ1 = (7 * D) / 10 < D - 1 ? (7 * D) / 10 : D - 1, PQ2 = D / 2 < 2 ? 2 : D / 2, PQ3 = (3 * D) / 10 < 1 ? 1 : (3 * D) / 10;
           LAYER_PRIO(0);
-          // ---- pass 1a: issue every LDS read of the layer, first edge first (the order pass 1b consumes them in)
+          // ---- pass 1a: issue every LDS read of the layer, first edge first (the order pass 1b consumes them in).  Column 0
+          // is the lane's own register; a handed-over column 1 comes from the predecessor's register (Lay::sigma, Lay::fwd1).
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             constexpr int col = B::col(E0 + j);
-            constexpr uint32_t off = 8u * (uint32_t)(col * ZS + B::shift(ILS, E0 + j) % ZC);
-            const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
-            if constexpr (off < 65536) t[j] = *(const double*)((const char*)Praw + (wraps ? zbw : zb) + off);
-            else t[j] = *(const double*)((const char*)Praw + (wraps ? zbwh : zbh) + (off - HI));
+            if constexpr (col == 0) {
+              t[j] = c0;
+            } else if constexpr (col == 1 && Y::fwd1(L)) {
+              t[j] = f1;
+            } else {
+              constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
+              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
+              if constexpr (off < 65536) t[j] = *(const double*)((const char*)Praw + (wraps ? zbw : zb) + off);
+              else t[j] = *(const double*)((const char*)Praw + (wraps ? zbwh : zbh) + (off - HI));
+            }
           });
           __builtin_amdgcn_sched_barrier(0);
           // ---- old state: pm1 / pm2 (scaled minima carrying the row parity), and the sign / argmin word: argmin in the low
@@ -483,11 +502,15 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // ---- pass 2: r_j = t_j + msg_new_j = fma(u_j, first argmin ? pm2 : pm1, t_j), written back to the element it was
           // read from.  The FIRST entry equal to min1 gets min2 (np.argmin, ldpc.py:1558-1570).
           uint32_t idx = 0;
-          auto put = [&](auto jc2) __attribute__((always_inline)) {      // r_j back to its column element / extension register
+          auto put = [&](auto jc2) __attribute__((always_inline)) {      // r_j back to its column element / register
             constexpr int j = decltype(jc2)::value;
             constexpr int col = B::col(E0 + j);
-            if constexpr (col < B::CORE) {
-              constexpr uint32_t off = 8u * (uint32_t)(col * ZS + B::shift(ILS, E0 + j) % ZC);
+            if constexpr (col == 0) {
+              c0 = t[j];
+            } else if constexpr (col == 1 && Y::give1(L)) {
+              f1 = t[j];                                    // the next layer takes it from here and writes the column itself
+            } else if constexpr (col < B::CORE) {
+              constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
               const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
               if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
               else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
@@ -530,7 +553,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           });
           PROBE_STAMP(WIDE ? 2 : 6);
         }
-        if constexpr (Y::barrier_in_before((L + 1) % B::ROWS)) __syncthreads();
+        if constexpr (Y::plan_rot.need[(L + 1) % B::ROWS]) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);   // nothing migrates between layers (register pressure)
       });
     }
@@ -543,7 +566,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       if (live) {
         static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
           constexpr int c = decltype(cc)::value;
-          hard[(size_t)cb * K + c * ZC + zh] = Ps[c * ZS + zh] < 0.0 ? 1 : 0;
+          if constexpr (c == 0) hard[(size_t)cb * K + zh] = c0 < 0.0 ? 1 : 0;
+          else hard[(size_t)cb * K + c * ZC + zh] = Ps[c * ZS + zh] < 0.0 ? 1 : 0;
         });
       }
     } else {
@@ -562,7 +586,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       static_for<B::KB>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
         constexpr uint32_t w = gf2_xpow24((uint32_t)((B::KB - 1 - c) * ZC));
-        const uint32_t bit = Ps[c * ZS + zt] < 0.0 ? 1u : 0u;
+        const uint32_t bit = (c == 0 ? c0 : Ps[c * ZS + zt]) < 0.0 ? 1u : 0u;
         if (live && zt < payload - c * ZC) dst[c * ZC + zt] = (uint8_t)bit;    // (thresholds are wave-uniform)
         v ^= (zt < cb_len - c * ZC && bit) ? w : 0u;
       });

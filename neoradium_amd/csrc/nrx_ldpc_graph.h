@@ -173,6 +173,63 @@ template <int BG, int RA = G<BG>::ROWS> struct Lay {  // compile-time layer fact
   }
   static constexpr BarPlanIn plan_in = make_plan_inplace();
   static constexpr bool barrier_in_before(int l) { return plan_in.need[l]; }
+  // ---- Rotated rows (nrx_ldpc_dec3.hip, round 3).  Lane z of layer L handles check row (z + sigma_L) mod Zc instead of row z:
+  // the layer's accesses to column c then hit element (z + sigma_L + shift_L(c)) mod Zc.  With sigma_L = -shift_L(0) in every
+  // layer that has column 0, lane z always meets element z of column 0: that column lives in a REGISTER (no LDS access, no
+  // address select) and stops forcing a barrier between layers that share nothing else.  A layer without column 0 that shares
+  // only column 1 with its predecessor is rotated so that it meets the element of column 1 its predecessor just updated in
+  // the same lane (`fwd1`): the value is handed over in a register and the barrier in front of that layer goes as well.
+  // (The check-node state of a layer is per row, and a layer's rows never change lanes, so nothing else moves.)
+  static constexpr bool has_col(int L, int c) {
+    for (int e = B::row_start(L); e < B::row_start(L + 1); ++e)
+      if (B::col(e) == c) return true;
+    return false;
+  }
+  static constexpr int shift_of(int ils, int zc, int L, int c) {
+    for (int e = B::row_start(L); e < B::row_start(L + 1); ++e)
+      if (B::col(e) == c) return B::shift(ils, e) % zc;
+    return 0;
+  }
+  static constexpr bool fwd1(int L) {          // layer L takes column 1 from the register its predecessor left it in
+    const int P = (L + B::ROWS - 1) % B::ROWS;
+    return !has_col(L, 0) && has_col(L, 1) && has_col(P, 1) && has_col(P, 0);
+  }
+  static constexpr bool give1(int L) { return fwd1((L + 1) % B::ROWS); }   // ... and this layer leaves it there (no LDS write)
+  static constexpr int sigma(int ils, int zc, int L) {
+    if (has_col(L, 0)) return (zc - shift_of(ils, zc, L, 0)) % zc;
+    if (fwd1(L)) {
+      const int P = (L + B::ROWS - 1) % B::ROWS;
+      return ((zc - shift_of(ils, zc, P, 0)) % zc + shift_of(ils, zc, P, 1) + zc - shift_of(ils, zc, L, 1)) % zc;
+    }
+    return 0;
+  }
+  static constexpr int eff_shift(int ils, int zc, int L, int e) { return (B::shift(ils, e) % zc + sigma(ils, zc, L)) % zc; }
+  // columns of layer L that go through LDS (column 0 never does)
+  static constexpr uint32_t lds_mask(int L) { return core_mask(L) & ~1u; }
+  // ... of which the layer READS from LDS (a handed-over column 1 is not read) -- what a barrier in front of it has to cover
+  static constexpr uint32_t lds_read_mask(int L) { return lds_mask(L) & ~(fwd1(L) ? 2u : 0u); }
+  static constexpr BarPlanIn make_plan_rot() {
+    BarPlanIn p{};
+    uint32_t touched = 0;
+    for (int it = 0; it < 3; ++it)
+      for (int l = 0; l < B::ROWS; ++l) {
+        const bool need = (lds_read_mask(l) & touched) != 0;
+        touched = need ? lds_mask(l) : (touched | lds_mask(l));
+        if (it == 2) p.need[l] = need;
+      }
+    p.ok = true;
+    p.count = 0;
+    touched = 0;   // cold start: the initial fill is followed by a barrier
+    for (int it = 0; it < 3; ++it)
+      for (int l = 0; l < B::ROWS; ++l) {
+        if (p.need[l]) touched = 0;
+        if (lds_read_mask(l) & touched) p.ok = false;
+        touched |= lds_mask(l);
+      }
+    for (int l = 0; l < B::ROWS; ++l) p.count += p.need[l] ? 1 : 0;
+    return p;
+  }
+  static constexpr BarPlanIn plan_rot = make_plan_rot();
   // the k-th layer (cyclically) with an extension column after layer L
   static constexpr int next_ext(int L, int k) {
     int l = L;
