@@ -394,7 +394,7 @@ def main():
             # failing block carries exactly the reference's result; a block that passes early is assumed to be the code word
             # the full run ends on as well, and the error counters of the same slots are compared with the reference schedule's
             tp = build_link(nr, decoder='f64', firstPassIter=8)
-            kt, wt = min(K, 6), min(W, 1)
+            kt, wt = min(K, 8), max(min(W, 2), 2)       # (two warm-up steps: the second pass allocates per-step sizes, let the allocator's cache settle)
             pts = []
             for snr_t in sorted({float(args.snr), 35.0}):
                 tdt, tc, _ = timed_steps(tp, ops, B, kt, wt, snr_t, slot_base, None, sync, timer_enabled=False)
