@@ -415,7 +415,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
 #endif
           // priority steps at about a quarter, a half and three quarters of the layer's VALU work (5 + 4 + 5 per edge)
           constexpr int PQ1 = (7 * D) / 10 < D - 1 ? (7 * D) / 10 : D - 1, PQ2 = D / 2 < 2 ? 2 : D / 2, PQ3 = (3 * D) / 10 < 1 ? 1 : (3 * D) / 10;
-          LAYER_PRIO(0);
+          LAYER_PRIO(Y::prio_q(L, 0));
           // ---- pass 1a: issue every LDS read of the layer, first edge first (the order pass 1b consumes them in).  Column 0
           // is the lane's own register; a handed-over column 1 comes from the predecessor's register (Lay::sigma, Lay::fwd1).
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
@@ -456,7 +456,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             constexpr int j = decltype(jc)::value;
             const double u = unit_of(uv, wrun);
             if constexpr (j < D - 1) wrun = dbl(wrun);
-            if constexpr (j == PQ1) LAYER_PRIO(1);
+            if constexpr (j == PQ1 && Y::prio_q(L, 1) != Y::prio_q(L, 0)) LAYER_PRIO(Y::prio_q(L, 1));
             t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
           });
           PROBE_STAMP(WIDE ? 0 : 4);
@@ -468,7 +468,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           uint32_t nsg = __builtin_amdgcn_alignbit(hi32(t[0]) >> 31, hi32(t[1]), 31);
           static_for<D - 2>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value + 2;
-            if constexpr (j == PQ2) LAYER_PRIO(2);
+            if constexpr (j == PQ2 && Y::prio_q(L, 2) != Y::prio_q(L, 1)) LAYER_PRIO(Y::prio_q(L, 2));
             a2 = vmin(a2, vmax_abs(a1, t[j]));
             a1 = vmin_abs(a1, t[j]);
             nsg = __builtin_amdgcn_alignbit(nsg, hi32(t[j]), 31);      // (nsg << 1) | sign(t_j)
@@ -521,7 +521,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           if (__builtin_expect(!tie_quirk, 1)) {
             static_for<D>([&](auto jc) __attribute__((always_inline)) {
               constexpr int j = D - 1 - decltype(jc)::value;      // last edge first: idx ends at the first index holding the minimum
-              if constexpr (decltype(jc)::value == PQ3) LAYER_PRIO(3);
+              if constexpr (decltype(jc)::value == PQ3 && Y::prio_q(L, 3) != Y::prio_q(L, 2)) LAYER_PRIO(Y::prio_q(L, 3));
               const double u = unit_of(uv, hi32(t[j]));
               t[j] = sel_fma_x<j>(t[j], idx, a1, u, nm1, nm2);
               put(std::integral_constant<int, j>{});

@@ -230,6 +230,22 @@ template <int BG, int RA = G<BG>::ROWS> struct Lay {  // compile-time layer fact
     return p;
   }
   static constexpr BarPlanIn plan_rot = make_plan_rot();
+  // Priority level (0 = first quarter ... 3 = last) of the point `q4` quarters into layer L, counted over the whole stretch
+  // between two barriers of plan_rot (a stretch may span several layers now): work ~ number of edges.
+  static constexpr int prio_q(int L, int q4) {
+    int first = L;                                       // first layer of the stretch: the nearest one (backwards) with a barrier in front
+    for (int i = 0; i < B::ROWS && !plan_rot.need[first]; ++i) first = (first + B::ROWS - 1) % B::ROWS;
+    int before = 0, total = 0;
+    bool seen = false;
+    for (int i = 0, l = first; i < B::ROWS; ++i, l = (l + 1) % B::ROWS) {
+      if (i > 0 && plan_rot.need[l]) break;
+      if (l == L) seen = true;
+      if (!seen) before += deg(l);
+      total += deg(l);
+    }
+    const int q = (4 * (4 * before + q4 * deg(L))) / (4 * total);
+    return q > 3 ? 3 : q;
+  }
   // the k-th layer (cyclically) with an extension column after layer L
   static constexpr int next_ext(int L, int k) {
     int l = L;
