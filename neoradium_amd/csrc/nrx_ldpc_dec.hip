@@ -409,6 +409,8 @@ int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ld
                                     int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec2.hip
 int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
                                       int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec3.hip
+int32_t nrx_ldpc_decode_chipz_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                     int32_t n_rows, uint8_t* hard, hipStream_t st);   // nrx_ldpc_dec4.hip
 namespace {
 
 template <typename T, bool EXACT>
@@ -440,7 +442,7 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
     // float64, hard decisions of the information bits, few enough rows: the whole working set fits on chip
     if (hard && !belief && out_cols == cfg->K) {
       const int32_t rc = nrx_ldpc_decode_chip64_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream);
-      if (rc != 1) return rc;      // 1 = no on-chip instantiation for this (bg, Zc, rows): workspace kernel below
+      if (rc != 1) return rc;      // 1 = no Zc = 384 instantiation for this (bg, Zc, rows)
     }
   }
   int zi = -1;
@@ -448,6 +450,13 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
     if (kZList.z[i] == cfg->Zc) zi = i;
   NRX_REQUIRE(zi >= 0 && kZList.ils[zi] == cfg->iLS, NRX_E_ARG, "nrx_ldpc_decode: (Zc=%d, iLS=%d) is not a lifting size",
               cfg->Zc, cfg->iLS);
+  if constexpr (EXACT) {
+    // ... any other lifting size, either base graph, <= 15 rows: the on-chip kernel with the lifting size at run time
+    if (hard && !belief && out_cols == cfg->K) {
+      const int32_t rc = nrx_ldpc_decode_chipz_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream);
+      if (rc != 1) return rc;      // 1 = more rows than fit on chip: workspace kernel below
+    }
+  }
   const int tab = zi * SHIFT_STRIDE;
   hipStream_t st = (hipStream_t)stream;
   if (cfg->bg == 1) return launch<T, 1, EXACT>(llr, n_cb, cfg, n_iter, out_cols, hard, belief, ws, ws_bytes, st, tab, n_rows);

@@ -643,7 +643,8 @@ int32_t wrap_table(int n_rows, const uint64_t** out) {
 }
 
 bool chip64_covers(const nrx_ldpc_cfg* cfg, int n_rows, int max_rows = 15) {
-  const bool off = getenv("NRX_LDPC_NOCHIP64") != nullptr;      // developer switch (read at every call): always the workspace kernel
+  // developer switches (read at every call): always the workspace kernel / never the Zc = 384 specialisation (nrx_ldpc_dec4.hip then)
+  const bool off = getenv("NRX_LDPC_NOCHIP64") != nullptr || getenv("NRX_LDPC_NOCHIP384") != nullptr;
   return !off && cfg->bg == 1 && cfg->Zc == 384 && cfg->iLS == 1 && n_rows <= max_rows;
 }
 

@@ -403,3 +403,45 @@ def test_onchip_decoder_runs_exactly_the_rows_asked_for(dev):
         ref = oc.decode(llr, 1, 1, 384, num_iter=7, rows=rows)
         got = ops.ldpc_decode(torch.from_numpy(llr).to(dev), cfg, 7, rows=rows).cpu().numpy()
         assert np.array_equal(got, ref.astype(np.uint8)), rows
+
+
+ALL_Z = sorted(b * 2 ** k for b in (2, 3, 5, 7, 9, 11, 13, 15) for k in range(8) if b * 2 ** k <= 384)
+
+
+@pytest.mark.parametrize("bg", [1, 2])
+def test_onchip_decoder_every_lifting_size(dev, bg):
+    """The run-time-Zc on-chip float64 kernel (nrx_ldpc_dec4.hip: <= 15 rows, any lifting size, both base graphs) gives
+    the bits of the workspace kernel (NRX_LDPC_NOCHIP64, read at every call) for every one of the 51 lifting sizes -- ragged
+    batches (a last workgroup with empty code-block slots), filler LLRs (1e20: the +1e5 quirk path), exact zeros, row counts
+    4..15 -- and the oracle's bits for the sizes it finishes quickly."""
+    import os
+    import torch
+    from neoradium_amd import ops, _lib
+    from oracle import coding as oc
+    kb, core, ncols = (22, 26, 68) if bg == 1 else (10, 14, 52)
+    assert len(ALL_Z) == 51
+    rng = np.random.default_rng(4000 + bg)
+    assert 'NRX_LDPC_NOCHIP64' not in os.environ
+    for i, zc in enumerate(ALL_Z):
+        ils = next(k for k, b in enumerate((2, 3, 5, 7, 9, 11, 13, 15)) if zc % b == 0 and (zc // b) & (zc // b - 1) == 0)
+        cfg = _lib.LdpcCfg()
+        cfg.bg, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F, cfg.C, cfg.B, cfg.cb_len = bg, zc, ils, kb * zc, (ncols - 2) * zc, 0, 1, 0, 0
+        rows = 4 + (i * 5) % 12                               # 4..15
+        n_cb = 1 + (i * 7) % 29
+        sig = 0.8 if bg == 1 else 1.0
+        llr = 2 / sig ** 2 + (2 / sig) * rng.standard_normal((n_cb, cfg.N))
+        llr[:, (core - 2 + rows - 4) * zc - zc // 3:] = 0.0   # nothing received beyond the rows that run
+        llr[rng.random(llr.shape) < 0.002] = 0.0
+        nf = zc // 2
+        llr[:, (kb - 2) * zc - nf:(kb - 2) * zc] = 1e20       # fillers at the end of the information columns
+        x = torch.from_numpy(llr).to(dev)
+        got = ops.ldpc_decode(x, cfg, 9, rows=rows)
+        os.environ['NRX_LDPC_NOCHIP64'] = '1'
+        try:
+            ref = ops.ldpc_decode(x, cfg, 9, rows=rows)
+        finally:
+            del os.environ['NRX_LDPC_NOCHIP64']
+        assert torch.equal(got, ref), (bg, zc, rows, n_cb)
+        if zc <= 40 or zc in (88, 208):
+            o = oc.decode(llr[:4], bg, ils, zc, num_iter=9, rows=rows)
+            assert np.array_equal(o, got[:4].cpu().numpy()), (bg, zc, rows)
