@@ -342,6 +342,12 @@ int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t w
 int32_t nrx_cdl_gains_f64(const void* A, const double* nu, const void* A_los, double nu_los, const double* times,
                           int32_t n_items, int32_t n_t, int32_t n_rx, int32_t n_tx, int32_t n_clusters,
                           int32_t n_rays, void* gains, void* stream);
+/* The same with ray coefficients of their own for every item -- A (n_items,n_rx,n_tx,n_clusters,n_rays), nu
+ * (n_items,n_clusters,n_rays): the statistical TDL model that redraws its angles and phases for every slot
+ * (tdl.py:1043-1067 getPathGains, sosType 'Xiao'). */
+int32_t nrx_cdl_gains_items_f64(const void* A, const double* nu, const void* A_los, double nu_los, const double* times,
+                                int32_t n_items, int32_t n_t, int32_t n_rx, int32_t n_tx, int32_t n_clusters,
+                                int32_t n_rays, void* gains, void* stream);
 /* channelmodel.py:343-346: cir (n_items,n_t,n_rx,n_tx,cl) = gains x coeff (n_paths,cl real); chan_offset
  * (nullable, n_items int32) = argmax_l sum_r |sum_{c<nc,t} cir| over the first nc instants. */
 int32_t nrx_cir_f64(const void* gains, const double* coeff, int32_t n_items, int32_t n_t, int32_t nc, int32_t n_rx,

@@ -74,6 +74,7 @@ for _t in ('f32', 'f64', 'f64o32'):
     SIGNATURES['nrx_qam_demap_cb_' + _t] = (i32, [vp, i64, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp, i64, i32, f64, vp])
 SIGNATURES.update({
     'nrx_cdl_gains_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'nrx_cdl_gains_items_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_cir_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_chan_setup_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_channel_matrix_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),

@@ -18,11 +18,15 @@ typedef cx<double> cd;
 // (channelmodel.py:451-469): everything that does not depend on time.
 __global__ void __launch_bounds__(256)
 cdl_gains_kernel(const cd* __restrict__ A, const double* __restrict__ nu, const cd* __restrict__ Alos, double nu_los,
-                 const double* __restrict__ times, int n_t, int n_rt, int n_cl, int n_ray, cd* __restrict__ gains) {
+                 const double* __restrict__ times, int n_t, int n_rt, int n_cl, int n_ray, cd* __restrict__ gains,
+                 int64_t a_item_stride, int64_t nu_item_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* ph = (cd*)smem;  // [n_cl*n_ray] Doppler phasors of this (item, instant)
   const int bt = blockIdx.x;  // item * n_t + instant
   const double t = times[bt];
+  // per-item ray coefficients (statistical models that redraw them for every slot, tdl.py:1043-1067); strides 0 = shared
+  A += (int64_t)(bt / n_t) * a_item_stride;
+  nu += (int64_t)(bt / n_t) * nu_item_stride;
   for (int i = threadIdx.x; i < n_cl * n_ray; i += blockDim.x) {
     double s, c;
     sincos((6.283185307179586 * t) * nu[i], &s, &c);  // cdl.py:887 exp(2j*pi*t*nu)
@@ -418,8 +422,25 @@ extern "C" int32_t nrx_cdl_gains_f64(const void* A, const double* nu, const void
   const size_t lds = sizeof(cd) * (size_t)n_clusters * n_rays;
   NRX_REQUIRE(lds <= 64 * 1024, NRX_E_UNSUPPORTED, "nrx_cdl_gains: too many rays (%d x %d)", n_clusters, n_rays);
   hipLaunchKernelGGL(cdl_gains_kernel, dim3(n_items * n_t), dim3(256), lds, (hipStream_t)stream, (const cd*)A, nu,
-                     (const cd*)A_los, nu_los, times, n_t, n_rx * n_tx, n_clusters, n_rays, (cd*)gains);
+                     (const cd*)A_los, nu_los, times, n_t, n_rx * n_tx, n_clusters, n_rays, (cd*)gains, (int64_t)0, (int64_t)0);
   NRX_CHECK_LAUNCH("nrx_cdl_gains");
+  return NRX_OK;
+}
+
+// The same with ray coefficients of their own for every item: A (n_items, Nr, Nt, N, M), nu (n_items, N, M).
+extern "C" int32_t nrx_cdl_gains_items_f64(const void* A, const double* nu, const void* A_los, double nu_los,
+                                           const double* times, int32_t n_items, int32_t n_t, int32_t n_rx, int32_t n_tx,
+                                           int32_t n_clusters, int32_t n_rays, void* gains, void* stream) {
+  NRX_REQUIRE(A && nu && times && gains, NRX_E_ARG, "nrx_cdl_gains_items: NULL buffer");
+  NRX_REQUIRE(n_t >= 1 && n_rx >= 1 && n_tx >= 1 && n_clusters >= 1 && n_rays >= 1 && n_items >= 0, NRX_E_ARG,
+              "nrx_cdl_gains_items: bad sizes");
+  if (n_items == 0) return NRX_OK;
+  const size_t lds = sizeof(cd) * (size_t)n_clusters * n_rays;
+  NRX_REQUIRE(lds <= 64 * 1024, NRX_E_UNSUPPORTED, "nrx_cdl_gains_items: too many rays (%d x %d)", n_clusters, n_rays);
+  hipLaunchKernelGGL(cdl_gains_kernel, dim3(n_items * n_t), dim3(256), lds, (hipStream_t)stream, (const cd*)A, nu,
+                     (const cd*)A_los, nu_los, times, n_t, n_rx * n_tx, n_clusters, n_rays, (cd*)gains,
+                     (int64_t)n_rx * n_tx * n_clusters * n_rays, (int64_t)n_clusters * n_rays);
+  NRX_CHECK_LAUNCH("nrx_cdl_gains_items");
   return NRX_OK;
 }
 

@@ -30,9 +30,6 @@ def host_tables(pdsch, channel, codeRate, baseGraphNo=1):
     pilot table of every slot of the frame, the layer-mapped RE index, scrambling sequence and LDPC configuration of
     every codeword, the channel's static ray coefficients and tap matrix, the slot geometry.  PdschLink uploads these;
     the CPU oracle harness (oracle/link.py, tests/test_oracle_e2e.py) consumes the same dictionary."""
-    if getattr(channel, '_static_per_slot', False):
-        raise NotImplementedError("PdschLink: this channel model draws new random coefficients for every slot (TDL sosType="
-                                  "'Xiao'), a sequential process the batched engine does not reproduce; use the class surface")
     bwp = pdsch.bwp
     car = bwp.carrier
     dmrs = pdsch.dmrs
@@ -68,7 +65,17 @@ def host_tables(pdsch, channel, codeRate, baseGraphNo=1):
         e_max = max(_lib.ldpc_cb_lens(G, ccfg.C, cw_layers[q], qm))
         cws.append(dict(tbs=tbs_all[q], qm=qm, nl=cw_layers[q], G=G, cfg=ccfg, e_max=e_max, lm=lm,
                         re_index=np.int32((np.int64(lm[0]) * L + lm[1]) * K + lm[2]), scr=pdsch._scrambling(q, G)))
-    A, nu, Alos, nulos = channel.staticCoefficients()
+    # A statistical model that redraws its ray coefficients for every slot (TDL sosType='Xiao', tdl.py:1043-1067): `static_at`
+    # gives the coefficients of the s-th slot after the channel's last restart() -- the draws the slot-by-slot class surface
+    # makes, reproduced from a copy of the generator -- and A / nu hold slot 0's (shapes; the oracle harness runs slot 0 only).
+    static_at = None
+    if getattr(channel, '_static_per_slot', False):
+        def static_at(s, _ch=channel):
+            a, v, _, _ = _ch.staticCoefficientsAt(s)
+            return np.complex128(a * _ch._normalisation()), np.float64(v)
+        A, nu, Alos, nulos = channel.staticCoefficientsAt(0)
+    else:
+        A, nu, Alos, nulos = channel.staticCoefficients()
     sc = channel._normalisation()
     spsf = bwp.slotsPerSubFrame
     sym_lens = [bwp.symbolLens[s * L:s * L + L + 1].astype(np.int64) for s in range(spsf)]
@@ -77,7 +84,7 @@ def host_tables(pdsch, channel, codeRate, baseGraphNo=1):
                 A=np.complex128(A * sc), nu=np.float64(nu), Alos=None if Alos is None else np.complex128(Alos * sc),
                 nulos=float(nulos), coeff=channel.getCoeffMatrix(), max_delay=channel.getMaxDelay(), fs=bwp.sampleRate,
                 sym_lens=sym_lens, nr=channel.nrNt[0], nt=channel.nrNt[1], nl=nl, K=K, L=L, nfft=bwp.nFFT, n_rb=bwp.numRbs,
-                slots_per_frame=bwp.slotsPerFrame, slots_per_subframe=spsf)
+                slots_per_frame=bwp.slotsPerFrame, slots_per_subframe=spsf, static_at=static_at)
 
 
 def gain_times(tables, slots):
@@ -189,6 +196,7 @@ class PdschLink:
         # ---- channel: static ray coefficients + tap matrix on the device
         self.A, self.nu = D(tb_['A']), D(tb_['nu'])
         self.Alos, self.nulos = (None if tb_['Alos'] is None else D(tb_['Alos'])), tb_['nulos']
+        self.static_at = tb_.get('static_at')
         coeff = tb_['coeff']
         self.coeff = D(coeff)
         taps, offs = ops.path_taps(coeff, channel.filterLen)
@@ -300,7 +308,12 @@ class PdschLink:
 
         # ---- channel state of each slot
         times = D(self.gain_times(slots))
-        gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
+        if self.static_at is None:
+            gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
+        else:                       # per-slot ray coefficients (host draws in the class surface's order, see host_tables)
+            per = [self.static_at(int(s)) for s in slots]
+            gains1 = ops.cdl_gains(D(np.stack([a for a, _ in per])), D(np.stack([v for _, v in per])), times,
+                                   A_los=self.Alos, nu_los=self.nulos)
         H = hsub = None
         need_h = self.freqDomain or self.chanEst == "Perfect" or self.prg
         fusedcs = None if need_h else ops.chan_setup(gains1, self.coeff, self.L, self.K, self.nfft, 12 * self.first_prb, 12)

@@ -577,18 +577,24 @@ def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None, cp_offset_rat
 
 # ----------------------------------------------------------------------------------------- tapped delay line
 def cdl_gains(A, nu, times, A_los=None, nu_los=0.0):
-    """Time-varying CDL path gains: A (Nr,Nt,N,M) c128, nu (N,M) f64, times (n,T) f64 -> (n,T,Nr,Nt,P)."""
+    """Time-varying CDL path gains: A (Nr,Nt,N,M) c128, nu (N,M) f64, times (n,T) f64 -> (n,T,Nr,Nt,P).
+    A (n,Nr,Nt,N,M) with nu (n,N,M): ray coefficients of their own for every item (TDL 'Xiao', tdl.py:1043-1067)."""
     A = A.to(torch.complex128).contiguous()
-    nr, nt, N, M = A.shape
+    per_item = A.dim() == 5
+    nr, nt, N, M = A.shape[-4:]
     dev = _dev(A)
     nu = nu.to(device=dev, dtype=torch.float64).contiguous()
     times = times.to(device=dev, dtype=torch.float64).contiguous()
     n, T = times.shape
+    if per_item and (A.shape[0] != n or tuple(nu.shape) != (n, N, M)):
+        raise ValueError("cdl_gains: per-item coefficients need A (n,Nr,Nt,N,M) and nu (n,N,M) for times (n,T)")
+    if not per_item and tuple(nu.shape) != (N, M):
+        raise ValueError("cdl_gains: nu must be (N,M)")
     al = None if A_los is None else A_los.to(device=dev, dtype=torch.complex128).contiguous()
     P = N + (0 if al is None else 1)
     gains = torch.empty((n, T, nr, nt, P), dtype=torch.complex128, device=dev)
-    check(lib().nrx_cdl_gains_f64(ptr(A), ptr(nu), ptr(al), float(nu_los), ptr(times), n, T, nr, nt, N, M, ptr(gains),
-                                  stream()))
+    fn = lib().nrx_cdl_gains_items_f64 if per_item else lib().nrx_cdl_gains_f64
+    check(fn(ptr(A), ptr(nu), ptr(al), float(nu_los), ptr(times), n, T, nr, nt, N, M, ptr(gains), stream()))
     return gains
 
 

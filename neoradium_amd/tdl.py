@@ -94,7 +94,35 @@ class TdlChannel(ChannelModel):
     def restart(self, restartRanGen=False, applyToBwp=True):
         if (self.seed is not None) and restartRanGen:
             self.rangen = random.getGenerator(self.seed)
+        # 'Xiao': the generator as it stands before slot 0's draws -- what staticCoefficientsAt() reproduces any slot's draws from
+        self._slot0_state = self._rangenState() if self._static_per_slot else None
         super().restart(restartRanGen, applyToBwp)
+
+    def _rangenState(self):
+        g = getattr(self.rangen, 'generator', self.rangen)
+        return ('legacy', g.get_state()) if isinstance(g, np.random.RandomState) else ('pcg', g.bit_generator.state)
+
+    def staticCoefficientsAt(self, slot):
+        """'Xiao' only: the coefficients the slot-by-slot class surface uses for the ``slot``-th slot after the last restart()
+        (tdl.py:1043-1067 draws one (theta, phi) pair per prepared slot), without touching the channel's own generator:
+        a copy of the generator as it stood before slot 0 is moved ``slot`` pairs of draws forward.  This is what lets the
+        batched engine (PdschLink) prepare any range of slots at once, on any rank."""
+        if not self._static_per_slot:
+            raise ValueError("staticCoefficientsAt: only the per-slot statistical model (sosType='Xiao') has per-slot coefficients")
+        nr, nt = self.nrNt
+        per_slot = self.sosNumSins * self.numPaths * (1 + nr * nt)       # doubles drawn per slot
+        kind, st = self._slot0_state
+        if kind == 'pcg':
+            bg = np.random.PCG64()
+            bg.state = st
+            bg.advance(int(slot) * per_slot)                              # Generator.random(): one 64-bit output per double
+            g = np.random.Generator(bg)
+        else:
+            g = np.random.RandomState()
+            g.set_state(st)
+            for _ in range(int(slot)):
+                g.random_sample(per_slot)
+        return self.staticCoefficients(gen=g)
 
     @property
     def nrNt(self):
@@ -104,7 +132,7 @@ class TdlChannel(ChannelModel):
         if self.profile in "ABCDE":
             self.pathDelays *= self.delaySpread
 
-    def staticCoefficients(self):
+    def staticCoefficients(self, gen=None):
         """GMEDS-1 sum of sinusoids (tdl.py:1070-1088) as 4N complex exponentials per (r,t,path) + one LOS ray.
 
         QUIRKS kept: the discrete Doppler 'frequencies' already carry a 2*pi and get another one in the phase
@@ -115,8 +143,10 @@ class TdlChannel(ChannelModel):
             # tdl.py:1043-1067 (Xiao et al., "Novel sum-of-sinusoids simulation models ...", eq. 6-7): N unit phasors per
             # (r,t,path), Doppler f_D cos(alpha_n) with alpha_n = (2 pi n + theta_n) / N; theta (per path) and phi (per
             # r,t,path) are drawn from the channel's generator in the reference's order, one pair of draws per call
-            theta = self.rangen.random(size=(1, N_, 1, 1, P)) * 2 * np.pi - np.pi
-            phi = self.rangen.random(size=(1, N_, nr, nt, P)) * 2 * np.pi - np.pi
+            gen = self.rangen if gen is None else gen
+            draw = gen.random if hasattr(gen, 'random') else gen.random_sample
+            theta = draw(size=(1, N_, 1, 1, P)) * 2 * np.pi - np.pi
+            phi = draw(size=(1, N_, nr, nt, P)) * 2 * np.pi - np.pi
             alpha = (2 * np.pi * (np.arange(N_, dtype=np.float64).reshape(1, -1, 1, 1, 1) + 1) + theta) / N_
             M = N_ + 1                                                                      # + one LOS ray
             A = np.zeros((nr, nt, P, M), dtype=np.complex128)

@@ -649,7 +649,7 @@ def test_cdl_filtering_vs_matlab(dev):
 def test_tdl_xiao_channel_vs_reference(dev):
     """TdlChannel(sosType='Xiao') on the class surface (tdl.py:1043-1067): new random angles / phases for every slot, drawn
     from the package generator in the reference's order; gains of two consecutive slots and the channel matrix of the second
-    against the reference.  The batched engine refuses the model (sequential draws) instead of approximating it."""
+    against the reference."""
     import neoradium_amd as nr
     g = np.load(os.path.join(GOLD, 'channels_xiao.npz'))
     specs = [('B', dict(delaySpread=100, dopplerShift=70, sosType='Xiao')),
@@ -665,10 +665,65 @@ def test_tdl_xiao_channel_vs_reference(dev):
         assert np.array_equal(ch.chanGainSamples, g[f'x{i}_samples1'])
         assert np.abs(ch.chanGains - g[f'x{i}_gains1']).max() < 1e-11 * np.abs(g[f'x{i}_gains1']).max()
         assert np.abs(H[::6, ::25] - g[f'x{i}_H']).max() < 1e-10 * np.abs(g[f'x{i}_H']).max()
-    p = nr.PDSCH(car.curBwp, numLayers=1)
+
+
+@pytest.mark.parametrize("freqDomain", [False, True])
+def test_engine_tdl_xiao_matches_class_surface(dev, freqDomain):
+    """The batched engine with TdlChannel(sosType='Xiao') (tdl.py:1043-1067: new angles / phases for every slot): every slot's
+    ray coefficients are the ones the slot-by-slot class surface draws -- reproduced from a copy of the channel's generator
+    moved forward by whole slots (TdlChannel.staticCoefficientsAt), so any range of slots can be prepared at once -- and the
+    LLRs and CRC verdicts of slots 0..3, and of slots 2..3 run on their own, equal the class surface's."""
+    import torch
+    import neoradium_amd as nr
+    from neoradium_amd._dev import D
+    nr.random.setSeed(77)
+    car = nr.Carrier(numRbs=25, spacing=15)
+    bwp = car.curBwp
+    p = nr.PDSCH(bwp, numLayers=2, nID=car.cellId, modulation='16QAM')
     p.setDMRS(configType=1, additionalPos=1)
-    with pytest.raises(NotImplementedError):
-        nr.PdschLink(p, ch, 0.5)
+    ch = nr.TdlChannel(bwp, 'B', delaySpread=100, dopplerShift=70, sosType='Xiao', txAntennaCount=2, rxAntennaCount=2,
+                       mimoCorrelation='Medium')
+    rate, snr, nit, n_slots = 0.45, 14.0, 8, 4
+    link = nr.PdschLink(p, ch, rate, numIter=nit, freqDomain=freqDomain, chanEst="LS", decoder="f64")
+    rng = np.random.default_rng(5)
+    tb = rng.integers(0, 2, (n_slots, link.tbs)).astype(np.uint8)
+    shape = (n_slots, link.nr, link.L, link.K) if freqDomain else (n_slots, link.nr, bwp.getSlotLen(0) + ch.getMaxDelay())
+    z = rng.standard_normal(shape + (2,))
+    zc = z[..., 0] + 1j * z[..., 1]
+    _, det = link.run(0, n_slots, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details=True)
+    d = det[0][1]
+    _, det2 = link.run(2, 2, snr, tb_bits=torch.from_numpy(tb[2:]), noise=D(zc[2:]), details=True)
+    assert torch.equal(det2[0][1]['llr'], d['llr'][2:]) and torch.equal(det2[0][1]['cb_ok'], d['cb_ok'][2:])
+    enc = nr.LdpcEncoder(baseGraphNo=1, modulation='16QAM', txLayers=2, targetRate=rate)
+    dec = enc.getDecoder()
+
+    class FixedNoise:
+        def __init__(self, zz): self.zz = zz
+        def normal(self, loc, scale, shape): return self.zz
+
+    for s in range(n_slots):
+        grid = p.getGrid()
+        p.populateGrid(grid, enc.getRateMatchedCodeBlocks(tb[s].astype(np.int8), p.getBitSizes(grid)[0]))
+        idx = p.getReIndexes(grid, "PDSCH")
+        H = ch.getChannelMatrix()
+        F = d['F'][s].cpu().numpy()
+        Fref = p.getPrecodingMatrix(H)
+        assert np.abs(F @ F.conj().T - Fref @ Fref.conj().T).max() < 1e-9
+        pg = grid.precode(F)
+        if freqDomain:
+            rx = pg.applyChannel(H).addNoise(snrDb=snr, useRxPower=True, ranGen=FixedNoise(z[s]))
+        else:
+            r = ch.applyToSignal(pg.ofdmModulate().pad(ch.getMaxDelay())).addNoise(snrDb=snr, bwp=bwp, useRxPower=True, ranGen=FixedNoise(z[s]))
+            rx = r.sync(ch.getTimingOffset()).ofdmDemodulate(bwp)
+        eq, sc = rx.equalize(rx.estimateChannelLS(p.dmrs)[0])
+        llr = p.getLLRsFromGrid(eq, idx, sc)[0]
+        ref = d['llr'][s].cpu().numpy()
+        assert np.abs(llr - ref).max() <= 1e-9 * np.abs(ref).max(), (s, np.abs(llr - ref).max())
+        _, crc = dec.checkCrcAndMerge(dec.decode(dec.recoverRate(llr, link.tbs), numIter=nit))
+        assert np.array_equal(np.asarray(crc, bool), d['cb_ok'][s].cpu().numpy().astype(bool))
+        ch.goNext()
+    with pytest.raises(ValueError):
+        nr.TdlChannel(bwp, 'B', delaySpread=100, dopplerShift=70).staticCoefficientsAt(1)
 
 
 def test_engine_with_ptrs(dev):
