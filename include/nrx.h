@@ -327,6 +327,14 @@ int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int3
                                        const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens,
                                        int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws,
                                        void* stream);
+/* nrx_ofdm_modulate_* with the symbols transformed in parallel (one workgroup per (row, symbol) instead of one per row):
+ * the same samples; tails_ws as above (n_rows*n_sym*window_len complex samples, may be NULL when window_len == 0). */
+int32_t nrx_ofdm_modulate_sym_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens,
+                                  int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws,
+                                  void* stream);
+int32_t nrx_ofdm_modulate_sym_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens,
+                                  int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws,
+                                  void* stream);
 int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
                                 int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
                                 const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream);
@@ -388,6 +396,13 @@ int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_t n_tx, int
                                int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
                                const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens, void* y,
                                void* stream);
+
+/* grid.py:505-516 Grid.precode with ONE precoder for all subcarriers, moved behind the modulator: out
+ * (n_items,n_sets,n_rx,n_layers,n_paths) = sum_t gains1[.,.,r,t,p] * F[.,t,l] (F: (n_tx,n_layers) complex128 per item,
+ * f_stride elements apart; 0 = shared).  nrx_apply_td_paths_f64 on the n_layers LAYER waveforms with these gains equals the
+ * filter on the n_tx precoded waveforms (precoding commutes with IFFT, cyclic prefix and windowing; channelmodel.py:431-447). */
+int32_t nrx_fold_precoder_f64(const void* gains1, const void* F, int64_t f_stride, int32_t n_items, int32_t n_sets,
+                              int32_t n_rx, int32_t n_tx, int32_t n_layers, int32_t n_paths, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------- LS channel estimation
  * grid.py:874-975 estimateChannelLS(polarInt=False, kernel='linear') (channel estimate; the noise-variance

@@ -63,6 +63,7 @@ for _t in ('f32', 'f64'):
         'nrx_add_noise_' + _t: (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
         'nrx_awgn_' + _t: (i32, [vp, vp, i32, i64, vp, i32, u64_, u64_, i64, vp, vp]),
         'nrx_ofdm_modulate_' + _t: (i32, [vp, i32, i32, i32, _i32p, i32, i32, vp, i64, vp]),
+        'nrx_ofdm_modulate_sym_' + _t: (i32, [vp, i32, i32, i32, _i32p, i32, i32, vp, i64, vp, vp]),
         'nrx_ofdm_modulate_precoded_' + _t: (i32, [vp, i32, i32, i32, vp, i64, i32, i32, _i32p, i32, i32, vp, i64, vp, vp]),
         'nrx_ofdm_demodulate_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, f64, vp, vp]),
         'nrx_ofdm_demodulate_awgn_' + _t: (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, vp, i32, u64_, u64_,
@@ -75,6 +76,7 @@ for _t in ('f32', 'f64', 'f64o32'):
 SIGNATURES.update({
     'nrx_cdl_gains_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_cdl_gains_items_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'nrx_fold_precoder_f64': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_cir_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_chan_setup_f64': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_channel_matrix_f64': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),

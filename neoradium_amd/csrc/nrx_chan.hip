@@ -801,6 +801,29 @@ extern "C" int32_t nrx_channel_matrix_sub_f64(const void* cir, int32_t n_items, 
 }
 
 namespace {
+// ------------------------------------------------------------------------ wideband precoder folded into the path gains
+// gl[b][c][r][l][p] = sum_t gains[b][c][r][t][p] * F[b][t][l].  The wideband precoder (Grid.precode, grid.py:505-516) is one
+// Nt x Nl matrix for every subcarrier, so it commutes with the IFFT, the cyclic prefix and the windowing, all of which act
+// on each waveform alone: sum_t g[r][t][p] FIR_p(IFFT(sum_l F[t][l] X_l)) = sum_l (sum_t g[r][t][p] F[t][l]) FIR_p(IFFT(X_l)).
+// The time-domain link therefore modulates the Nl LAYER grids (one read of each row, no mixing in the load) and filters
+// them with these folded gains (channelmodel.py:431-447 with the layers as inputs).
+__global__ void __launch_bounds__(256)
+fold_precoder_kernel(const cd* __restrict__ gains, const cd* __restrict__ F, int64_t f_stride, int n_sets, int nr, int nt, int nl,
+                     int P, int64_t total, cd* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    int64_t q = i / P;
+    const int l = (int)(q % nl);
+    q /= nl;                                   // (b * n_sets + c) * nr + r
+    const int64_t b = q / ((int64_t)n_sets * nr);
+    const cd* g = gains + q * nt * P + p;
+    const cd* f = F + b * f_stride + l;
+    cd acc(0, 0);
+    for (int t = 0; t < nt; ++t) nrx::cmac(acc, g[(size_t)t * P], f[(size_t)t * nl]);
+    out[i] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------ fused channel set-up (round 3)
 // chanOffset and the channel matrix at n_k subcarriers straight from the path gains: what cir_kernel + chan_offset_kernel +
 // chan_matrix_sub_kernel do in three launches through a (n, T, Nr, Nt, cl) CIR in HBM (1.3 MB per slot written and read twice;
@@ -1055,5 +1078,19 @@ extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_
   }
 #undef NRX_TDP_CASE
   NRX_CHECK_LAUNCH("nrx_apply_td_paths");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_fold_precoder_f64(const void* gains, const void* F, int64_t f_stride, int32_t n_items, int32_t n_sets,
+                                         int32_t n_rx, int32_t n_tx, int32_t n_layers, int32_t n_paths, void* out, void* stream) {
+  NRX_REQUIRE(gains && F && out, NRX_E_ARG, "nrx_fold_precoder: NULL buffer");
+  NRX_REQUIRE(n_items >= 0 && n_sets >= 1 && n_rx >= 1 && n_tx >= 1 && n_layers >= 1 && n_layers <= n_tx && n_paths >= 1, NRX_E_ARG,
+              "nrx_fold_precoder: bad sizes");
+  NRX_REQUIRE(f_stride == 0 || f_stride >= (int64_t)n_tx * n_layers, NRX_E_SHAPE, "nrx_fold_precoder: f_stride too small");
+  const int64_t total = (int64_t)n_items * n_sets * n_rx * n_layers * n_paths;
+  if (total == 0) return NRX_OK;
+  hipLaunchKernelGGL(fold_precoder_kernel, dim3(nrx::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const cd*)gains,
+                     (const cd*)F, f_stride, n_sets, n_rx, n_tx, n_layers, n_paths, total, (cd*)out);
+  NRX_CHECK_LAUNCH("nrx_fold_precoder");
   return NRX_OK;
 }

@@ -14,6 +14,24 @@
 #define NRX_MOD_THREADS 512
 #endif
 
+#ifndef NRX_OFDM_ABLATE
+#define NRX_OFDM_ABLATE 0     // developer timing ablations (tools/probe_ofdm.py): 1 = no FFT passes, 2 = no global loads in the fill
+#endif
+#ifdef NRX_OFDM_PROBE
+// Developer build only (tools/probe_ofdm.py): s_memtime stamps at the phase boundaries of the symbol-parallel modulator [0..4]
+// and the demodulator [8..12], summed over waves; [5] / [13] = waves stamped.
+__device__ unsigned long long g_ofdm_probe[16];
+#define OFDM_STAMP(K)                                                              \
+  do {                                                                             \
+    unsigned long long pt_;                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pt_)::"memory"); \
+    if ((K) >= 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_ofdm_probe[(K)], pt_ - pk_prev); \
+    pk_prev = pt_;                                                                 \
+  } while (0)
+#else
+#define OFDM_STAMP(K) do {} while (0)
+#endif
+
 namespace {
 using nrx::cx;
 
@@ -115,7 +133,11 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
                   const int64_t* __restrict__ item_ids, double cp_offset_ratio) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
+#ifdef NRX_OFDM_PROBE
+  unsigned long long pk_prev = 0;
+#endif
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    OFDM_STAMP(-1);
     const int l = task % g.n_sym;
     const int row = task / g.n_sym;  // item * n_ant + antenna
     const int item = row / n_ant;
@@ -127,7 +149,11 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
 #pragma unroll 4
     for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
       const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));  // waveform.py:509
+#if NRX_OFDM_ABLATE != 2
       cx<T> v = s < wave_len ? src[s] : cx<T>(0, 0);
+#else
+      cx<T> v = cx<T>((T)s, (T)i);
+#endif
       // sigma != null: the received waveform is noiseless and the AWGN of nrx_awgn_* (same generator, same element
       // numbering: element = antenna * wave_len + sample of the item) is added while loading
       if (sigma && s < wave_len)
@@ -136,14 +162,23 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
                              (int64_t)(row - item * n_ant) * wave_len + s);
       buf[nrx::fft_idx(i)] = v;
     }
+    OFDM_STAMP(8);
     __syncthreads();
+    OFDM_STAMP(9);
+#if NRX_OFDM_ABLATE != 1
     nrx::fft_dif_lds(buf, tw, nfft, log2n, false);
+#endif
+    OFDM_STAMP(10);
     cx<T>* dst = grid + ((size_t)row * g.n_sym + l) * K;
 #pragma unroll 4
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
       const int q = (k - K / 2 + nfft) & (nfft - 1);  // fftshift + centre K bins (waveform.py:514-520)
       dst[k] = buf[nrx::fft_idx(nrx::fft_bitrev(q, log2n))];
     }
+#ifdef NRX_OFDM_PROBE
+    OFDM_STAMP(11);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_ofdm_probe[13], 1ull);
+#endif
   }
 }
 
@@ -180,6 +215,10 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
   cx<T>* dst = wave + (size_t)row * wave_stride;
   const int pad_lo = (nfft - K + 1) / 2;  // grid.py:543
   const double inv_n = 1.0 / (double)nfft;
+#ifdef NRX_OFDM_PROBE
+  unsigned long long pk_prev = 0;
+  OFDM_STAMP(-1);
+#endif
   // (unrolled by 4: the loads of four iterations are in flight together -- with two 4-wave workgroups per CU a
   //  load-use-load chain of 16 iterations was most of this kernel's time)
 #pragma unroll 4
@@ -187,6 +226,7 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
     const int j = (i + nfft / 2) & (nfft - 1);
     const int k = j - pad_lo;
     cx<T> v(0, 0);
+#if NRX_OFDM_ABLATE != 2
     if (k >= 0 && k < K) {
       if (f) {
         cx<double> acc(0, 0);
@@ -196,10 +236,18 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
         v = src[(size_t)l * K + k];
       }
     }
+#else
+    v = cx<T>((T)k, (T)i);
+#endif
     buf[nrx::fft_idx(i)] = v;
   }
+  OFDM_STAMP(0);
   __syncthreads();
+  OFDM_STAMP(1);
+#if NRX_OFDM_ABLATE != 1
   nrx::fft_dif_lds(buf, tw, nfft, log2n, true);
+#endif
+  OFDM_STAMP(2);
   const int cp = g.cp[l], n_l = cp + nfft;
 #pragma unroll 4
   for (int i = threadIdx.x; i < n_l + w; i += blockDim.x) {
@@ -217,6 +265,10 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
       dst[pos] = v;
     }
   }
+#ifdef NRX_OFDM_PROBE
+  OFDM_STAMP(3);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_ofdm_probe[5], 1ull);
+#endif
 }
 
 template <typename T>
@@ -260,7 +312,7 @@ int32_t fill_geom(const int32_t* cp_lens, int32_t n_sym, int32_t nfft, SymGeom* 
 template <typename T>
 int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
                   int32_t window_len, void* wave, int64_t wave_stride, void* stream, const void* f = nullptr,
-                  int64_t f_stride = 0, int32_t nl = 0, int32_t ports = 1, void* tails = nullptr) {
+                  int64_t f_stride = 0, int32_t nl = 0, int32_t ports = 1, void* tails = nullptr, bool force_sym = false) {
   NRX_REQUIRE(grid && wave, NRX_E_ARG, "nrx_ofdm_modulate: NULL buffer");
   NRX_REQUIRE(!f || (nl >= 1 && nl <= 8 && ports >= 1 && n_rows % ports == 0), NRX_E_ARG,
               "nrx_ofdm_modulate_precoded: bad layer / port counts");
@@ -277,7 +329,8 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
   if (n_rows == 0) return NRX_OK;
   const cx<double>* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_ofdm_modulate: FFT twiddle table unavailable");
-  if (tails || window_len == 0) {   // symbol-parallel form
+  if (tails || window_len == 0 || force_sym) {   // symbol-parallel form
+    NRX_REQUIRE(tails || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_sym: windowing needs the tails workspace");
     const size_t lds = sizeof(cx<T>) * nrx::fft_lds_elems((size_t)nfft);
     auto kern = ofdm_mod_sym_kernel<T>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -342,7 +395,20 @@ extern "C" int32_t nrx_ofdm_demodulate_awgn_f32(const void* wave, int64_t wave_s
 extern "C" int32_t nrx_ofdm_demodulate_awgn_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset, item_ids); }
 extern "C" int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<float>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
 extern "C" int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
+extern "C" int32_t nrx_ofdm_modulate_sym_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { return mod_entry<float>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, nullptr, 0, 0, 1, tails_ws, true); }
+extern "C" int32_t nrx_ofdm_modulate_sym_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, nullptr, 0, 0, 1, tails_ws, true); }
 extern "C" int32_t nrx_ofdm_modulate_precoded_f32(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); NRX_REQUIRE(tails_ws || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_precoded: windowing needs the tails workspace"); return mod_entry<float>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports, tails_ws); }
 extern "C" int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_items, int32_t n_layers, int32_t n_ports, const void* f, int64_t f_stride, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* tails_ws, void* stream) { NRX_REQUIRE(f, NRX_E_ARG, "nrx_ofdm_modulate_precoded: NULL precoder"); NRX_REQUIRE(tails_ws || window_len == 0, NRX_E_ARG, "nrx_ofdm_modulate_precoded: windowing needs the tails workspace"); return mod_entry<double>(layers, n_items * n_ports, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream, f, f_stride, n_layers, n_ports, tails_ws); }
 extern "C" int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream) { return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, nullptr, 0, 0, 0, 0, nullptr, cp_offset_ratio); }
 extern "C" int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream) { return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, nullptr, 0, 0, 0, 0, nullptr, cp_offset_ratio); }
+
+#ifdef NRX_OFDM_PROBE
+extern "C" int32_t nrx_debug_ofdm_probe(unsigned long long* out16, int32_t reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ofdm_probe), sizeof(unsigned long long) * 16) != hipSuccess) return NRX_E_HIP;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ofdm_probe), z, sizeof(z)) != hipSuccess) return NRX_E_HIP;
+  }
+  return NRX_OK;
+}
+#endif

@@ -341,10 +341,12 @@ class PdschLink:
         else:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
-            tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay,
-                                   f=None if self.prg else F)                   # wideband precoder fused into the load
-            ry = ops.apply_td_paths(tx, gains1, self.taps, self.tap_off, [int(v) for v in self.sym_lens[sis]],
-                                    hist=self.td_hist)
+            # A wideband precoder is the same Nt x Nl matrix on every subcarrier, so it commutes with the modulator: the Nl
+            # LAYER grids are modulated (one read of each row) and the precoder goes into the path gains of the channel filter
+            # (ops.fold_precoder).  Per-PRG precoders depend on the subcarrier and were applied to the grid above.
+            tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay)
+            ry = ops.apply_td_paths(tx, gains1 if self.prg else ops.fold_precoder(gains1, F), self.taps, self.tap_off,
+                                    [int(v) for v in self.sym_lens[sis]], hist=self.td_hist)
             width = ry.shape[-1]
             _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=self.nfft / (12.0 * self.bwp.numRbs),
                                            nv_mult=float(self.nfft), gather=self._cp_gather(sis, width))

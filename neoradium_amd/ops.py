@@ -531,7 +531,11 @@ def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0, f=None):
     wave = torch.empty((n, nt, S + pad), dtype=grid.dtype, device=dev)
     if pad:
         wave[:, :, S:].zero_()
-    if f is None:
+    if f is None and n * P >= 64:      # enough rows to fill the chip twice over: symbols in parallel (the same samples)
+        fn = getattr(lib(), 'nrx_ofdm_modulate_sym_' + sfx)
+        tails = torch.empty((n, nt, L, int(window_len)), dtype=grid.dtype, device=dev) if window_len else None
+        check(fn(ptr(grid), n * P, K, nfft, _host_i32(cp_lens), L, int(window_len), ptr(wave), S + pad, ptr(tails), stream()))
+    elif f is None:
         fn = getattr(lib(), 'nrx_ofdm_modulate_' + sfx)
         check(fn(ptr(grid), n * P, K, nfft, _host_i32(cp_lens), L, int(window_len), ptr(wave), S + pad, stream()))
     else:
@@ -959,6 +963,21 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None):
     check(lib().nrx_apply_td_paths_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen,
                                        hist, _host_i32(set_lens), ptr(y), stream()))
     return y
+
+
+def fold_precoder(gains1, f):
+    """Wideband precoder folded into the path gains: gains1 (n,T,Nr,Nt,P), f (Nt,Nl) | (n,Nt,Nl) -> (n,T,Nr,Nl,P), so that
+    apply_td_paths on the Nl layer waveforms equals the filter on the Nt precoded ones (see nrx.h)."""
+    gains1 = gains1.to(torch.complex128).contiguous()
+    n, T, nr, nt, P = gains1.shape
+    f = f.to(device=_dev(gains1), dtype=torch.complex128).contiguous()
+    shared = f.dim() == 2
+    if f.shape[-2] != nt or (not shared and f.shape[0] != n):
+        raise ValueError("fold_precoder: the precoder's shape does not match the gains")
+    nl = f.shape[-1]
+    out = torch.empty((n, T, nr, nl, P), dtype=torch.complex128, device=_dev(gains1))
+    check(lib().nrx_fold_precoder_f64(ptr(gains1), ptr(f), 0 if shared else nt * nl, n, T, nr, nt, nl, P, ptr(out), stream()))
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------- polar

@@ -129,6 +129,7 @@ def test_noise_level_and_noise(dev):
 
 @pytest.mark.parametrize("mu,nfft,K,slot", [(0, 2048, 300, 0), (1, 1024, 612, 1), (1, 4096, 3276, 0), (2, 512, 240, 2)])
 def test_ofdm_mod_demod(dev, mu, nfft, K, slot):
+    import torch
     from neoradium_amd import ops
     rng = np.random.default_rng(nfft + K)
     n, P, L = 2, 2, 14
@@ -147,6 +148,12 @@ def test_ofdm_mod_demod(dev, mu, nfft, K, slot):
         two = ops.ofdm_modulate(ops.precode(T(grid, dev), T(F, dev)), nfft, cps, window_len=win, pad=5)
         assert fused.shape == two.shape == (n, 4, ref.shape[-1] + 5)
         assert np.array_equal(fused.cpu().numpy(), two.cpu().numpy()), win
+    # many rows: the symbol-parallel entry (nrx_ofdm_modulate_sym_*) == the sequential one, sample for sample
+    big = crandn(rng, 40, P, L, K)
+    for win in (0, w):
+        par = ops.ofdm_modulate(T(big, dev), nfft, cps, window_len=win, pad=3)              # 80 rows: symbol-parallel
+        seq = torch.cat([ops.ofdm_modulate(T(big[i:i + 10], dev), nfft, cps, window_len=win, pad=3) for i in range(0, 40, 10)])
+        assert torch.equal(par, seq), win
     # demodulate a time-shifted noisy waveform with per-item timing offsets
     S = ref.shape[-1]
     rxw = np.concatenate([crandn(rng, n, P, 20), ref, crandn(rng, n, P, 30)], axis=-1)
@@ -225,6 +232,20 @@ def test_tdl_chain(dev):
     for b in range(n):
         ref_y = op.apply_td(x[b], ref_g[b], coeff, cps + nfft)
         assert rel(y[b], ref_y) < 1e-11 and rel(y2[b], ref_y) < 1e-11
+    # a wideband precoder folded into the gains (nrx_fold_precoder_f64): filtering the Nl layer signals with the folded gains
+    # == filtering the Nt precoded signals (the time-domain link modulates layers, grid.py:505-516 + channelmodel.py:431-447)
+    nl = 3
+    F = crandn(rng, n, nt, nl)
+    s_l = crandn(rng, n, nl, ns)
+    s_l[..., slot_len:] = 0
+    gf = ops.fold_precoder(gains, T(F, dev))
+    assert rel(gf.cpu().numpy(), np.einsum('bcrtp,btl->bcrlp', ref_g, F)) < 1e-13
+    y3 = ops.apply_td_paths(T(s_l, dev), gf, T(taps, dev), offs, list(cps + nfft)).cpu().numpy()
+    xp = np.einsum('btl,bls->bts', F, s_l)
+    y4 = ops.apply_td_paths(T(xp, dev), gains, T(taps, dev), offs, list(cps + nfft)).cpu().numpy()
+    assert rel(y3, y4) < 1e-12
+    gs = ops.fold_precoder(gains, T(F[0], dev))                                             # one precoder for all items
+    assert rel(gs.cpu().numpy(), np.einsum('bcrtp,tl->bcrlp', ref_g, F[0])) < 1e-13
 
 
 @pytest.mark.parametrize("P,l_cdm,ds,ctype", [(1, 1, [2], 1), (2, 1, [2, 11], 1), (4, 1, [2, 7, 11], 1), (4, 2, [2, 3, 10, 11], 1),
