@@ -16,6 +16,8 @@ everything that depends only on (configuration, slot number in frame) is precomp
 Slots are independent given their absolute slot index (channel time, DMRS/scrambling by slotNoInFrame), so a
 sweep shards over GPUs by slot range with no data-path communication; only the 4 error counters are reduced.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -197,6 +199,7 @@ class PdschLink:
         self.A, self.nu = D(tb_['A']), D(tb_['nu'])
         self.Alos, self.nulos = (None if tb_['Alos'] is None else D(tb_['Alos'])), tb_['nulos']
         self.static_at = tb_.get('static_at')
+        self._side = None            # second stream: the channel chain of a batch runs beside its Tx chain
         coeff = tb_['coeff']
         self.coeff = D(coeff)
         taps, offs = ops.path_taps(coeff, channel.filterLen)
@@ -272,6 +275,39 @@ class PdschLink:
                 det.append((sel, d))
         return (counters, det) if details else counters
 
+    def _channel_chain(self, slots, n):
+        """Path gains, timing offset, channel matrix (where the link needs it), precoder(s) and -- time-domain link with a
+        wideband precoder -- the gains with the precoder folded in, of the slots of one batch."""
+        times = D(self.gain_times(slots))
+        if self.static_at is None:
+            gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
+        else:                       # per-slot ray coefficients (host draws in the class surface's order, see host_tables)
+            per = [self.static_at(int(s)) for s in slots]
+            gains1 = ops.cdl_gains(D(np.stack([a for a, _ in per])), D(np.stack([v for _, v in per])), times,
+                                   A_los=self.Alos, nu_los=self.nulos)
+        H = hsub = None
+        need_h = self.freqDomain or self.chanEst == "Perfect" or self.prg
+        fusedcs = None if need_h else ops.chan_setup(gains1, self.coeff, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+        if fusedcs is not None:     # time-domain link, estimated channel, wideband precoder: the CIR is needed for nothing else
+            hsub, off = fusedcs
+        else:
+            cir1, off = ops.cir(gains1, self.coeff, self.L)
+        if need_h:
+            H = ops.channel_matrix(cir1, off, self.L, self.K, self.nfft)
+        if self.prg:        # one SVD precoder per PRG: mean channel of the group -> right singular vectors
+            hm = ops.group_mean(H, self.prg_k0, self.prg_nk)                    # (n, G, Nr, Nt)
+            G = hm.shape[1]
+            F = ops.svd_precoder(hm.reshape(n * G, 1, self.nr, self.nt), self.nl).reshape(n, G, self.nt, self.nl)
+        else:
+            if hsub is None:
+                hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+            F = ops.svd_precoder(hsub, self.nl)                                 # wideband SVD precoder (first PRB)
+        # A wideband precoder is the same Nt x Nl matrix on every subcarrier, so it commutes with the modulator: the Nl LAYER
+        # grids are modulated (one read of each row) and the precoder goes into the path gains of the channel filter.
+        # Per-PRG precoders depend on the subcarrier and are applied to the grid.
+        gfold = None if (self.freqDomain or self.prg) else ops.fold_precoder(gains1, F)
+        return gains1, off, H, F, gfold
+
     def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details, harq=None):
         """One batch of slots with identical geometry.  ``harq`` = one (rv, circ, reset) per codeword: per-slot redundancy
         versions (int32 device tensor), the resident soft buffers and the restart flags of a batched HARQ round."""
@@ -284,6 +320,20 @@ class PdschLink:
         ids = None if contiguous else torch.as_tensor(np.asarray(slots, dtype=np.int64), device=dev)
         snr_lin = torch.full((n,), 10.0 ** (float(snr_db) / 10.0), dtype=torch.float64, device=dev) \
             if np.isscalar(snr_db) else D(10.0 ** (np.float64(snr_db) / 10.0))
+
+        # ---- channel state of each slot, on a second stream: it depends on nothing of the Tx bit chain (since the wideband
+        # precoder went into the channel filter's gains the modulator does not wait for it either), and its kernels are one
+        # workgroup per slot, latency-bound -- they run beside the Tx chain instead of in front of it.
+        cur = torch.cuda.current_stream(dev)
+        if self._side is None:      # (NRX_NO_SIDE_STREAM: developer switch, everything on one stream)
+            self._side = cur if os.environ.get('NRX_NO_SIDE_STREAM') else torch.cuda.Stream(device=dev)
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ch = self._channel_chain(slots, n)
+        for t in ch:
+            if t is not None:
+                t.record_stream(cur)         # allocated on the side stream, consumed on this one
 
         # ---- Tx
         grid = None if self.numCW == 1 else self.templates.index_select(0, sif)   # DMRS-filled (n, Nl, L, K)
@@ -306,32 +356,13 @@ class PdschLink:
                 ops.qam_map(bits, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], out=grid)
         tb = tbs_in[0]
 
-        # ---- channel state of each slot
-        times = D(self.gain_times(slots))
-        if self.static_at is None:
-            gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
-        else:                       # per-slot ray coefficients (host draws in the class surface's order, see host_tables)
-            per = [self.static_at(int(s)) for s in slots]
-            gains1 = ops.cdl_gains(D(np.stack([a for a, _ in per])), D(np.stack([v for _, v in per])), times,
-                                   A_los=self.Alos, nu_los=self.nulos)
-        H = hsub = None
-        need_h = self.freqDomain or self.chanEst == "Perfect" or self.prg
-        fusedcs = None if need_h else ops.chan_setup(gains1, self.coeff, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
-        if fusedcs is not None:     # time-domain link, estimated channel, wideband precoder: the CIR is needed for nothing else
-            hsub, off = fusedcs
-        else:
-            cir1, off = ops.cir(gains1, self.coeff, self.L)
-        if need_h:
-            H = ops.channel_matrix(cir1, off, self.L, self.K, self.nfft)
-        if self.prg:        # one SVD precoder per PRG: mean channel of the group -> right singular vectors
-            hm = ops.group_mean(H, self.prg_k0, self.prg_nk)                    # (n, G, Nr, Nt)
-            G = hm.shape[1]
-            F = ops.svd_precoder(hm.reshape(n * G, 1, self.nr, self.nt), self.nl).reshape(n, G, self.nt, self.nl)
+        # ---- join the channel chain (launched on the side stream in front of the Tx chain) where its results are first consumed:
+        # behind the modulator on the time-domain link with a wideband precoder, here otherwise
+        gains1, off, H, F, gfold = ch
+        if self.prg or self.freqDomain:
+            cur.wait_stream(side)
+        if self.prg:
             grid = ops.precode_prg(grid, F, self.prg_k2g)                       # (n, Nt, L, K); F is applied from here on
-        else:
-            if hsub is None:
-                hsub = ops.channel_matrix_sub(cir1, off, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
-            F = ops.svd_precoder(hsub, self.nl)                                 # wideband SVD precoder (first PRB)
 
         if self.freqDomain:
             rx = ops.apply_channel_fd(grid if self.prg else ops.precode(grid, F), H)
@@ -341,11 +372,10 @@ class PdschLink:
         else:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
-            # A wideband precoder is the same Nt x Nl matrix on every subcarrier, so it commutes with the modulator: the Nl
-            # LAYER grids are modulated (one read of each row) and the precoder goes into the path gains of the channel filter
-            # (ops.fold_precoder).  Per-PRG precoders depend on the subcarrier and were applied to the grid above.
-            tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay)
-            ry = ops.apply_td_paths(tx, gains1 if self.prg else ops.fold_precoder(gains1, F), self.taps, self.tap_off,
+            tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay)      # layers (wideband) | ports (PRG)
+            if not self.prg:
+                cur.wait_stream(side)
+            ry = ops.apply_td_paths(tx, gains1 if self.prg else gfold, self.taps, self.tap_off,
                                     [int(v) for v in self.sym_lens[sis]], hist=self.td_hist)
             width = ry.shape[-1]
             _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=self.nfft / (12.0 * self.bwp.numRbs),
