@@ -167,7 +167,7 @@ __device__ __forceinline__ void sel_fma_first(double& x, uint32_t& idx, uint64_t
 // Developer build only (tools/probe_dec3.sh): s_memtime stamps at the phase boundaries of every layer, accumulated per
 // wave in SGPRs and summed here.  [0..3] wide layers (degree > 10), [4..7] narrow layers: pass 1 (LDS reads + t = r - m),
 // min-sum, pass 2 (+ write drain + next layer's mask loads), barrier; [8] waves, [9] layers stamped.
-__device__ unsigned long long g_probe[10];
+__device__ unsigned long long g_probe[14];   // [10] fill (+ its barrier), [11] tail (hard decisions / CRC + merge, + its barrier), [12] code-block rounds
 #define PROBE_STAMP(K)                                                                   \
   do {                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -310,9 +310,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   double f1 = 0.0;                                         // column 1 handed from a layer to its successor (Lay::fwd1)
 
 #ifdef NRX_DEC3_PROBE
-  uint32_t pk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0;
+  uint32_t pk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0, pk_rounds = 0;
 #endif
   for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
+    PROBE_STAMP(-1);
     const int cb = cb0 + slot;
     int one = 1;
     asm volatile("" : "+s"(one));                          // keeps the per-layer `if (live)` a real branch (see dec2)
@@ -345,42 +346,69 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     asm volatile("" : "+v"(zl0));
     const int zl = zl0;
     // rot: the element wanted is (z + rot) mod Zc (a layer's extension column under the layer's row rotation, Lay::sigma)
-    auto fetch = [&](int p0, int rot = 0) __attribute__((always_inline)) -> double {
-      int zl = zl0 + rot;
-      zl -= zl >= ZC ? ZC : 0;
+    // Two phases: every load of the fill first (35 per lane, all in flight together), the selection afterwards.  Written as
+    // one expression per column the compiler put a branch around each column's clip ("no lane of the wave received this
+    // column"), and with it a full wait behind each load: 35 dependent round trips per code block, 0.6 ms per 256 slots.
+    auto elem = [&](int rot) __attribute__((always_inline)) -> int {
+      int zr = zl0 + rot;
+      zr -= zr >= ZC ? ZC : 0;
+      return zr;
+    };
+    auto addr = [&](int p0, int rot) __attribute__((always_inline)) -> int {
+      const int zr = elem(rot);
       if constexpr (!FUSED) {
-        return clip10(in[p0 + zl]) + 0.0;
+        return p0 + zr;
       } else {
         // lanes [0, a): before the fillers (buffer position p0 + z); [a, b): fillers; [b, Zc): behind them (p0 - F + z);
         // transmitted iff the buffer position is < E_r, i.e. z < t1 resp. z < t2 -- four wave-uniform thresholds per column
         const int a = fg.sys_len - p0, b = a + fg.F, t1 = fE - p0, t2 = t1 + fg.F;
-        const bool use1 = zl < a && zl < t1, use2 = zl >= b && zl < t2;
-        const double x = in[foff + (use1 ? p0 + zl : (use2 ? p0 - fg.F + zl : 0))];
+        const bool use1 = zr < a && zr < t1, use2 = zr >= b && zr < t2;
+        return foff + (use1 ? p0 + zr : (use2 ? p0 - fg.F + zr : 0));     // (a lane without a value loads the block's first one)
+      }
+    };
+    auto value = [&](double x, int p0, int rot) __attribute__((always_inline)) -> double {
+      const double v = clip10(x) + 0.0;
+      if constexpr (!FUSED) {
+        return v;
+      } else {
         // (the selection is recomputed from an opaque copy of the lane index: otherwise the flags of all 35 columns are kept
-        //  alive across the loads -- 11 of them went to scratch and came back one dependent round trip at a time)
-        int zz = zl;
-        asm volatile("" : "+v"(zz));
+        //  alive across the loads)
+        int zz = elem(rot);
+        asm("" : "+v"(zz));
+        const int a = fg.sys_len - p0, b = a + fg.F, t1 = fE - p0, t2 = t1 + fg.F;
         const bool sent = (zz < a && zz < t1) || (zz >= b && zz < t2);
         const bool filler = zz >= a && zz < b;                             // LARGE_LLR 1e20, clipped (ldpc.py:1414-1418)
-        const double v = sent ? clip10(x) + 0.0 : 0.0;
-        return filler ? 1e10 : v;
+        const double w = sent ? v : 0.0;
+        return filler ? 1e10 : w;
       }
     };
     // ---- load: prepend the two punctured columns as zeros (ldpc.py:1536-1538)
-    static_for<B::CORE>([&](auto cc) __attribute__((always_inline)) {
-      constexpr int c = decltype(cc)::value;
-      if constexpr (c == 1) Ps[c * ZS + zl] = 0.0;
-      else if constexpr (c >= 2) Ps[c * ZS + zl] = fetch((c - 2) * ZC);
-    });
-    static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
-      constexpr int L = decltype(lc)::value;
-      m1[L] = 0.0;
-      m2[L] = 0.0;
-      if constexpr (Y::has_ext(L)) {
-        rext[Y::ext_idx(L)] = fetch((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L));      // element of row (z + sigma_L)
-        if constexpr (!FUSED) rext[Y::ext_idx(L)] = L < rows_live ? rext[Y::ext_idx(L)] : 0.0;      // (wave-uniform)
-      }
-    });
+    {
+      double xs[B::CORE - 2 + NEXT];
+      static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        xs[c] = in[addr(c * ZC, 0)];
+      });
+      static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(lc)::value;
+        if constexpr (Y::has_ext(L)) xs[B::CORE - 2 + Y::ext_idx(L)] = in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))];   // element of row (z + sigma_L)
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      Ps[1 * ZS + zl] = 0.0;
+      static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        Ps[(c + 2) * ZS + zl] = value(xs[c], c * ZC, 0);
+      });
+      static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(lc)::value;
+        m1[L] = 0.0;
+        m2[L] = 0.0;
+        if constexpr (Y::has_ext(L)) {
+          rext[Y::ext_idx(L)] = value(xs[B::CORE - 2 + Y::ext_idx(L)], (Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L));
+          if constexpr (!FUSED) rext[Y::ext_idx(L)] = L < rows_live ? rext[Y::ext_idx(L)] : 0.0;      // (wave-uniform)
+        }
+      });
+    }
     c0 = 0.0;                                              // punctured column (ldpc.py:1536-1538)
     static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
     static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
@@ -392,7 +420,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       wcur[decltype(jc)::value] = wm[B::row_start(0) + decltype(jc)::value];
     });
 
-    PROBE_STAMP(-1);
+    PROBE_STAMP(8);
     for (int it = 0; it < n_iter; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -558,6 +586,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       });
     }
     __syncthreads();
+    PROBE_STAMP(-1);
 
     // ---- hard decisions of the information columns (ldpc.py:1578-1581)
     if constexpr (!FUSED) {
@@ -607,9 +636,16 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       }
     }
     __syncthreads();
+#ifdef NRX_DEC3_PROBE
+    PROBE_STAMP(9);
+    pk_rounds += 1;
+#endif
   }
 #ifdef NRX_DEC3_PROBE
   if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&g_probe[10], (unsigned long long)pk_acc[8]);
+    atomicAdd(&g_probe[11], (unsigned long long)pk_acc[9]);
+    atomicAdd(&g_probe[12], (unsigned long long)pk_rounds);
     for (int k = 0; k < 8; ++k) atomicAdd(&g_probe[k], (unsigned long long)pk_acc[k]);
     atomicAdd(&g_probe[8], 1ull);
     atomicAdd(&g_probe[9], (unsigned long long)pk_layers);
@@ -720,10 +756,10 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t 
 }
 
 #ifdef NRX_DEC3_PROBE
-extern "C" int32_t nrx_debug_dec3_probe(unsigned long long* out10, int32_t reset) {
-  if (out10 && hipMemcpyFromSymbol(out10, HIP_SYMBOL(nrx_dec3::g_probe), sizeof(unsigned long long) * 10) != hipSuccess) return NRX_E_HIP;
+extern "C" int32_t nrx_debug_dec3_probe(unsigned long long* out14, int32_t reset) {
+  if (out14 && hipMemcpyFromSymbol(out14, HIP_SYMBOL(nrx_dec3::g_probe), sizeof(unsigned long long) * 14) != hipSuccess) return NRX_E_HIP;
   if (reset) {
-    const unsigned long long z[10] = {};
+    const unsigned long long z[14] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(nrx_dec3::g_probe), z, sizeof(z)) != hipSuccess) return NRX_E_HIP;
   }
   return NRX_OK;

@@ -16,8 +16,13 @@ rows = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 llr = (2 / 0.78**2 + (2 / 0.78) * torch.randn((n_cb, cfg.N), device=dev, generator=g, dtype=torch.float64))
 llr[:, 13104:] = 0
 lib = ctypes.CDLL(os.environ['NRX_LIB'])
-out = (ctypes.c_ulonglong * 10)()
+out = (ctypes.c_ulonglong * 14)()
 run = lambda: ops.ldpc_decode(llr, cfg, 50, rows=rows)
+if len(sys.argv) > 3 and sys.argv[3] == 'fused':      # the headline entry: rate recovery in the fill, CRC + merge in the tail
+    G, nl, qm = 943488, 4, 6
+    raw = (2 / 0.78**2 + (2 / 0.78) * torch.randn((n_cb // cfg.C, G), device=dev, generator=g, dtype=torch.float64))
+    rows = ops.ldpc_active_rows(cfg, max(_lib.ldpc_cb_lens(G, cfg.C, nl, qm)))
+    run = lambda: ops.ldpc_recover_decode_merge(raw, cfg, nl, qm, 50, rows=rows)
 run(); torch.cuda.synchronize()
 assert lib.nrx_debug_dec3_probe(out, 1) == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,3 +46,6 @@ per_iter = tot / waves / (layers / waves / rows)
 res['cycles_per_iteration_per_wave'] = per_iter
 print(f"sum over phases: {per_iter:.0f} cycles per iteration per wave")
 print(json.dumps(res))
+if len(v) > 12 and v[12]:
+    print(f"fill (+ barrier) {v[10] / v[12]:9.0f}   tail (+ barrier) {v[11] / v[12]:9.0f}  cycles per code-block round per wave; "
+          f"{v[12] / waves:.1f} rounds per wave")
