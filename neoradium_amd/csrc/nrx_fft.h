@@ -36,17 +36,22 @@ __device__ __forceinline__ void fft_dif_fused(cx<T>* buf, const cx<double>* __re
     const int a = ((gi >> lq) << (lq + LG)) | lo;
     // the P - 1 distinct twiddles of the fused stages (stage t uses P >> (t+1) of them, each for 2^t butterflies): all
     // fetched up front, so their latency is paid once per pass instead of once per dependent batch of butterflies
-    cx<T> wt[P - 1];
+    // (the loads are fenced from what follows: left to itself the scheduler sinks every one of them to its first use to
+    //  save registers -- load, wait, multiply, P - 1 dependent round trips per pass)
+    cx<double> wd[P - 1];
 #pragma unroll
     for (int t = 0; t < LG; ++t) {
       const int half = P >> (t + 1);
 #pragma unroll
       for (int r = 0; r < half; ++r) {
         const int j = (lo + (r << lq)) << (s + t);
-        const cx<double> wd = tw[(size_t)j * tws];
-        wt[(P - 2 * half) + r] = cx<T>((T)wd.re, inverse ? -(T)wd.im : (T)wd.im);   // offsets 0, P/2, 3P/4, ...
+        wd[(P - 2 * half) + r] = tw[(size_t)j * tws];                             // offsets 0, P/2, 3P/4, ...
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    cx<T> wt[P - 1];
+#pragma unroll
+    for (int m = 0; m < P - 1; ++m) wt[m] = cx<T>((T)wd[m].re, inverse ? -(T)wd[m].im : (T)wd[m].im);
     cx<T> x[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) x[m] = buf[fft_idx(a + (m << lq))];

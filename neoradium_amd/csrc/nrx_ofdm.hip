@@ -7,12 +7,14 @@
 #include "nrx_fft.h"
 #include "nrx_rng.h"
 
-// Threads of a symbol-parallel modulator workgroup.  The radix-16 passes of a 4096-point transform occupy 256 of them;
-// the others double the loads / stores in flight of the fill and write-out phases, which is where this kernel's time goes
-// (two 68 KB workgroups per CU: 8 waves cannot cover the HBM latency of the gathers, 16 do better).
+// Threads of a symbol-parallel modulator workgroup: the 256 the radix-16 passes of a 4096-point transform occupy.  (512 were
+// used while the fill kept one load per thread in flight; with the loads of a chunk issued together 256 threads cover the
+// latency, and at two waves per SIMD each has the 256 registers that keeping a pass's twiddle loads together needs.)
 #ifndef NRX_MOD_THREADS
-#define NRX_MOD_THREADS 512
+#define NRX_MOD_THREADS 256
 #endif
+// elements per thread whose global loads are issued together in the fill phases
+constexpr int FILL_U = 8;
 
 #ifndef NRX_OFDM_ABLATE
 #define NRX_OFDM_ABLATE 0     // developer timing ablations (tools/probe_ofdm.py): 1 = no FFT passes, 2 = no global loads in the fill
@@ -125,7 +127,7 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
 
 // One FFT per (item, antenna, symbol); workgroups loop over tasks so the twiddle table is built once.
 template <typename T>
-__global__ void __launch_bounds__(256)   // (512 threads as in the modulator need <= 128 VGPRs here: spills, 0.96 -> 1.01 ms)
+__global__ void __launch_bounds__(256, 2)   // two 68 KB workgroups per CU = two waves per SIMD: 256 registers each
 ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t wave_len,
                   const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
                   cx<T>* __restrict__ grid, int n_tasks, const cx<double>* __restrict__ tw,
@@ -146,21 +148,45 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
     const int cp = g.cp[l];
     const int off = (int)rint((double)cp * cp_offset_ratio);  // np.round(cpLens * cpOffsetRatio), waveform.py:507
     __syncthreads();
-#pragma unroll 4
-    for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
-      const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));  // waveform.py:509
+    // Fill in two phases per chunk of FILL_U elements per thread: all loads first (in flight together), then the noise and
+    // the LDS stores.  (As one loop the compiler kept one load in flight: load, wait, noise, store -- the branch around
+    // the noise ends the block the loads could have been hoisted in.)
+    const double sg = sigma ? (double)sigma[(size_t)item * sigma_stride] : 0.0;
+    const uint64_t nid = sigma ? (uint64_t)(item_ids ? item_ids[item] : batch_offset + item) : 0;
+    for (int i0 = threadIdx.x; i0 < nfft; i0 += FILL_U * blockDim.x) {
+      cx<T> xs[FILL_U];
+#pragma unroll
+      for (int u = 0; u < FILL_U; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));  // waveform.py:509
 #if NRX_OFDM_ABLATE != 2
-      cx<T> v = s < wave_len ? src[s] : cx<T>(0, 0);
+        xs[u] = (i < nfft && s < wave_len) ? src[s] : cx<T>(0, 0);
 #else
-      cx<T> v = cx<T>((T)s, (T)i);
+        xs[u] = cx<T>((T)s, (T)i);
 #endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
       // sigma != null: the received waveform is noiseless and the AWGN of nrx_awgn_* (same generator, same element
-      // numbering: element = antenna * wave_len + sample of the item) is added while loading
-      if (sigma && s < wave_len)
-        v = nrx::awgn_add<T>(v, (double)sigma[(size_t)item * sigma_stride], seed, stream_id,
-                             (uint64_t)(item_ids ? item_ids[item] : batch_offset + item),
-                             (int64_t)(row - item * n_ant) * wave_len + s);
-      buf[nrx::fft_idx(i)] = v;
+      // numbering: element = antenna * wave_len + sample of the item) is added while loading -- computed here, behind the
+      // issue of the loads and in front of their first use
+      cx<double> nz[FILL_U];
+      if (sigma) {
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) {
+          const int i = i0 + u * blockDim.x;
+          const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));
+          nz[u] = nrx::awgn_noise(sg, seed, stream_id, nid, (int64_t)(row - item * n_ant) * wave_len + s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < FILL_U; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));
+        cx<T> v = xs[u];
+        if (sigma && s < wave_len) v = cx<T>((T)((double)v.re + nz[u].re), (T)((double)v.im + nz[u].im));
+        if (i < nfft) buf[nrx::fft_idx(i)] = v;
+      }
     }
     OFDM_STAMP(8);
     __syncthreads();
@@ -187,7 +213,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
 // place and parks its windowed tail in `tails`; ofdm_tail_add_kernel then adds tail l onto head l+1 (head + tail, the
 // order of the sequential kernel, so both produce identical samples).
 template <typename T>
-__global__ void __launch_bounds__(NRX_MOD_THREADS)
+__global__ void __launch_bounds__(NRX_MOD_THREADS, 2)
 ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
                     cx<T>* __restrict__ wave, int64_t wave_stride, const cx<T>* __restrict__ f, int64_t f_stride, int nl,
                     int ports, const cx<double>* __restrict__ tw, cx<T>* __restrict__ tails, int xcd_pairs) {
@@ -221,25 +247,40 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
 #endif
   // (unrolled by 4: the loads of four iterations are in flight together -- with two 4-wave workgroups per CU a
   //  load-use-load chain of 16 iterations was most of this kernel's time)
+  if (f) {
 #pragma unroll 4
-  for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
-    const int j = (i + nfft / 2) & (nfft - 1);
-    const int k = j - pad_lo;
-    cx<T> v(0, 0);
-#if NRX_OFDM_ABLATE != 2
-    if (k >= 0 && k < K) {
-      if (f) {
+    for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
+      const int j = (i + nfft / 2) & (nfft - 1);
+      const int k = j - pad_lo;
+      cx<T> v(0, 0);
+      if (k >= 0 && k < K) {
         cx<double> acc(0, 0);
         for (int n = 0; n < nl; ++n) nrx::cmac(acc, fw[n], cx<double>(src[((size_t)n * g.n_sym + l) * K + k]));
         v = cx<T>(acc);
-      } else {
-        v = src[(size_t)l * K + k];
+      }
+      buf[nrx::fft_idx(i)] = v;
+    }
+  } else {
+    // all loads of a chunk first, then the LDS stores (see the demodulator's fill)
+    for (int i0 = threadIdx.x; i0 < nfft; i0 += FILL_U * blockDim.x) {
+      cx<T> xs[FILL_U];
+#pragma unroll
+      for (int u = 0; u < FILL_U; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const int k = ((i + nfft / 2) & (nfft - 1)) - pad_lo;
+#if NRX_OFDM_ABLATE != 2
+        xs[u] = (i < nfft && k >= 0 && k < K) ? src[(size_t)l * K + k] : cx<T>(0, 0);
+#else
+        xs[u] = cx<T>((T)k, (T)i);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < FILL_U; ++u) {
+        const int i = i0 + u * blockDim.x;
+        if (i < nfft) buf[nrx::fft_idx(i)] = xs[u];
       }
     }
-#else
-    v = cx<T>((T)k, (T)i);
-#endif
-    buf[nrx::fft_idx(i)] = v;
   }
   OFDM_STAMP(0);
   __syncthreads();

@@ -34,4 +34,18 @@ __device__ __forceinline__ cx<T> awgn_add(cx<T> v, double sigma, uint64_t seed, 
   return cx<T>((T)((double)v.re + s * rad * cs), (T)((double)v.im + s * rad * sn));
 }
 
+// The noise term of awgn_add on its own (what is added to the sample): lets a kernel compute it while the sample's load is
+// still in flight.  v + awgn_noise(...) (component-wise, in double, then rounded to T) IS awgn_add(v, ...).
+__device__ __forceinline__ cx<double> awgn_noise(double sigma, uint64_t seed, uint64_t stream_id, uint64_t item, int64_t e) {
+  uint32_t c[4] = {(uint32_t)e, (uint32_t)((uint64_t)e >> 32), (uint32_t)item, (uint32_t)(item >> 32) ^ (uint32_t)stream_id};
+  philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const double u1 = ((double)(((uint64_t)c[0] << 21) ^ (c[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(((uint64_t)c[2] << 21) ^ (c[3] >> 11))) * (1.0 / 9007199254740992.0);
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincospi(2.0 * u2, &sn, &cs);
+  const double s = sigma / 1.4142135623730951;
+  return cx<double>(s * rad * cs, s * rad * sn);
+}
+
 }  // namespace nrx

@@ -34,6 +34,7 @@ wave = ops.ofdm_modulate(grid, nfft, cp, window_len=0, pad=400, f=f)
 res = {}
 res['mod_nowin_ms'] = timed(lambda: ops.ofdm_modulate(grid, nfft, cp, window_len=0, pad=400, f=f))
 res['mod_win_ms'] = timed(lambda: ops.ofdm_modulate(grid, nfft, cp, window_len=144, pad=400, f=f))
+res['mod_layers_win_ms'] = timed(lambda: ops.ofdm_modulate(grid, nfft, cp, window_len=144, pad=400))      # what the engine runs
 res['demod_awgn_ms'] = timed(lambda: ops.ofdm_demodulate(wave, nfft, cp, K, t_off=toff, awgn=(sig, 1, 2, 0)))
 res['demod_plain_ms'] = timed(lambda: ops.ofdm_demodulate(wave, nfft, cp, K, t_off=toff))
 print(json.dumps(res))
