@@ -201,68 +201,91 @@ qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __
   double lev[h > 0 ? (1 << h) : 1];
 #pragma unroll
   for (int a = 0; a < (1 << h); ++a) lev[a] = (double)pam_level(a, h) * scale;
-  // grid: (x-blocks over the symbols, batch items): 32-bit indices, no 64-bit division per element
-  for (int b = blockIdx.y; b < n_batch; b += gridDim.y)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sym; i += gridDim.x * blockDim.x) {
-    const int64_t src = re_index ? (int64_t)re_index[i] : (int64_t)i;
-    const cx<T> y = syms[(size_t)b * sym_stride + src];
+  // grid: (x-blocks over the symbols, batch items): 32-bit indices, no 64-bit division per element.
+  // Every load of a symbol is issued before its arithmetic starts, the RE index of the thread's NEXT symbol with them: left
+  // as one expression per use the compiler sank each load to its use -- index, wait, symbol, wait, and one scrambling byte
+  // with a wait behind each of the QM division chains: QM + 2 dependent round trips per symbol.
+  const int stride = gridDim.x * blockDim.x;
+  for (int b = blockIdx.y; b < n_batch; b += gridDim.y) {
     double nv = (double)noise_var[(size_t)b * nv_stride];
     nv = nv > nv_floor ? nv : nv_floor;  // pdsch.py:966 max(noiseVar, 1e-10)
-    const double sc = scales ? (double)scales[(size_t)b * sym_stride + src] : 1.0;
-    const double rn = RECIP ? sc / nv : 0.0;
-    // LLR q of symbol i goes to i*QM + q (the reference's order), or -- code-block option -- to its de-interleaved place
-    // inside its code block: position q*(E_r/QM) + s of block r (ldpc.py:1390-1397 done by the store; stride dq between the
-    // QM values of a symbol, consecutive symbols = consecutive lanes = consecutive addresses)
-    TL* dst = llr + (size_t)b * llr_stride + (size_t)i * QM;
-    int dq = 1;
-    if (dg.e_small > 0) {
-      const int ss = dg.e_small / QM, split = dg.n_small * ss;
-      int r, sidx, off;
-      if (i < split) { r = i / ss; sidx = i - r * ss; dq = ss; off = r * dg.e_small; }
-      else { dq = (dg.e_small + dg.f) / QM; r = (i - split) / dq; sidx = (i - split) - r * dq; off = dg.n_small * dg.e_small + r * (dg.e_small + dg.f); }
-      dst = llr + (size_t)b * llr_stride + off + sidx;
-    }
-    if constexpr (QM == 1) {
-      const double d0 = ((double)y.re - scale) * ((double)y.re - scale) + ((double)y.im - scale) * ((double)y.im - scale);
-      const double d1 = ((double)y.re + scale) * ((double)y.re + scale) + ((double)y.im + scale) * ((double)y.im + scale);
-      double l = (-d0 / nv) - (-d1 / nv);
-      if (scr) l *= (double)(1 - 2 * (int)(scr[i] & 1));
-      dst[0] = (TL)(l * sc);
-    } else {
-      TL out[QM];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t src = i < n_sym ? (re_index ? (int64_t)re_index[i] : (int64_t)i) : 0;
+    for (; i < n_sym; i += stride) {
+      const cx<T> y = syms[(size_t)b * sym_stride + src];
+      const double sc = scales ? (double)scales[(size_t)b * sym_stride + src] : 1.0;
+      uint32_t sbits = 0;                 // bit `pos` = scrambling bit of LLR `pos` of this symbol (pdsch.py:611-616)
+      if (scr) {
+        if constexpr (QM == 1) {
+          sbits = scr[i] & 1u;
+        } else {
+          const uint16_t* sp = (const uint16_t*)(scr + (size_t)i * QM);     // QM even: 16-bit aligned (checked by the host)
 #pragma unroll
-      for (int axis = 0; axis < 2; ++axis) {
-        const double yv = axis == 0 ? (double)y.re : (double)y.im;
-        double m0[h], m1[h];
-#pragma unroll
-        for (int q = 0; q < h; ++q) m0[q] = m1[q] = 1e300;
-#pragma unroll
-        for (int a = 0; a < (1 << h); ++a) {
-          const double d = yv - lev[a];
-          const double d2 = d * d;
-#pragma unroll
-          for (int q = 0; q < h; ++q) {
-            if ((a >> (h - 1 - q)) & 1) m1[q] = d2 < m1[q] ? d2 : m1[q];
-            else m0[q] = d2 < m0[q] ? d2 : m0[q];
+          for (int k = 0; k < h; ++k) {
+            const uint32_t w = sp[k];
+            sbits |= ((w & 1u) << (2 * k)) | (((w >> 8) & 1u) << (2 * k + 1));
           }
-        }
-#pragma unroll
-        for (int q = 0; q < h; ++q) {
-          const int pos = 2 * q + axis;  // bit index inside the symbol
-          double l;
-          if constexpr (RECIP) {
-            l = (m1[q] - m0[q]) * rn;                        // = ((-m0/nv) - (-m1/nv)) * sc up to rounding
-            if (scr) l = (scr[(size_t)i * QM + pos] & 1) ? -l : l;
-          } else {
-            l = (-m0[q] / nv) - (-m1[q] / nv);               // modulation.py:200-202, positive = bit 0
-            if (scr) l *= (double)(1 - 2 * (int)(scr[(size_t)i * QM + pos] & 1));  // pdsch.py:611-616
-            l = l * sc;                                                              // pdsch.py:1002-1003
-          }
-          out[pos] = (TL)l;
         }
       }
+      const int inext = i + stride;
+      const int64_t src_next = inext < n_sym ? (re_index ? (int64_t)re_index[inext] : (int64_t)inext) : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      const double rn = RECIP ? sc / nv : 0.0;
+      // LLR q of symbol i goes to i*QM + q (the reference's order), or -- code-block option -- to its de-interleaved place
+      // inside its code block: position q*(E_r/QM) + s of block r (ldpc.py:1390-1397 done by the store; stride dq between the
+      // QM values of a symbol, consecutive symbols = consecutive lanes = consecutive addresses)
+      TL* dst = llr + (size_t)b * llr_stride + (size_t)i * QM;
+      int dq = 1;
+      if (dg.e_small > 0) {
+        const int ss = dg.e_small / QM, split = dg.n_small * ss;
+        int r, sidx, off;
+        if (i < split) { r = i / ss; sidx = i - r * ss; dq = ss; off = r * dg.e_small; }
+        else { dq = (dg.e_small + dg.f) / QM; r = (i - split) / dq; sidx = (i - split) - r * dq; off = dg.n_small * dg.e_small + r * (dg.e_small + dg.f); }
+        dst = llr + (size_t)b * llr_stride + off + sidx;
+      }
+      if constexpr (QM == 1) {
+        const double d0 = ((double)y.re - scale) * ((double)y.re - scale) + ((double)y.im - scale) * ((double)y.im - scale);
+        const double d1 = ((double)y.re + scale) * ((double)y.re + scale) + ((double)y.im + scale) * ((double)y.im + scale);
+        double l = (-d0 / nv) - (-d1 / nv);
+        if (scr) l *= (double)(1 - 2 * (int)(sbits & 1u));
+        dst[0] = (TL)(l * sc);
+      } else {
+        TL out[QM];
 #pragma unroll
-      for (int q = 0; q < QM; ++q) dst[(size_t)q * dq] = out[q];
+        for (int axis = 0; axis < 2; ++axis) {
+          const double yv = axis == 0 ? (double)y.re : (double)y.im;
+          double m0[h], m1[h];
+#pragma unroll
+          for (int q = 0; q < h; ++q) m0[q] = m1[q] = 1e300;
+#pragma unroll
+          for (int a = 0; a < (1 << h); ++a) {
+            const double d = yv - lev[a];
+            const double d2 = d * d;
+#pragma unroll
+            for (int q = 0; q < h; ++q) {
+              if ((a >> (h - 1 - q)) & 1) m1[q] = d2 < m1[q] ? d2 : m1[q];
+              else m0[q] = d2 < m0[q] ? d2 : m0[q];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < h; ++q) {
+            const int pos = 2 * q + axis;  // bit index inside the symbol
+            double l;
+            if constexpr (RECIP) {
+              l = (m1[q] - m0[q]) * rn;                        // = ((-m0/nv) - (-m1/nv)) * sc up to rounding
+              if (scr) l = ((sbits >> pos) & 1u) ? -l : l;
+            } else {
+              l = (-m0[q] / nv) - (-m1[q] / nv);               // modulation.py:200-202, positive = bit 0
+              if (scr) l *= (double)(1 - 2 * (int)((sbits >> pos) & 1u));  // pdsch.py:611-616
+              l = l * sc;                                                    // pdsch.py:1002-1003
+            }
+            out[pos] = (TL)l;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < QM; ++q) dst[(size_t)q * dq] = out[q];
+      }
+      src = src_next;
     }
   }
 }
@@ -400,6 +423,7 @@ int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, co
   }
   NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_qam_demap: unsupported modulation order %d", qm);
   NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && llr_stride >= (int64_t)n_sym * qm, NRX_E_SHAPE, "nrx_qam_demap: bad sizes");
+  NRX_REQUIRE(!scr || qm == 1 || ((uintptr_t)scr & 1u) == 0, NRX_E_ARG, "nrx_qam_demap: the scrambling sequence must be 2-byte aligned");
   if (n_sym == 0 || n_batch == 0) return NRX_OK;
   const dim3 grid = sym_batch_grid(n_sym, n_batch);
   if (exact)
