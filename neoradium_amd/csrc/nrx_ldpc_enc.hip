@@ -85,6 +85,20 @@ __device__ uint32_t block_crc(const uint8_t* __restrict__ row, int64_t n, const 
   if (i < 0) i = 0;
   uint32_t reg = 0;
   for (; i < e && ((uintptr_t)(row + i) & 15u); ++i) reg = crc_step(reg, row[i] & 1u, low, mask, L);
+  for (; i + 64 <= e; i += 64) {     // four loads in flight (the register recurrence would otherwise serialise them: load, 16 steps, load)
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(row + i + 16 * u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) reg = crc_step(reg, (w[q] >> (8 * b)) & 1u, low, mask, L);
+    }
+  }
   for (; i + 16 <= e; i += 16) {
     const uint4 v = *reinterpret_cast<const uint4*>(row + i);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -152,19 +166,39 @@ __global__ void __launch_bounds__(256)
 segment_kernel(const uint8_t* __restrict__ tb, int A, int B, int C, int K, int cb_len, uint8_t* __restrict__ cbs,
                const CrcPlan pl) {
   __shared__ uint32_t red[16];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[8448];   // the block's payload: the CRC runs on this copy, not on a re-read of dst
   const int t = blockIdx.x / C, c = blockIdx.x % C;
   const int per = (B + C - 1) / C;  // payload bits per block before its CRC
   const uint8_t* src = tb + (size_t)t * A;
   uint8_t* dst = cbs + (size_t)blockIdx.x * K;
-  for (int i = threadIdx.x; i < per; i += blockDim.x) {
+  const bool staged = per <= (int)sizeof(stage);
+  auto copy1 = [&](int i) {
     const int64_t g = (int64_t)c * per + i;
-    if (g < A) dst[i] = src[g] & 1;
-    else if (g >= B) dst[i] = 0;  // zero padding at the end of the last block (ldpc.py:1014-1016)
-    // A <= g < B: TB-CRC bit, already written by tb_crc_scatter_kernel (or part of the caller's TB when B == A)
+    uint8_t v;
+    if (g < A) { v = src[g] & 1; dst[i] = v; }
+    else if (g >= B) { v = 0; dst[i] = 0; }  // zero padding at the end of the last block (ldpc.py:1014-1016)
+    else v = dst[i];   // A <= g < B: TB-CRC bit, already written by tb_crc_scatter_kernel (or part of the caller's TB when B == A)
+    if (staged) stage[i] = v;
+  };
+  const uint8_t* s0 = src + (int64_t)c * per;
+  if ((per & 7) == 0 && (((uintptr_t)s0 | (uintptr_t)dst) & 7u) == 0) {
+    // eight bits per load / store; the word that straddles the end of the payload goes bit by bit
+    for (int w = threadIdx.x; w < (per >> 3); w += blockDim.x) {
+      const int64_t g0 = (int64_t)c * per + 8 * w;
+      if (g0 + 8 <= A) {
+        const uint64_t v = *(const uint64_t*)(s0 + 8 * w) & 0x0101010101010101ull;
+        *(uint64_t*)(dst + 8 * w) = v;
+        if (staged) *(uint64_t*)(stage + 8 * w) = v;
+      } else {
+        for (int k = 0; k < 8; ++k) copy1(8 * w + k);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < per; i += blockDim.x) copy1(i);
   }
   __syncthreads();
   if (C > 1) {
-    const uint32_t r = block_crc(dst, per, pl, red);
+    const uint32_t r = block_crc(staged ? (const uint8_t*)stage : (const uint8_t*)dst, per, pl, red);
     if (threadIdx.x < 24) dst[per + threadIdx.x] = (r >> (23 - threadIdx.x)) & 1u;
   }
   for (int i = cb_len + threadIdx.x; i < K; i += blockDim.x) dst[i] = 0;  // fillers are ZERO bits (ldpc.py:1025-1028)
@@ -275,16 +309,42 @@ encode_packed_kernel(const uint8_t* __restrict__ cbs, int zc, int puncture, uint
     return __builtin_amdgcn_alignbit(W[col * NWMAX + b], W[col * NWMAX + a], r);
   };
 
-  // ---- pack the information columns: 64 bits per ballot
-  for (int c = 0; c < KB; ++c)
-    for (int k = 0; k < zc; k += 64) {
-      const int z = k + lane;
-      const unsigned long long m = __ballot(z < zc && (in[c * zc + (z < zc ? z : 0)] & 1));
-      if (lane == 0) {
-        W[c * NWMAX + (k >> 5)] = (uint32_t)m;
-        if (k + 32 < zc) W[c * NWMAX + (k >> 5) + 1] = (uint32_t)(m >> 32);
+  // ---- pack the information columns.  A lane takes 16 bytes (one load), folds each 4 of them into a nibble -- bytes b0..b3
+  // of a word are 0/1, (w * 0x10204080) >> 28 = b0 | b1<<1 | b2<<2 | b3<<3: the sixteen partial products land on distinct bits
+  // -- and stores its 16 bits as one half word of W; all loads of the lane are issued before the first is used.  (The first
+  // version went column by column with a wave ballot per 64 bytes: 132 dependent load -> ballot round trips per code block.)
+  if ((zc & 15) == 0 && (((uintptr_t)in) & 15u) == 0) {
+    const int cpc = zc >> 4;                      // 16-byte chunks per column
+    const int n_chunk = KB * cpc;
+    constexpr int MAXR = (KB * (ZMAX / 16) + 63) / 64;
+    uint4 ld[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int t = lane + 64 * r;
+      ld[r] = t < n_chunk ? ((const uint4*)in)[t] : uint4{0u, 0u, 0u, 0u};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint16_t* W16 = (uint16_t*)W;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int t = lane + 64 * r;
+      if (t < n_chunk) {
+        const int c = t / cpc, p = t - c * cpc;
+        auto nib = [](uint32_t w) -> uint32_t { return ((w & 0x01010101u) * 0x10204080u) >> 28; };
+        W16[c * NWMAX * 2 + p] = (uint16_t)(nib(ld[r].x) | (nib(ld[r].y) << 4) | (nib(ld[r].z) << 8) | (nib(ld[r].w) << 12));
       }
     }
+  } else {
+    for (int c = 0; c < KB; ++c)      // 64 bits per ballot
+      for (int k = 0; k < zc; k += 64) {
+        const int z = k + lane;
+        const unsigned long long m = __ballot(z < zc && (in[c * zc + (z < zc ? z : 0)] & 1));
+        if (lane == 0) {
+          W[c * NWMAX + (k >> 5)] = (uint32_t)m;
+          if (k + 32 < zc) W[c * NWMAX + (k >> 5) + 1] = (uint32_t)(m >> 32);
+        }
+      }
+  }
   __syncthreads();
   // ---- information part of core rows 0..3 (lane = (row, word))
   int sh_p[4][4];
@@ -396,7 +456,64 @@ rate_match_cb_kernel(const uint8_t* __restrict__ coded, RmGeom g, uint8_t* __res
   const int eq = E / QM;
   const uint8_t* src = coded + (size_t)cbi * g.N;
   uint8_t* dst = out + (size_t)t * g.G + off;
-  for (int sidx = blockIdx.x * blockDim.x + threadIdx.x; sidx < eq; sidx += gridDim.x * blockDim.x) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  // Four symbols per thread where the geometry allows 32-bit accesses (bit plane q of four consecutive symbols = four
+  // consecutive coded bits: one load when they neither wrap nor straddle the fillers and sit on a word boundary; the 4 x QM
+  // output bytes are consecutive: QM word stores), one modulo per bit plane and thread instead of one per bit.
+  int n_vec = 0;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 3u) == 0) {
+    n_vec = eq >> 2;
+    int bq[QM];     // (q * eq + k0) mod cs, by additions: a 64-bit modulo is ~130 instructions
+    const int eqm = (int)((uint32_t)eq % (uint32_t)g.cs);
+    bq[0] = (int)((uint32_t)k0 % (uint32_t)g.cs);
+#pragma unroll
+    for (int q = 1; q < QM; ++q) {
+      bq[q] = bq[q - 1] + eqm;
+      bq[q] -= bq[q] >= g.cs ? g.cs : 0;
+    }
+    for (int v = tid; v < n_vec; v += nth) {
+      const int sidx0 = 4 * v;
+      uint32_t w[QM];
+      int ci[QM], pp[QM];
+      bool fast = true;
+#pragma unroll
+      for (int q = 0; q < QM; ++q) {
+        ci[q] = bq[q] + sidx0;
+        while (ci[q] >= g.cs) ci[q] -= g.cs;
+        pp[q] = ci[q] < g.sys_len ? ci[q] : ci[q] + g.F;
+        fast = fast && ci[q] + 3 < g.cs && (ci[q] >= g.sys_len || ci[q] + 3 < g.sys_len) && (pp[q] & 3) == 0;
+      }
+      if (fast) {     // (one branch for the thread, so that its QM loads are issued together)
+#pragma unroll
+        for (int q = 0; q < QM; ++q) w[q] = *(const uint32_t*)(src + pp[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < QM; ++q) {
+          w[q] = 0;
+          for (int k = 0; k < 4; ++k) {
+            int c2 = ci[q] + k;
+            if (c2 >= g.cs) c2 -= g.cs;
+            w[q] |= (uint32_t)src[c2 < g.sys_len ? c2 : c2 + g.F] << (8 * k);
+          }
+        }
+      }
+      // byte k of w[q] = bit plane q of symbol sidx0 + k  ->  output byte (sidx0 + k) * QM + q
+      uint32_t o[QM];
+#pragma unroll
+      for (int j = 0; j < QM; ++j) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int n = 4 * j + b, k = n / QM, q = n - k * QM;
+          x |= ((w[q] >> (8 * k)) & 0xffu) << (8 * b);
+        }
+        o[j] = x;
+      }
+#pragma unroll
+      for (int j = 0; j < QM; ++j) *(uint32_t*)(dst + (size_t)sidx0 * QM + 4 * j) = o[j];
+    }
+  }
+  for (int sidx = 4 * n_vec + tid; sidx < eq; sidx += nth) {
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
       const int e = q * eq + sidx;
@@ -668,7 +785,10 @@ static int32_t rate_match_impl(const uint8_t* coded, int32_t n_tb, const nrx_ldp
   g.G = ((G + nl * qm - 1) / (nl * qm)) * (nl * qm);  // = sum of E_r (ldpc.py:852-855); equals G for PDSCH
   {
     const int eq_max = (g.e_small + g.f) / qm;
-    const dim3 grid2((eq_max + 255) / 256 > 8 ? 8 : (eq_max + 255) / 256, n_tb * cfg->C);
+    // x-strips per code block: a thread takes four symbols (vector path), and a workgroup should have a few microseconds of
+    // work -- 150 k workgroups of one symbol per thread were bound by their own dispatch
+    const int strips = (eq_max / 4 + 1023) / 1024;
+    const dim3 grid2(strips > 8 ? 8 : (strips < 1 ? 1 : strips), n_tb * cfg->C);
     bool done = true;
     switch (qm) {
       case 1: hipLaunchKernelGGL(rate_match_cb_kernel<1>, grid2, dim3(256), 0, (hipStream_t)stream, coded, g, out, rvs); break;
