@@ -16,8 +16,6 @@ everything that depends only on (configuration, slot number in frame) is precomp
 Slots are independent given their absolute slot index (channel time, DMRS/scrambling by slotNoInFrame), so a
 sweep shards over GPUs by slot range with no data-path communication; only the 4 error counters are reduced.
 """
-import os
-
 import numpy as np
 import torch
 
@@ -199,7 +197,6 @@ class PdschLink:
         self.A, self.nu = D(tb_['A']), D(tb_['nu'])
         self.Alos, self.nulos = (None if tb_['Alos'] is None else D(tb_['Alos'])), tb_['nulos']
         self.static_at = tb_.get('static_at')
-        self._side = None            # second stream: the channel chain of a batch runs beside its Tx chain
         coeff = tb_['coeff']
         self.coeff = D(coeff)
         taps, offs = ops.path_taps(coeff, channel.filterLen)
@@ -321,19 +318,11 @@ class PdschLink:
         snr_lin = torch.full((n,), 10.0 ** (float(snr_db) / 10.0), dtype=torch.float64, device=dev) \
             if np.isscalar(snr_db) else D(10.0 ** (np.float64(snr_db) / 10.0))
 
-        # ---- channel state of each slot, on a second stream: it depends on nothing of the Tx bit chain (since the wideband
-        # precoder went into the channel filter's gains the modulator does not wait for it either), and its kernels are one
-        # workgroup per slot, latency-bound -- they run beside the Tx chain instead of in front of it.
-        cur = torch.cuda.current_stream(dev)
-        if self._side is None:      # (NRX_NO_SIDE_STREAM: developer switch, everything on one stream)
-            self._side = cur if os.environ.get('NRX_NO_SIDE_STREAM') else torch.cuda.Stream(device=dev)
-        side = self._side
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            ch = self._channel_chain(slots, n)
-        for t in ch:
-            if t is not None:
-                t.record_stream(cur)         # allocated on the side stream, consumed on this one
+        # ---- channel state of each slot.  (It depends on nothing of the Tx bit chain, and since the wideband precoder went into
+        # the channel filter's gains the modulator does not wait for it either.  Running it on a second stream beside the Tx
+        # chain was tried: its one-workgroup-per-slot kernels and the bit-chain kernels then share the CUs and each takes as
+        # much longer as the overlap saves -- 36.04 against 36.04 ms per step -- so it stays on the one stream.)
+        ch = self._channel_chain(slots, n)
 
         # ---- Tx
         grid = None if self.numCW == 1 else self.templates.index_select(0, sif)   # DMRS-filled (n, Nl, L, K)
@@ -356,11 +345,7 @@ class PdschLink:
                 ops.qam_map(bits, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], out=grid)
         tb = tbs_in[0]
 
-        # ---- join the channel chain (launched on the side stream in front of the Tx chain) where its results are first consumed:
-        # behind the modulator on the time-domain link with a wideband precoder, here otherwise
         gains1, off, H, F, gfold = ch
-        if self.prg or self.freqDomain:
-            cur.wait_stream(side)
         if self.prg:
             grid = ops.precode_prg(grid, F, self.prg_k2g)                       # (n, Nt, L, K); F is applied from here on
 
@@ -373,8 +358,6 @@ class PdschLink:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
             tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay)      # layers (wideband) | ports (PRG)
-            if not self.prg:
-                cur.wait_stream(side)
             ry = ops.apply_td_paths(tx, gains1 if self.prg else gfold, self.taps, self.tap_off,
                                     [int(v) for v in self.sym_lens[sis]], hist=self.td_hist)
             width = ry.shape[-1]

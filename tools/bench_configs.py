@@ -2,6 +2,8 @@
 """The other BASELINE.json configurations through the batched engine (parity-test cases in the contract; this tool
 only reports their throughput and error counters on the GPU):
 
+  cfg1  the reference's own CPU-runnable case as a batch: 25 PRB @15 kHz, QPSK, 1 layer, SISO TDL-A 30 ns, BG2 R = 0.3, 5 iterations,
+        batch 4096 slots
   cfg2  PDSCH BLER sweep point: 106 PRB @30 kHz, 64-QAM, 2 layers, 2x2 MMSE, CDL-C 300 ns, BG1, batch 1024 slots
   cfg3  273 PRB / 100 MHz, 256-QAM, 4 layers, 4x4 MMSE, CDL-D (LOS) 300 ns, BG1 R = 0.75 (TBS 950 984, 113 code blocks), once
         with the DMRS-LS estimate (every block fails at any SNR -- in the reference too, tests/golden/e2e_cfg3_*) and once with
@@ -26,6 +28,13 @@ DECODER = "f64"
 
 def build(nr, which):
     nr.random.setSeed(123)
+    if which == 'cfg1':
+        car = nr.Carrier(numRbs=25, spacing=15)
+        bwp = car.curBwp
+        p = nr.PDSCH(bwp, numLayers=1, nID=car.cellId, modulation='QPSK')
+        p.setDMRS(configType=1, additionalPos=1)
+        ch = nr.TdlChannel(bwp, 'A', delaySpread=30, dopplerShift=5, txAntennaCount=1, rxAntennaCount=1)
+        return nr.PdschLink(p, ch, 0.3, baseGraphNo=2, numIter=5, freqDomain=False, chanEst="LS", decoder=DECODER), 4096, 4.0
     if which == 'cfg2':
         car = nr.Carrier(numRbs=106, spacing=30)
         bwp = car.curBwp
@@ -55,7 +64,7 @@ def main():
     global DECODER
     DECODER = a.decoder
     import neoradium_amd as nr
-    for which in ('cfg2', 'cfg3', 'cfg3_perfect'):
+    for which in ('cfg1', 'cfg2', 'cfg3', 'cfg3_perfect'):
         link, B, snr = build(nr, which)
         link.run(0, B, snr, seed=1)
         torch.cuda.synchronize()
