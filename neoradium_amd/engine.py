@@ -211,6 +211,24 @@ class PdschLink:
         self.slot_len = [int(v[:-1].sum()) for v in self.sym_lens]
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
+        # gain instants on the device (no host -> device copy per batch: such a copy from pageable memory waits for the
+        # stream to drain, i.e. for the previous batch's decoder, and the GPU then idles while the host prepares the next one)
+        spsf = bwp.slotsPerSubFrame
+        tab = np.empty((spsf, self.L + 1), dtype=np.int64)
+        for r in range(spsf):
+            sl = np.int64(self.sym_lens[r]).copy()
+            sl[0] -= self.nfft
+            tab[r] = int(sum(self.slot_len[:r])) + np.cumsum(sl)
+        self._gt_tab = D(tab)
+        self._one_geometry = all(tuple(v) == tuple(self.sym_lens[0]) for v in self.sym_lens)
+
+    def gain_times_dev(self, slots_dev):
+        """gain_times() for a device tensor of absolute slot numbers, computed on the device with the same integer and
+        floating-point operations (sample index as int64 -> float64, divided by the sample rate)."""
+        spsf = self.bwp.slotsPerSubFrame
+        q = torch.div(slots_dev, spsf, rounding_mode='floor')
+        samples = (q * self.subframe_len)[:, None] + self._gt_tab.index_select(0, slots_dev - q * spsf)
+        return samples.to(torch.float64) / float(self.fs)
 
     # ------------------------------------------------------------------------------------------- geometry
     def slot_start(self, n):
@@ -256,8 +274,11 @@ class PdschLink:
         spsf = self.bwp.slotsPerSubFrame
         # one sub-batch per slot geometry (identical for mu <= 1)
         geoms = {}
-        for i, n in enumerate(slots):
-            geoms.setdefault(tuple(self.sym_lens[n % spsf]), []).append(i)
+        if self._one_geometry:
+            geoms[0] = np.arange(n_slots)
+        else:
+            for i, n in enumerate(slots):
+                geoms.setdefault(tuple(self.sym_lens[n % spsf]), []).append(i)
         det = []
         for _, sel in geoms.items():
             sel = np.asarray(sel)
@@ -272,10 +293,10 @@ class PdschLink:
                 det.append((sel, d))
         return (counters, det) if details else counters
 
-    def _channel_chain(self, slots, n):
+    def _channel_chain(self, slots, n, slots_dev):
         """Path gains, timing offset, channel matrix (where the link needs it), precoder(s) and -- time-domain link with a
         wideband precoder -- the gains with the precoder folded in, of the slots of one batch."""
-        times = D(self.gain_times(slots))
+        times = self.gain_times_dev(slots_dev)
         if self.static_at is None:
             gains1 = ops.cdl_gains(self.A, self.nu, times, A_los=self.Alos, nu_los=self.nulos)
         else:                       # per-slot ray coefficients (host draws in the class surface's order, see host_tables)
@@ -311,10 +332,12 @@ class PdschLink:
         dev, cfg = self.dev, self.cfg
         n = len(slots)
         sis = int(slots[0]) % self.bwp.slotsPerSubFrame
-        sif = torch.as_tensor(slots % self.bwp.slotsPerFrame, dtype=torch.int64, device=dev)
         # device generator keys = the ABSOLUTE slot numbers (a geometry group at mu >= 2 is not a contiguous slot range)
         contiguous = bool(np.all(np.diff(slots) == 1))
-        ids = None if contiguous else torch.as_tensor(np.asarray(slots, dtype=np.int64), device=dev)
+        slots_dev = torch.arange(int(slots[0]), int(slots[0]) + n, dtype=torch.int64, device=dev) if contiguous else \
+            torch.as_tensor(np.asarray(slots, dtype=np.int64), device=dev)
+        sif = slots_dev % self.bwp.slotsPerFrame
+        ids = None if contiguous else slots_dev
         snr_lin = torch.full((n,), 10.0 ** (float(snr_db) / 10.0), dtype=torch.float64, device=dev) \
             if np.isscalar(snr_db) else D(10.0 ** (np.float64(snr_db) / 10.0))
 
@@ -322,7 +345,7 @@ class PdschLink:
         # the channel filter's gains the modulator does not wait for it either.  Running it on a second stream beside the Tx
         # chain was tried: its one-workgroup-per-slot kernels and the bit-chain kernels then share the CUs and each takes as
         # much longer as the overlap saves -- 36.04 against 36.04 ms per step -- so it stays on the one stream.)
-        ch = self._channel_chain(slots, n)
+        ch = self._channel_chain(slots, n, slots_dev)
 
         # ---- Tx
         grid = None if self.numCW == 1 else self.templates.index_select(0, sif)   # DMRS-filled (n, Nl, L, K)
