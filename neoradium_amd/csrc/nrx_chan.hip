@@ -834,6 +834,28 @@ fold_precoder_kernel(const cd* __restrict__ gains, const cd* __restrict__ F, int
 constexpr int CS_THREADS = 512;
 constexpr int CS_NK = 12;      // subcarriers (one PRB)
 typedef const cd __attribute__((address_space(4))) * cgain_t;      // read-only in this kernel: wave-uniform rows come by scalar loads
+#ifdef NRX_CS_PROBE
+// developer build (tools/probe_chan_setup.py): s_memtime at the phase boundaries of wave 0 of every workgroup, summed:
+// [0] tap matrix to LDS, [1] offset pass, [2] argmax, [3] twiddles, [4] matrix pass, [5] workgroups
+__device__ unsigned long long g_cs_probe[6];
+extern "C" int32_t nrx_debug_cs_probe(unsigned long long* out6, int32_t reset) {
+  if (out6 && hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_cs_probe), sizeof(unsigned long long) * 6) != hipSuccess) return -4;
+  if (reset) {
+    const unsigned long long z[6] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cs_probe), z, sizeof(z)) != hipSuccess) return -4;
+  }
+  return 0;
+}
+#define CS_STAMP(K)                                                                                         \
+  do {                                                                                                      \
+    unsigned long long pt_;                                                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pt_)::"memory"); \
+    if ((K) >= 0 && threadIdx.x == 0) atomicAdd(&g_cs_probe[(K)], pt_ - cs_prev);                           \
+    cs_prev = pt_;                                                                                          \
+  } while (0)
+#else
+#define CS_STAMP(K) do {} while (0)
+#endif
 template <int P>      // paths: a template parameter so that the per-tap / per-row register arrays are fully unrolled without guards
 __global__ void __launch_bounds__(CS_THREADS)
 chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff, int n_t_total, int nc, int nr, int nt,
@@ -842,16 +864,21 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* csT = (double*)smem;                              // [cl][P] tap matrix, transposed: a tap's coefficients are contiguous
   cd* W = (cd*)(csT + (size_t)P * cl);                      // [use][12] twiddles of (tap, subcarrier) once chanOffset is known
-  __shared__ double bestv[CS_THREADS];
-  __shared__ int besti[CS_THREADS];
+  __shared__ double bestv[CS_THREADS / 64];
+  __shared__ int besti[CS_THREADS / 64];
   __shared__ int off_s;
   const int b = blockIdx.x, tid = threadIdx.x, n_rt = nr * nt;
+#ifdef NRX_CS_PROBE
+  unsigned long long cs_prev = 0;
+  CS_STAMP(-1);
+#endif
   for (int i = tid; i < P * cl; i += CS_THREADS) {
     const int p = i / cl, l = i - p * cl;
     csT[(size_t)l * P + p] = coeff[i];
   }
   const cd* gb = gains + (size_t)b * n_t_total * n_rt * P;
   __syncthreads();
+  CS_STAMP(0);
   // ---- chanOffset = argmax_l sum_r | sum_{c<nc, t} cir[c][r][t][l] |   (channelmodel.py:345-346; first max): one tap per thread,
   // its coefficients in registers, the gains of a (c, r, t) row wave-uniform
   double bv = -1.0;
@@ -878,18 +905,27 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
     }
     if (tot > bv) { bv = tot; bi = l; }
   }
-  bestv[tid] = bv;
-  besti[tid] = bi;
+  // first maximum over the threads (largest value, smallest tap among equals -- np.argmax): inside the wave by shuffles, then
+  // over the waves.  (A serial scan of 512 LDS entries by one thread was 84 k cycles of the workgroup's 1.46 M.)
+  CS_STAMP(1);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
   __syncthreads();
   if (tid == 0) {
     double v = -1.0;
     int idx = 0;
-    for (int i = 0; i < CS_THREADS; ++i)
+    for (int i = 0; i < CS_THREADS / 64; ++i)
       if (bestv[i] > v || (bestv[i] == v && besti[i] < idx)) { v = bestv[i]; idx = besti[i]; }
     off_out[b] = idx;
     off_s = idx;
   }
   __syncthreads();
+  CS_STAMP(2);
   // ---- channel matrix at subcarriers k0 .. k0 + 11 (channelmodel.py:362-400 at those bins: direct DFT of the CIR placed
   // circularly shifted by chanOffset).  The twiddle of (tap, bin) is the same for every row: tabulated once.
   const int o = off_s;
@@ -906,29 +942,48 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
     W[i] = w;
   }
   __syncthreads();
-  // one (instant, rx, tx) row per thread: its gains in registers, the CIR value of a tap feeds the 12 bins
-  for (int row = tid; row < nc * n_rt; row += CS_THREADS) {
+  CS_STAMP(3);
+  // one (instant, rx, tx) row and one half of the 12 bins per thread: the row's gains in registers, the CIR value of a tap (computed
+  // by both halves, same expression) feeds the thread's 6 bins.  (With all 12 bins per thread the 24 gains, 12 accumulators and a
+  // tap's coefficients and twiddles did not fit in the 256 registers of a 512-thread workgroup: 9 gains were re-read from scratch
+  // for every tap, 1.1 M of the workgroup's 1.46 M cycles; and only 224 of the 512 threads had a row.)
+  constexpr int NKH = CS_NK / 2;
+  for (int it = tid; it < 2 * nc * n_rt; it += CS_THREADS) {
+    const int row = it >> 1, kh = (it & 1) * NKH;
     cd g[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) g[p] = gb[(size_t)row * P + p];
-    cd acc[CS_NK];
+    cd acc[NKH];
 #pragma unroll
-    for (int k = 0; k < CS_NK; ++k) acc[k] = cd(0, 0);
+    for (int k = 0; k < NKH; ++k) acc[k] = cd(0, 0);
     for (int l = 0; l < use; ++l) {
+      // a tap's coefficients (same address in every lane: broadcast) and twiddles, all read before the first is used
+      // (the scheduler otherwise sinks each LDS read to its multiply: a dozen exposed LDS latencies per tap)
+      double cf[P];
+      cd wv[NKH];
+#pragma unroll
+      for (int p = 0; p < P; ++p) cf[p] = csT[(size_t)l * P + p];
+#pragma unroll
+      for (int k = 0; k < NKH; ++k) wv[k] = W[l * CS_NK + kh + k];
+      __builtin_amdgcn_sched_barrier(0);
       cd v(0, 0);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const double c = csT[(size_t)l * P + p];         // (same address in every lane: broadcast)
-        v.re += g[p].re * c;
-        v.im += g[p].im * c;
+        v.re += g[p].re * cf[p];
+        v.im += g[p].im * cf[p];
       }
 #pragma unroll
-      for (int k = 0; k < CS_NK; ++k) nrx::cmac(acc[k], v, W[l * CS_NK + k]);
+      for (int k = 0; k < NKH; ++k) nrx::cmac(acc[k], v, wv[k]);
     }
     const int c = row / n_rt, rt = row - c * n_rt;
 #pragma unroll
-    for (int k = 0; k < CS_NK; ++k) H[(((size_t)b * nc + c) * CS_NK + k) * n_rt + rt] = acc[k];
+    for (int k = 0; k < NKH; ++k) H[(((size_t)b * nc + c) * CS_NK + kh + k) * n_rt + rt] = acc[k];
   }
+#ifdef NRX_CS_PROBE
+  __syncthreads();
+  CS_STAMP(4);
+  if (tid == 0) atomicAdd(&g_cs_probe[5], 1ull);
+#endif
 }
 }  // namespace
 
