@@ -42,6 +42,22 @@ def test_modem(dev, mod):
     refl = np.stack([op.demap_maxlog(y[i], nv[i], qm) for i in range(n)])
     assert np.abs(llr - refl).max() <= 1e-9
     assert np.array_equal(llr < 0, refl < 0) or np.abs(refl[(llr < 0) != (refl < 0)]).max() < 1e-9
+    if qm >= 2:
+        # bit for bit the per-axis form in IEEE float64 with true divisions, (-m0/nv) - (-m1/nv): the kernel's quotients come
+        # from one reciprocal per item and a correction step (nrx_modem.hip div_by) and must be the correctly rounded ones
+        h = qm // 2
+        cst = op.constellation(qm)
+        # level of real-axis bit pattern a (bits b0 b2 b4 .. of the symbol, MSB first), as the kernel forms it: integer * (1 / sqrt(norm))
+        idx = [sum(((a >> (h - 1 - i)) & 1) << (qm - 1 - 2 * i) for i in range(h)) for a in range(1 << h)]
+        lev = np.rint(cst[idx].real * np.sqrt(op._NORM[qm])) * (1.0 / np.sqrt(float(op._NORM[qm])))
+        want = np.empty_like(llr)
+        for axis, yv in enumerate((y.real, y.imag)):
+            d2 = (yv[..., None] - lev) * (yv[..., None] - lev)
+            for q in range(h):
+                one = np.array([(a >> (h - 1 - q)) & 1 for a in range(1 << h)], bool)
+                m0, m1 = d2[..., ~one].min(-1), d2[..., one].min(-1)
+                want[:, 2 * q + axis::qm] = (-m0 / nv[:, None]) - (-m1 / nv[:, None])
+        assert np.array_equal(llr, want)
     llr32 = ops.qam_demap(T(y, dev), T(nv, dev), qm, llr_dtype=torch.float32).cpu().numpy()
     assert np.abs(llr32 - refl).max() <= 1e-5 * np.abs(refl).max()
     if qm <= 6:
