@@ -503,6 +503,12 @@ int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, const int32_t*
                               const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
                               int32_t K, int32_t nr, int32_t P, const double* noise_var, int32_t nv_stride, void* hk_ws,
                               void* eq, double* scale, int32_t n_batch, void* stream);
+/* The same for the OFDM symbols of sym_mask only (bit l = symbol l, L <= 32; the equalised values of symbols without data REs
+ * -- the DMRS symbols -- are read by nobody): eq / scale of the other symbols are left untouched. */
+int32_t nrx_chest_ls_mmse_syms_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                   const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k, int32_t L,
+                                   int32_t K, int32_t nr, int32_t P, const double* noise_var, int32_t nv_stride, void* hk_ws,
+                                   void* eq, double* scale, int32_t n_batch, uint32_t sym_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ Polar
  * Control-channel codec (DCI / PBCH / UCI).  The code construction (polar.py:298-408 PolarBase.initialize) is

@@ -87,6 +87,7 @@ SIGNATURES.update({
     'nrx_svd_precoder_f64': (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_effective_channel_f64': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_chest_ls_mmse_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp]),
+    'nrx_chest_ls_mmse_syms_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, C.c_uint32, vp]),
     'nrx_chest_ls_ex_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
     'nrx_chest_noise_f64': (i32, [vp, vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]),
     'nrx_chest_pilot_means_f64': (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),

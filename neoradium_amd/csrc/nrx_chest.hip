@@ -285,7 +285,7 @@ int32_t chest_entry(const void* rx, const void* pilots, const int32_t* pil_set, 
 template <int NR, int NL>
 __global__ void __launch_bounds__(128, 2)   // two waves per SIMD (256 registers; the 4x4 solve wants 284: 29 words of scratch) beat one: 0.72 -> 0.67 ms
 mmse_interp_kernel(const cd* __restrict__ rx, const cd* __restrict__ hk, ChestGeom g, const double* __restrict__ noise_var,
-                   int nv_stride, cd* __restrict__ eq, double* __restrict__ scale, int n_batch) {
+                   int nv_stride, cd* __restrict__ eq, double* __restrict__ scale, int n_batch, uint32_t sym_mask) {
   const int n_g = g.n_ds / g.l_cdm;
   const int64_t total = (int64_t)n_batch * g.K;
   const int64_t lk = (int64_t)g.L * g.K;
@@ -320,6 +320,7 @@ mmse_interp_kernel(const cd* __restrict__ rx, const cd* __restrict__ hk, ChestGe
       }
     }
     for (int l = 0; l < g.L; ++l) {
+      if (!((sym_mask >> (l & 31)) & 1u)) continue;       // a symbol the caller does not want equalised (it holds no data RE)
       cd H[NR][NL], y[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -413,11 +414,11 @@ xcorr_abs_kernel(const cd* __restrict__ rx, const cd* __restrict__ ref, int N, i
 }
 }  // namespace
 
-extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
-                                         const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
-                                         int32_t L, int32_t K, int32_t nr, int32_t P, const double* noise_var,
-                                         int32_t nv_stride, void* hk_ws, void* eq, double* scale, int32_t n_batch,
-                                         void* stream) {
+static int32_t chest_ls_mmse_impl(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                  const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                  int32_t L, int32_t K, int32_t nr, int32_t P, const double* noise_var,
+                                  int32_t nv_stride, void* hk_ws, void* eq, double* scale, int32_t n_batch,
+                                  uint32_t sym_mask, void* stream) {
   NRX_REQUIRE(rx && pilots && port_ks && dmrs_syms && noise_var && hk_ws && eq && scale, NRX_E_ARG,
               "nrx_chest_ls_mmse: NULL buffer");
   NRX_REQUIRE(n_ds >= 1 && n_ds <= 8 && l_cdm >= 1 && k_cdm >= 1 && n_k >= 1, NRX_E_ARG, "nrx_chest_ls_mmse: bad DMRS geometry");
@@ -446,7 +447,7 @@ extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, con
                        dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (cd*)hk_ws, n_batch, 1,  \
                        (cd*)nullptr, (const double*)means);                                                             \
     hipLaunchKernelGGL((mmse_interp_kernel<NR, NL>), grid2, dim3(128), 0, st, (const cd*)rx, (const cd*)hk_ws, g,        \
-                       noise_var, nv_stride, (cd*)eq, scale, n_batch);                                                   \
+                       noise_var, nv_stride, (cd*)eq, scale, n_batch, sym_mask);                                         \
     NRX_CHECK_LAUNCH("nrx_chest_ls_mmse");                                                                               \
     return NRX_OK;                                                                                                       \
   }
@@ -454,6 +455,27 @@ extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, con
   NRX_CM_CASE(8, 1) NRX_CM_CASE(8, 2) NRX_CM_CASE(8, 4)
 #undef NRX_CM_CASE
   NRX_REQUIRE(false, NRX_E_UNSUPPORTED, "nrx_chest_ls_mmse: (Nr=%d, layers=%d) not built", nr, P);
+}
+
+extern "C" int32_t nrx_chest_ls_mmse_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                         const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                         int32_t L, int32_t K, int32_t nr, int32_t P, const double* noise_var,
+                                         int32_t nv_stride, void* hk_ws, void* eq, double* scale, int32_t n_batch,
+                                         void* stream) {
+  return chest_ls_mmse_impl(rx, pilots, pil_set, port_ks, dmrs_syms, n_ds, l_cdm, k_cdm, n_k, L, K, nr, P, noise_var, nv_stride,
+                            hk_ws, eq, scale, n_batch, 0xffffffffu, stream);
+}
+
+// ... for the OFDM symbols of `sym_mask` only (bit l = symbol l, L <= 32): the others -- symbols without data REs, whose
+// equalised values nobody reads -- are left untouched in eq / scale.
+extern "C" int32_t nrx_chest_ls_mmse_syms_f64(const void* rx, const void* pilots, const int32_t* pil_set, const int32_t* port_ks,
+                                              const int32_t* dmrs_syms, int32_t n_ds, int32_t l_cdm, int32_t k_cdm, int32_t n_k,
+                                              int32_t L, int32_t K, int32_t nr, int32_t P, const double* noise_var,
+                                              int32_t nv_stride, void* hk_ws, void* eq, double* scale, int32_t n_batch,
+                                              uint32_t sym_mask, void* stream) {
+  NRX_REQUIRE(L <= 32, NRX_E_ARG, "nrx_chest_ls_mmse_syms: at most 32 symbols");
+  return chest_ls_mmse_impl(rx, pilots, pil_set, port_ks, dmrs_syms, n_ds, l_cdm, k_cdm, n_k, L, K, nr, P, noise_var, nv_stride,
+                            hk_ws, eq, scale, n_batch, sym_mask, stream);
 }
 
 

@@ -166,6 +166,11 @@ class PdschLink:
             inv[ri] = np.arange(len(ri), dtype=np.int32)
             self.re_inv = D(inv)
             self.re_planes = None         # ops.layer_planes(self.re_inv): asked once, on first use (a device reduction)
+        # OFDM symbols that hold at least one data RE of any codeword: the only ones the throughput path equalises
+        self.data_sym_mask = 0
+        for lm in lms:
+            for l in np.unique(np.asarray(lm[1])):
+                self.data_sym_mask |= 1 << int(l)
         c0 = self.cw[0]     # (single-codeword attribute names kept: bench.py, the oracle harness and the tests use them)
         self.G, self.re_index, self.scr, self.cfg = c0['G'], c0['re_index'], c0['scr'], c0['cfg']
         self.first_prb = int(pdsch.prbSet[0])
@@ -406,7 +411,7 @@ class PdschLink:
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
         else:       # estimate + equalise fused: the (L, K, Nr, Nl) estimate is never written out
             eq, sc = ops.chest_ls_mmse(rxg, self.pilots, self.port_ks_d, self.dmrs_syms, nv, l_cdm=self.l_cdm,
-                                       k_cdm=self.k_cdm, pil_set=sif.to(torch.int32))
+                                       k_cdm=self.k_cdm, pil_set=sif.to(torch.int32), sym_mask=self.data_sym_mask)
         per_cw = []
         for q, cw in enumerate(self.cw):
             ccfg = cw['cfg']

@@ -811,8 +811,9 @@ def xcorr_abs(rx, ref, ref_start, ref_len):
     return out
 
 
-def chest_ls_mmse(rx, pilots, port_ks, dmrs_syms, noise_var, l_cdm=1, k_cdm=2, pil_set=None):
+def chest_ls_mmse(rx, pilots, port_ks, dmrs_syms, noise_var, l_cdm=1, k_cdm=2, pil_set=None, sym_mask=None):
     """chest_ls + mmse_equalize fused (complex128, <= 2 DMRS time groups): -> eq (n,P,L,K), llrScales (n,P,L,K).
+    ``sym_mask`` (bit l = OFDM symbol l): equalise those symbols only, the others stay uninitialised in eq / llrScales.
 
     Trusted inputs (the engine validates its tables once): no host-side range checks, no device synchronisation."""
     rx = rx.contiguous()
@@ -828,9 +829,14 @@ def chest_ls_mmse(rx, pilots, port_ks, dmrs_syms, noise_var, l_cdm=1, k_cdm=2, p
     hk = torch.empty((n * n_g * (K + nk // k_cdm) * nr * P,), dtype=torch.complex128, device=dev)   # estimates + CDM-group means
     eq = torch.empty((n, P, L, K), dtype=torch.complex128, device=dev)
     sc = torch.empty((n, P, L, K), dtype=torch.float64, device=dev)
-    check(lib().nrx_chest_ls_mmse_f64(ptr(rx), ptr(pilots), ptr(pil_set), ptr(port_ks), _host_i32(dmrs_syms), nds, l_cdm,
-                                      k_cdm, nk, L, K, nr, P, ptr(nv), 0 if nv.numel() == 1 else 1, ptr(hk), ptr(eq),
-                                      ptr(sc), n, stream()))
+    if sym_mask is None:
+        check(lib().nrx_chest_ls_mmse_f64(ptr(rx), ptr(pilots), ptr(pil_set), ptr(port_ks), _host_i32(dmrs_syms), nds, l_cdm,
+                                          k_cdm, nk, L, K, nr, P, ptr(nv), 0 if nv.numel() == 1 else 1, ptr(hk), ptr(eq),
+                                          ptr(sc), n, stream()))
+    else:
+        check(lib().nrx_chest_ls_mmse_syms_f64(ptr(rx), ptr(pilots), ptr(pil_set), ptr(port_ks), _host_i32(dmrs_syms), nds, l_cdm,
+                                               k_cdm, nk, L, K, nr, P, ptr(nv), 0 if nv.numel() == 1 else 1, ptr(hk), ptr(eq),
+                                               ptr(sc), n, int(sym_mask) & 0xffffffff, stream()))
     return eq, sc
 
 

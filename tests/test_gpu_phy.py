@@ -207,6 +207,12 @@ def test_chest_mmse_fused_equals_separate(dev):
         eq1, sc1 = ops.chest_ls_mmse(T(rx, dev), T(pilots, dev), T(port_ks, dev), ds, T(nv, dev), l_cdm=1, k_cdm=2,
                                      pil_set=pil_set)
         assert torch.equal(eq0, eq1) and torch.equal(sc0, sc1), ds
+        # ... for selected OFDM symbols only (nrx_chest_ls_mmse_syms_f64: the engine skips the symbols without data REs)
+        keep = [l for l in range(L) if l not in ds and l != 5]
+        mask = sum(1 << l for l in keep)
+        eq2, sc2 = ops.chest_ls_mmse(T(rx, dev), T(pilots, dev), T(port_ks, dev), ds, T(nv, dev), l_cdm=1, k_cdm=2,
+                                     pil_set=pil_set, sym_mask=mask)
+        assert torch.equal(eq0[:, :, keep], eq2[:, :, keep]) and torch.equal(sc0[:, :, keep], sc2[:, :, keep]), ds
 
 
 def test_tdl_chain(dev):
