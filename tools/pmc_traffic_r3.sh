@@ -6,13 +6,14 @@ PY=$(python3 -c 'import sys,os;print(os.path.realpath(sys.executable))')
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_r3_fetch -- $PY $R/bench.py --no-cpu --no-fast --no-allrows --no-twopass --steps 1 --warmup 1 > $R/gpurun_out/pmc_r3_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_r3_write -- $PY $R/bench.py --no-cpu --no-fast --no-allrows --no-twopass --steps 1 --warmup 1 > $R/gpurun_out/pmc_r3_write.log 2>&1
 $PY - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 def per_kernel(pat, name):
     acc = collections.defaultdict(list)
     for f in glob.glob(pat):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == name:
-                acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+                m = re.search(r'(\\w+_kernel(?:<[^(]*>)?)', r['Kernel_Name'])
+                acc[m.group(1) if m else r['Kernel_Name'][:60]].append(float(r['Counter_Value']))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 fe = per_kernel("$R/gpurun_out/pmc_r3_fetch/*/*counter_collection.csv", 'FETCH_SIZE')
 wr = per_kernel("$R/gpurun_out/pmc_r3_write/*/*counter_collection.csv", 'WRITE_SIZE')
