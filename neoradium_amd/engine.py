@@ -93,13 +93,13 @@ def gain_times(tables, slots):
     spsf, nfft = tables['slots_per_subframe'], tables['nfft']
     slot_len = [int(v[:-1].sum()) for v in tables['sym_lens']]
     sub = int(sum(slot_len))
-    out = np.empty((len(slots), tables['L'] + 1))
-    for i, n in enumerate(slots):
-        n = int(n)
-        sl = tables['sym_lens'][n % spsf].copy()
+    tab = np.empty((spsf, tables['L'] + 1), dtype=np.int64)       # sample offsets inside the subframe, per slot-in-subframe
+    for r in range(spsf):
+        sl = np.int64(tables['sym_lens'][r]).copy()
         sl[0] -= nfft
-        out[i] = ((n // spsf) * sub + int(sum(slot_len[:n % spsf])) + np.cumsum(sl)) / tables['fs']
-    return out
+        tab[r] = int(sum(slot_len[:r])) + np.cumsum(sl)
+    n = np.asarray(slots, dtype=np.int64)
+    return (((n // spsf) * sub)[:, None] + tab[n % spsf]) / tables['fs']
 
 
 class PdschLink:
