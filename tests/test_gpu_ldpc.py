@@ -442,6 +442,13 @@ def test_onchip_decoder_every_lifting_size(dev, bg):
         finally:
             del os.environ['NRX_LDPC_NOCHIP64']
         assert torch.equal(got, ref), (bg, zc, rows, n_cb)
+        if zc == 384 and bg == 1:                              # the Zc = 384 specialisation served `got`: the generic kernel too
+            os.environ['NRX_LDPC_NOCHIP384'] = '1'
+            try:
+                gen = ops.ldpc_decode(x, cfg, 9, rows=rows)
+            finally:
+                del os.environ['NRX_LDPC_NOCHIP384']
+            assert torch.equal(gen, ref), (zc, rows)
         if zc <= 40 or zc in (88, 208):
             o = oc.decode(llr[:4], bg, ils, zc, num_iter=9, rows=rows)
             assert np.array_equal(o, got[:4].cpu().numpy()), (bg, zc, rows)
