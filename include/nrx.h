@@ -152,6 +152,15 @@ int32_t nrx_ldpc_decode_rows_f64(const double* llr, int32_t n_cb, const nrx_ldpc
 int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
                                           int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
                                           uint8_t* cb_ok, void* stream);
+/* The same for a selection of the code blocks: sel[0 .. *n_sel) index the n_tb * C blocks, list and count on the DEVICE (the
+ * launch covers the worst case, no host read); only the selected blocks' payload bits in tb_out and their cb_ok entries are
+ * written.  nrx_select_failed gives the list of the blocks whose cb_ok is 0 (ascending).  Together: the opt-in two-pass
+ * schedule -- every block with few iterations first, the ones whose CRC24B fails again FROM SCRATCH with all iterations (not
+ * the reference's schedule, ldpc.py:1495-1581 runs a fixed count; same bits for every block that passes either way). */
+int32_t nrx_ldpc_recover_decode_merge_sel_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                              int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                              uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream);
+int32_t nrx_select_failed(const uint8_t* flags, int32_t n, int32_t* sel, int32_t* n_sel, void* stream);
 
 /* ldpc.py:1584-1619 checkCrcAndMerge (+ the TB-level checkCrc('24A') the harness applies).
  * dec: (n_tb*C) x K hard bits.  tb_out (nullable): n_tb x M bits, M = C*(cb_len - 24) for C>1 (>= B: the TB incl.

@@ -47,6 +47,8 @@ SIGNATURES = {
     'nrx_ldpc_decode_f64': (i32, [vp, i32, _cfgp, i32, i32, vp, vp, vp, u64, vp]),
     'nrx_ldpc_crc_merge': (i32, [vp, i32, _cfgp, vp, vp, vp, vp]),
     'nrx_ldpc_recover_decode_merge_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp]),
+    'nrx_ldpc_recover_decode_merge_sel_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'nrx_select_failed': (i32, [vp, i32, vp, vp, vp]),
     'nrx_count_errors': (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
 }
 f64 = C.c_double

@@ -252,6 +252,10 @@ struct FuseArgs {
   FuseGeom g;
   uint8_t* tb_out;
   uint8_t* cb_ok;
+  // FUSED, optional: decode only the code blocks sel[0 .. *n_sel) (indices into the n_tb * C blocks; the count is read on the
+  // device, so the launch covers the worst case and needs no host read): the second pass of the two-pass schedule
+  const int32_t* sel;
+  const int32_t* n_sel;
 };
 // The kernel reads FuseArgs through the kernarg segment pointer at the two places that need it (initial fill, tail)
 // instead of through its parameter: as a parameter its ten scalars and two pointers stay live across the whole layer
@@ -312,13 +316,21 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
 #ifdef NRX_DEC3_PROBE
   uint32_t pk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0, pk_rounds = 0;
 #endif
+  const int32_t* sel = nullptr;
+  if constexpr (FUSED) {
+    const fargs_t fa0 = fuse_args();
+    sel = fa0->sel;
+    if (sel) n_cb = *fa0->n_sel;                            // (wave-uniform; a workgroup beyond the count leaves at once)
+  }
   for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
     PROBE_STAMP(-1);
-    const int cb = cb0 + slot;
+    const int cbi = cb0 + slot;                             // position in the work list
     int one = 1;
     asm volatile("" : "+s"(one));                          // keeps the per-layer `if (live)` a real branch (see dec2)
-    const bool live = cb < n_cb && one != 0;
-    const int cbq = live ? cb : n_cb - 1;                   // (a wave without a code block loads an existing one)
+    const bool live = cbi < n_cb && one != 0;
+    const int cbl = live ? cbi : n_cb - 1;                  // (a wave without a code block loads an existing one)
+    const int cbq = (FUSED && sel) ? sel[cbl] : cbl;        // the code block itself
+    const int cb = cbq;
     const double* in = FUSED ? llr : llr + (size_t)cbq * N;
     int fE = 0, foff = 0;                                  // FUSED: E_r and the offset of the block in the LLR stream
     int rows_live = B::ROWS;
@@ -710,9 +722,9 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
 
 // ldpc.py:1330-1418 recoverRate (first transmission) + :1495-1581 decode + :1584-1619 checkCrcAndMerge in ONE launch.
 // NRX_E_UNSUPPORTED when the configuration has no fused instantiation: the caller runs the three separate entries.
-extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
-                                                     int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
-                                                     uint8_t* cb_ok, void* stream) {
+static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                         int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                         uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream) {
   using namespace nrx_dec3;
   NRX_REQUIRE(llr && cfg && tb_out && cb_ok, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: NULL buffer");
   NRX_REQUIRE(nl >= 1 && qm >= 1 && llr_len > 0 && n_tb >= 0 && n_iter >= 0, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: bad argument");
@@ -721,6 +733,8 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t 
   FuseArgs fa;
   fa.tb_out = tb_out;
   fa.cb_ok = cb_ok;
+  fa.sel = sel;
+  fa.n_sel = n_sel;
   FuseGeom& fg = fa.g;
   fg.C = cfg->C; fg.f = f; fg.qm = qm; fg.F = cfg->F; fg.llr_len = llr_len; fg.cb_len = cfg->cb_len;
   fg.e_small = (gb / cfg->C) * f;
@@ -752,6 +766,61 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t 
   else
     hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 15, true>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa);
   NRX_CHECK_LAUNCH("nrx_ldpc_recover_decode_merge_f64");
+  return NRX_OK;
+}
+
+extern "C" int32_t nrx_ldpc_recover_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                                     int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                                     uint8_t* cb_ok, void* stream) {
+  return recover_decode_merge_impl(llr, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, nullptr, nullptr, stream);
+}
+
+// The same for a selection of the code blocks: sel[0 .. *n_sel) are indices into the n_tb * C blocks, list and count both on
+// the device (the launch covers the worst case; no host read).  Only the selected blocks' payload bits in tb_out and their
+// cb_ok entries are written.  With nrx_select_failed this is the second pass of the two-pass schedule: every block decoded with
+// few iterations first, the ones whose CRC fails decoded again from scratch with all of them.
+extern "C" int32_t nrx_ldpc_recover_decode_merge_sel_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                                         int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                                         uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream) {
+  NRX_REQUIRE(sel && n_sel, NRX_E_ARG, "nrx_ldpc_recover_decode_merge_sel: NULL selection");
+  return recover_decode_merge_impl(llr, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, sel, n_sel, stream);
+}
+
+namespace {
+// indices of the zero entries of flags[0 .. n), ascending, and their number: one workgroup, a ballot scan per 1024 entries
+__global__ void __launch_bounds__(1024)
+select_failed_kernel(const uint8_t* __restrict__ flags, int n, int32_t* __restrict__ sel, int32_t* __restrict__ n_sel) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool f = i < n && flags[i] == 0;
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int k = 0; k < w; ++k) off += wave_cnt[k];
+    if (f) sel[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int k = 0; k < 16; ++k) t += wave_cnt[k];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *n_sel = base_s;
+}
+}  // namespace
+
+// sel (>= n entries) = the indices i with flags[i] == 0 in ascending order, *n_sel = how many: all on the device.
+extern "C" int32_t nrx_select_failed(const uint8_t* flags, int32_t n, int32_t* sel, int32_t* n_sel, void* stream) {
+  NRX_REQUIRE(flags && sel && n_sel && n >= 0, NRX_E_ARG, "nrx_select_failed: bad argument");
+  hipLaunchKernelGGL(select_failed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flags, n, sel, n_sel);
+  NRX_CHECK_LAUNCH("nrx_select_failed");
   return NRX_OK;
 }
 

@@ -417,12 +417,16 @@ class PdschLink:
             ccfg = cw['cfg']
             # rate recovery + decode + CRC/merge in one launch where an instantiation exists (same bits): the demapper then
             # writes every code block's LLRs de-interleaved.  With details=True the LLRs are wanted in the reference's order.
-            fuse = (harq is None and self.firstPassIter is None and self.decoder == "f64" and self.useMax and details is not True
+            fuse = (harq is None and self.decoder == "f64" and self.useMax and details is not True
                     and ops.ldpc_fused_supported(ccfg, cw['nl'], cw['qm'], cw['G'], cw['rows']))
             llr = ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
                                 exact=not self.useMax, llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64,
                                 code_blocks=(ccfg.C, cw['nl']) if fuse else None)
-            fused = ops.ldpc_recover_decode_merge(llr, ccfg, cw['nl'], cw['qm'], self.numIter, rows=cw['rows']) if fuse else None
+            if fuse and self.firstPassIter is not None:     # two passes, both on the fused entry, the failing blocks' list on the device
+                fused = ops.ldpc_recover_decode_merge_two_pass(llr, ccfg, cw['nl'], cw['qm'], self.firstPassIter, self.numIter,
+                                                               rows=cw['rows'])
+            else:
+                fused = ops.ldpc_recover_decode_merge(llr, ccfg, cw['nl'], cw['qm'], self.numIter, rows=cw['rows']) if fuse else None
             if fuse and fused is None:
                 raise RuntimeError("nrx_ldpc_recover_decode_merge_f64 declined a configuration ops.ldpc_fused_supported accepted")
             if fused is not None:

@@ -219,6 +219,25 @@ def ldpc_recover_decode_merge(llr, cfg, nl, qm, n_iter, rows=0):
     return tb_out, cb_ok
 
 
+def ldpc_recover_decode_merge_two_pass(llr, cfg, nl, qm, first_iter, n_iter, rows=0):
+    """The opt-in two-pass schedule on the fused entry: every code block decoded with ``first_iter`` iterations, the ones whose
+    CRC24B fails decoded again FROM SCRATCH with ``n_iter`` -- the list of failing blocks and its length stay on the device
+    (nrx_select_failed, nrx_ldpc_recover_decode_merge_sel_f64): no host read, no gathers.  -> (tb_out, cb_ok) or None."""
+    first = ldpc_recover_decode_merge(llr, cfg, nl, qm, first_iter, rows=rows)
+    if first is None:
+        return None
+    tb_out, cb_ok = first
+    n_tb, G = llr.shape
+    dev = _dev(llr)
+    n_cb = n_tb * cfg.C
+    sel = torch.empty(n_cb, dtype=torch.int32, device=dev)
+    n_sel = torch.empty(1, dtype=torch.int32, device=dev)
+    check(lib().nrx_select_failed(ptr(cb_ok), n_cb, ptr(sel), ptr(n_sel), stream()))
+    check(lib().nrx_ldpc_recover_decode_merge_sel_f64(ptr(llr.contiguous()), n_tb, G, C.byref(cfg), nl, qm, int(n_iter), int(rows or 0),
+                                                      ptr(tb_out), ptr(cb_ok), ptr(sel), ptr(n_sel), stream()))
+    return tb_out, cb_ok
+
+
 def ldpc_fused_supported(cfg, nl, qm, G, rows):
     """Host-side mirror of nrx_ldpc_recover_decode_merge_f64's capability test (so that a caller can choose the demapper's
     output layout before it demaps)."""

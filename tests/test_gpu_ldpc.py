@@ -341,6 +341,21 @@ def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_e
     # rows = 0: the library works the row count out itself
     tb2, ok2 = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, 12, rows=0)
     assert torch.equal(ok2, ok_ref) and torch.equal(tb2, tb_ref)
+    # the two-pass schedule on the same entry (failing blocks listed and counted on the device, decoded again from scratch):
+    # a block that passes after the first pass keeps those bits, every other block gets the 12-iteration result
+    fi = next(k for k in (1, 2, 3, 4) if int(ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, k + 1, rows=rows)[1].sum()) == n_ok)
+    tb3, ok3 = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, fi, rows=rows)      # one iteration short of what the clean block needs
+    n3 = int(ok3.sum())
+    assert n3 < n_ok, "want blocks that pass early (if any), blocks that pass late and blocks that never do"
+    tbt, okt = ops.ldpc_recover_decode_merge_two_pass(xd, cfg, nl, qm, fi, 12, rows=rows)
+    pl = cfg.cb_len - 24
+    early = ok3.bool()
+    want_tb = torch.where(early[:, :, None], tb3.reshape(n_tb, cfg.C, pl), tb_out.reshape(n_tb, cfg.C, pl)).reshape(n_tb, -1)
+    assert torch.equal(okt, torch.where(early, ok3, ok)) and torch.equal(tbt, want_tb)
+    sel = torch.empty(ok.numel(), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().nrx_select_failed(_lib.ptr(ok3), ok3.numel(), _lib.ptr(sel), _lib.ptr(cnt), _lib.stream()))
+    assert int(cnt) == ok3.numel() - n3 and torch.equal(sel[:int(cnt)].long(), (ok3.reshape(-1) == 0).nonzero().reshape(-1))
     # unsupported configurations are reported, not approximated: Zc 352
     cfg2 = _lib.ldpc_config(1, 7500 * 3)
     assert cfg2.Zc != 384 and ops.ldpc_recover_decode_merge(xd[:, :cfg2.C * 1200], cfg2, nl, qm, 5) is None
