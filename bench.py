@@ -390,10 +390,11 @@ def main():
             del fl
         if not args.stub and world == 1 and not args.no_twopass and f64:
             # OPT-IN schedule, reported beside `value`, never instead of it: every code block gets `first_pass_iter` iterations,
-            # the blocks whose CRC fails are decoded again from scratch with all numIter (PdschLink(firstPassIter=n)), so a
-            # failing block carries exactly the reference's result; a block that passes early is assumed to be the code word
-            # the full run ends on as well, and the error counters of the same slots are compared with the reference schedule's
-            tp = build_link(nr, decoder='f64', firstPassIter=10)
+            # the blocks whose CRC fails continue (from their parked decoder state: no iteration twice) to the next check and
+            # finally to all numIter (PdschLink(firstPassIter=(n1, n2))), so a block that never passes carries exactly the
+            # reference's result; a block that passes early is assumed to be the code word the full run ends on as well, and the
+            # error counters of the same slots are compared with the reference schedule's
+            tp = build_link(nr, decoder='f64', firstPassIter=(8, 16))
             kt, wt = min(K, 8), max(min(W, 2), 2)       # (two warm-up steps: the second pass allocates per-step sizes, let the allocator's cache settle)
             pts = []
             for snr_t in sorted({float(args.snr), 35.0}):
@@ -405,7 +406,8 @@ def main():
                 pts.append({"snr_db": snr_t, "value": B * kt / tdt, "unit": "slots/s", "steps": kt, "ms_per_step": tdt / kt * 1e3,
                             "block_errors": int(tc[0]), "blocks": int(tc[1]), "bit_errors": int(tc[2]),
                             "counters_identical_to_reference_schedule": bool((tc == cs).all())})
-            out["two_pass"] = {"first_pass_iter": tp.firstPassIter, "num_iter": link.numIter, "exact_by_construction": False,
+            out["two_pass"] = {"first_pass_iter": tp.firstPassIter, "crc_checks_at": [tp.firstPassIter] + list(tp.passStages),
+                               "num_iter": link.numIter, "exact_by_construction": False,
                                "note": "opt-in (off by default, not the reference's schedule): shown as the labelled fast line",
                                "points": pts}
             del tp

@@ -161,6 +161,20 @@ int32_t nrx_ldpc_recover_decode_merge_sel_f64(const double* llr, int32_t n_tb, i
                                               int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
                                               uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream);
 int32_t nrx_select_failed(const uint8_t* flags, int32_t n, int32_t* sel, int32_t* n_sel, void* stream);
+/* The continuation form: nrx_ldpc_recover_decode_merge_park_f64 = nrx_ldpc_recover_decode_merge_f64, and every code block whose
+ * CRC24B fails leaves its complete decoder state (posterior columns, check-node minima, sign / argmin words) in `state`
+ * (n_tb * C slots of nrx_ldpc_fused_state_bytes(...) bytes, indexed by code block; only failing blocks' slots are written).
+ * nrx_ldpc_resume_decode_merge_sel_f64 continues the selected blocks from their parked state for n_iter MORE iterations:
+ * park(n1) then resume(n2) computes for those blocks exactly what one run of n1 + n2 iterations computes (ldpc.py:1495-1581
+ * with numIter = n1 + n2), so the second pass of the two-pass schedule does not repeat the first pass's iterations. */
+int64_t nrx_ldpc_fused_state_bytes(const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm, int32_t llr_len, int32_t n_rows);
+int32_t nrx_ldpc_recover_decode_merge_park_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                               int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                               uint8_t* cb_ok, void* state, void* stream);
+int32_t nrx_ldpc_resume_decode_merge_sel_f64(int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm,
+                                             int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,
+                                             const int32_t* sel, const int32_t* n_sel, void* state, int32_t park_again,
+                                             void* stream);      /* park_again != 0: blocks that still fail park their state once more */
 
 /* ldpc.py:1584-1619 checkCrcAndMerge (+ the TB-level checkCrc('24A') the harness applies).
  * dec: (n_tb*C) x K hard bits.  tb_out (nullable): n_tb x M bits, M = C*(cb_len - 24) for C>1 (>= B: the TB incl.

@@ -256,6 +256,8 @@ struct FuseArgs {
   // device, so the launch covers the worst case and needs no host read): the second pass of the two-pass schedule
   const int32_t* sel;
   const int32_t* n_sel;
+  // FUSED, MODE 1 / 2: where a code block's decoder state is parked between two launches (see StateLay), indexed by code block
+  double* state;
 };
 // The kernel reads FuseArgs through the kernarg segment pointer at the two places that need it (initial fill, tail)
 // instead of through its parameter: as a parameter its ten scalars and two pointers stay live across the whole layer
@@ -276,7 +278,21 @@ __device__ __forceinline__ fargs_t fuse_args() {
 // unified registers, the rest went to scratch and the kernel was slower than the workspace kernel, 146.6 against 137.5 ms.)
 // FUSED = false: llr = rate-recovered LLRs (n_cb, N), hard = (n_cb, K) hard decisions.
 // FUSED = true:  llr = demapper output (n_tb, llr_len), tb_out = (n_tb, C*payload) merged hard bits, cb_ok = (n_cb,).
-template <int BG, int ZI, int RA, bool FUSED, int NS = 2>
+// MODE (FUSED only), two bits: 0 = a whole decode.  Bit 0 (park): a block whose CRC fails at the end leaves its complete decoder
+// state (posterior columns, check-node minima, sign / argmin words) in fa.state.  Bit 1 (resume): the initial fill is replaced by
+// reading that state back, and n_iter more iterations follow.  park(n1), then resume(n2) on the failing blocks, IS one run of
+// n1 + n2 iterations for them -- the continuation form of the multi-pass schedule: no pass repeats an earlier pass's iterations.
+template <int BG, int RA> struct StateLay {
+  using B = GR<BG, RA>;
+  using Y = Lay<BG, RA>;
+  static constexpr int NEXT = Y::n_ext() > 0 ? Y::n_ext() : 1;
+  static constexpr int NW = Y::n_wide() > 0 ? Y::n_wide() : 1, NN = (Y::n_narrow() + 1) / 2;
+  static constexpr int COL = 0;                       // columns 1 .. CORE-1 (column 0 lives in a register)
+  static constexpr int C0 = COL + B::CORE - 1, F1 = C0 + 1, M1 = F1 + 1, M2 = M1 + B::ROWS, REXT = M2 + B::ROWS;
+  static constexpr int WORDS = REXT + NEXT;           // one 32-bit word per slot (low half)
+  static constexpr int NF = WORDS + NW + NN;          // fields of Zc doubles
+};
+template <int BG, int ZI, int RA, bool FUSED, int NS = 2, int MODE = 0>
 __global__ void __launch_bounds__(NS * kZ.z[ZI], NS == 2 ? 3 : 1)
 ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint8_t* __restrict__ hard, mtab_t wtab,
                        FuseArgs /* read through fuse_args() */) {
@@ -395,7 +411,28 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       }
     };
     // ---- load: prepend the two punctured columns as zeros (ldpc.py:1536-1538)
-    {
+    if constexpr (FUSED && (MODE & 2)) {
+      using SL = StateLay<BG, RA>;
+      const double* st = fuse_args()->state + (size_t)cbq * SL::NF * ZC + zl;
+      static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value + 1;
+        Ps[c * ZS + zl] = st[(size_t)(SL::COL + c - 1) * ZC];
+      });
+      c0 = st[(size_t)SL::C0 * ZC];
+      f1 = st[(size_t)SL::F1 * ZC];
+      static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(lc)::value;
+        m1[L] = st[(size_t)(SL::M1 + L) * ZC];
+        m2[L] = st[(size_t)(SL::M2 + L) * ZC];
+        if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC];
+      });
+      static_for<SL::NW>([&](auto i) __attribute__((always_inline)) {
+        sgw[decltype(i)::value] = (uint32_t)__double_as_longlong(st[(size_t)(SL::WORDS + decltype(i)::value) * ZC]);
+      });
+      static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
+        sgn[decltype(i)::value] = (uint32_t)__double_as_longlong(st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC]);
+      });
+    } else {
       double xs[B::CORE - 2 + NEXT];
       static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
@@ -421,9 +458,11 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         }
       });
     }
-    c0 = 0.0;                                              // punctured column (ldpc.py:1536-1538)
-    static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
-    static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
+    if constexpr (!(FUSED && (MODE & 2))) {
+      c0 = 0.0;                                            // punctured column (ldpc.py:1536-1538)
+      static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
+      static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
+    }
     __syncthreads();
 
     // wrap masks of the layer about to run (SGPR pairs)
@@ -645,6 +684,32 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         uint32_t tot = 0;
         for (int w = 0; w < ZC / 64; ++w) tot = gf2_mulc24<gf2_xpow24(64)>(tot) ^ red[slot * (ZC / 64) + w];
         fa->cb_ok[cb] = tot == 0 ? 1 : 0;
+        if constexpr ((MODE & 1) != 0) red[NS * (ZC / 64) + slot] = tot == 0 ? 1u : 0u;
+      }
+      if constexpr ((MODE & 1) != 0) {
+        __syncthreads();
+        if (live && red[NS * (ZC / 64) + slot] == 0u) {      // CRC failed: park the state for the continuation launch
+          using SL = StateLay<BG, RA>;
+          double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
+          static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value + 1;
+            st[(size_t)(SL::COL + c - 1) * ZC] = Ps[c * ZS + zt];
+          });
+          st[(size_t)SL::C0 * ZC] = c0;
+          st[(size_t)SL::F1 * ZC] = f1;
+          static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
+            constexpr int L = decltype(lc)::value;
+            st[(size_t)(SL::M1 + L) * ZC] = m1[L];
+            st[(size_t)(SL::M2 + L) * ZC] = m2[L];
+            if constexpr (Y::has_ext(L)) st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC] = rext[Y::ext_idx(L)];
+          });
+          static_for<SL::NW>([&](auto i) __attribute__((always_inline)) {
+            st[(size_t)(SL::WORDS + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgw[decltype(i)::value]);
+          });
+          static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
+            st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgn[decltype(i)::value]);
+          });
+        }
       }
     }
     __syncthreads();
@@ -724,7 +789,8 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
 // NRX_E_UNSUPPORTED when the configuration has no fused instantiation: the caller runs the three separate entries.
 static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
                                          int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
-                                         uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream) {
+                                         uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream,
+                                         int mode = 0, double* state = nullptr, size_t* state_bytes_per_cb = nullptr) {
   using namespace nrx_dec3;
   NRX_REQUIRE(llr && cfg && tb_out && cb_ok, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: NULL buffer");
   NRX_REQUIRE(nl >= 1 && qm >= 1 && llr_len > 0 && n_tb >= 0 && n_iter >= 0, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: bad argument");
@@ -735,6 +801,7 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   fa.cb_ok = cb_ok;
   fa.sel = sel;
   fa.n_sel = n_sel;
+  fa.state = state;
   FuseGeom& fg = fa.g;
   fg.C = cfg->C; fg.f = f; fg.qm = qm; fg.F = cfg->F; fg.llr_len = llr_len; fg.cb_len = cfg->cb_len;
   fg.e_small = (gb / cfg->C) * f;
@@ -752,6 +819,10 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
     ::nrx::set_error("nrx_ldpc_recover_decode_merge: no fused instantiation for bg %d Zc %d C %d rows %d", cfg->bg, cfg->Zc, cfg->C, n_rows);
     return NRX_E_UNSUPPORTED;
   }
+  if (state_bytes_per_cb) {          // (query: the size of a parked state for this configuration's instantiation)
+    *state_bytes_per_cb = sizeof(double) * 384 * (size_t)(n_rows <= 13 ? StateLay<1, 13>::NF : StateLay<1, 15>::NF);
+    return NRX_OK;
+  }
   if (n_tb == 0) return NRX_OK;
   const uint64_t* wt = nullptr;
   const int32_t rc = wrap_table(n_rows, &wt);
@@ -761,10 +832,14 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   const int grid = n_wg < 1024 ? n_wg : 1024;
   constexpr int ZI384 = zindex_c(384);
   hipStream_t st = (hipStream_t)stream;
-  if (n_rows <= 13)
-    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 13, true>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa);
-  else
-    hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 15, true>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa);
+#define NRX_FUSED_LAUNCH(RA_, MODE_) \
+  hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, RA_, true, 2, MODE_>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa)
+  if (n_rows <= 13) {
+    if (mode == 0) NRX_FUSED_LAUNCH(13, 0); else if (mode == 1) NRX_FUSED_LAUNCH(13, 1); else if (mode == 2) NRX_FUSED_LAUNCH(13, 2); else NRX_FUSED_LAUNCH(13, 3);
+  } else {
+    if (mode == 0) NRX_FUSED_LAUNCH(15, 0); else if (mode == 1) NRX_FUSED_LAUNCH(15, 1); else if (mode == 2) NRX_FUSED_LAUNCH(15, 2); else NRX_FUSED_LAUNCH(15, 3);
+  }
+#undef NRX_FUSED_LAUNCH
   NRX_CHECK_LAUNCH("nrx_ldpc_recover_decode_merge_f64");
   return NRX_OK;
 }
@@ -784,6 +859,33 @@ extern "C" int32_t nrx_ldpc_recover_decode_merge_sel_f64(const double* llr, int3
                                                          uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream) {
   NRX_REQUIRE(sel && n_sel, NRX_E_ARG, "nrx_ldpc_recover_decode_merge_sel: NULL selection");
   return recover_decode_merge_impl(llr, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, sel, n_sel, stream);
+}
+
+// The continuation form of the two-pass schedule.  _park: nrx_ldpc_recover_decode_merge_f64, and every block whose CRC24B
+// fails leaves its decoder state in `state` (nrx_ldpc_fused_state_bytes per code block, indexed by code block).  _resume: the
+// blocks of the selection continue from their parked state for n_iter MORE iterations (llr is not read): park(n1) followed by
+// resume(n2) computes exactly what one run of n1 + n2 iterations computes for those blocks.
+extern "C" int64_t nrx_ldpc_fused_state_bytes(const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm, int32_t llr_len, int32_t n_rows) {
+  if (!cfg) return -1;
+  size_t b = 0;
+  uint8_t dummy = 0;
+  const double d0 = 0;
+  const int32_t rc = recover_decode_merge_impl(&d0, 1, llr_len, cfg, nl, qm, 1, n_rows, &dummy, &dummy, nullptr, nullptr, nullptr, 0, nullptr, &b);
+  return rc == NRX_OK ? (int64_t)b : (int64_t)rc;
+}
+extern "C" int32_t nrx_ldpc_recover_decode_merge_park_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
+                                                          int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
+                                                          uint8_t* cb_ok, void* state, void* stream) {
+  NRX_REQUIRE(state, NRX_E_ARG, "nrx_ldpc_recover_decode_merge_park: NULL state");
+  return recover_decode_merge_impl(llr, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, nullptr, nullptr, stream, 1, (double*)state);
+}
+extern "C" int32_t nrx_ldpc_resume_decode_merge_sel_f64(int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm,
+                                                        int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,
+                                                        const int32_t* sel, const int32_t* n_sel, void* state, int32_t park_again,
+                                                        void* stream) {
+  NRX_REQUIRE(state && sel && n_sel, NRX_E_ARG, "nrx_ldpc_resume_decode_merge_sel: NULL state / selection");
+  return recover_decode_merge_impl((const double*)state, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, sel, n_sel, stream,
+                                   park_again ? 3 : 2, (double*)state);
 }
 
 namespace {

@@ -121,13 +121,19 @@ class PdschLink:
         self.numIter = int(numIter)
         self.polarInt = bool(polarInt)        # estimateChannelLS(polarInt=True, kernel='linear') of PDSCH-endToEnd.ipynb
         self.useMax = bool(useMax)            # getLLRsFromGrid(useMax=...): max-log (default) or exact log-sum-exp LLRs
-        # Opt-in two-pass decoding (NOT the reference's schedule, off by default): every code block is first decoded
-        # with `firstPassIter` iterations; the blocks whose CRC fails are then decoded again FROM SCRATCH with the full
-        # `numIter` iterations, so a failing block gets exactly the reference's result and a passing block is the
-        # code word the full run converges to as well.  Costs one host read (the number of failing blocks) per batch.
-        self.firstPassIter = None if firstPassIter is None else int(firstPassIter)
-        if self.firstPassIter is not None and not 0 < self.firstPassIter < self.numIter:
-            raise ValueError("firstPassIter must be between 1 and numIter-1")
+        # Opt-in multi-pass decoding (NOT the reference's schedule, off by default): `firstPassIter` = n or an ascending
+        # list (n1, n2, ...).  Every code block is decoded with n1 iterations; the blocks whose CRC fails go on to n2, ...,
+        # `numIter` iterations in total, so a block that never passes gets exactly the reference's result and a passing
+        # block is assumed to be the code word the full run ends on as well.  Where the fused float64 entry exists the
+        # failing blocks CONTINUE from their parked decoder state (no iteration is done twice) and the list of failing
+        # blocks stays on the device; elsewhere they are decoded again from scratch after one host read per batch.
+        if firstPassIter is None:
+            self.firstPassIter, self.passStages = None, ()
+        else:
+            marks = [int(v) for v in (firstPassIter if isinstance(firstPassIter, (list, tuple)) else [firstPassIter])]
+            if not marks or marks != sorted(set(marks)) or not 0 < marks[0] or not marks[-1] < self.numIter:
+                raise ValueError("firstPassIter must be between 1 and numIter-1 (an ascending list for several checks)")
+            self.firstPassIter, self.passStages = marks[0], tuple(marks[1:])
         self.codeRate = codeRate
         self.nl = pdsch.numLayers
         self.numCW = pdsch.numCW
@@ -424,7 +430,7 @@ class PdschLink:
                                 code_blocks=(ccfg.C, cw['nl']) if fuse else None)
             if fuse and self.firstPassIter is not None:     # two passes, both on the fused entry, the failing blocks' list on the device
                 fused = ops.ldpc_recover_decode_merge_two_pass(llr, ccfg, cw['nl'], cw['qm'], self.firstPassIter, self.numIter,
-                                                               rows=cw['rows'])
+                                                               rows=cw['rows'], stages=self.passStages)
             else:
                 fused = ops.ldpc_recover_decode_merge(llr, ccfg, cw['nl'], cw['qm'], self.numIter, rows=cw['rows']) if fuse else None
             if fuse and fused is None:

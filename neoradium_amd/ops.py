@@ -219,22 +219,61 @@ def ldpc_recover_decode_merge(llr, cfg, nl, qm, n_iter, rows=0):
     return tb_out, cb_ok
 
 
-def ldpc_recover_decode_merge_two_pass(llr, cfg, nl, qm, first_iter, n_iter, rows=0):
-    """The opt-in two-pass schedule on the fused entry: every code block decoded with ``first_iter`` iterations, the ones whose
-    CRC24B fails decoded again FROM SCRATCH with ``n_iter`` -- the list of failing blocks and its length stay on the device
-    (nrx_select_failed, nrx_ldpc_recover_decode_merge_sel_f64): no host read, no gathers.  -> (tb_out, cb_ok) or None."""
-    first = ldpc_recover_decode_merge(llr, cfg, nl, qm, first_iter, rows=rows)
-    if first is None:
+_fused_state = {}       # (device index) -> parked-state buffer of the continuation form, grown on demand and reused
+
+
+def ldpc_recover_decode_merge_two_pass(llr, cfg, nl, qm, first_iter, n_iter, rows=0, restart=False, stages=None):
+    """The opt-in two-pass schedule on the fused entry: every code block decoded with ``first_iter`` iterations; the ones whose
+    CRC24B fails CONTINUE from their parked decoder state for the remaining ``n_iter - first_iter`` (for them the result is
+    exactly that of one run of ``n_iter`` iterations, and no iteration is done twice), or -- ``restart=True`` -- are decoded
+    again from scratch with ``n_iter``.  ``stages`` = ascending iteration counts between the two (continuation form only): the
+    failing blocks are checked again at each of them.  The list of failing blocks and its length stay on the device
+    (nrx_select_failed): no host read, no gathers.  -> (tb_out, cb_ok) or None when the configuration has no fused instantiation."""
+    if llr.dtype != torch.float64 or llr.dim() != 2 or not (cfg.bg == 1 and cfg.Zc == 384 and cfg.C > 1):
         return None
-    tb_out, cb_ok = first
+    llr = llr.contiguous()
     n_tb, G = llr.shape
     dev = _dev(llr)
     n_cb = n_tb * cfg.C
+    if restart:
+        first = ldpc_recover_decode_merge(llr, cfg, nl, qm, first_iter, rows=rows)
+        if first is None:
+            return None
+        tb_out, cb_ok = first
+        state = None
+    else:
+        per = int(lib().nrx_ldpc_fused_state_bytes(C.byref(cfg), nl, qm, G, int(rows or 0)))
+        if per == -3:
+            return None
+        if per < 0:
+            check(per)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        state = _fused_state.get(key)
+        if state is None or state.numel() < n_cb * per:
+            state = _fused_state[key] = torch.empty(n_cb * per, dtype=torch.uint8, device=dev)
+        tb_out = torch.empty((n_tb, cfg.C * (cfg.cb_len - 24)), dtype=torch.uint8, device=dev)
+        cb_ok = torch.empty((n_tb, cfg.C), dtype=torch.uint8, device=dev)
+        check(lib().nrx_ldpc_recover_decode_merge_park_f64(ptr(llr), n_tb, G, C.byref(cfg), nl, qm, int(first_iter), int(rows or 0),
+                                                           ptr(tb_out), ptr(cb_ok), ptr(state), stream()))
     sel = torch.empty(n_cb, dtype=torch.int32, device=dev)
     n_sel = torch.empty(1, dtype=torch.int32, device=dev)
     check(lib().nrx_select_failed(ptr(cb_ok), n_cb, ptr(sel), ptr(n_sel), stream()))
-    check(lib().nrx_ldpc_recover_decode_merge_sel_f64(ptr(llr.contiguous()), n_tb, G, C.byref(cfg), nl, qm, int(n_iter), int(rows or 0),
-                                                      ptr(tb_out), ptr(cb_ok), ptr(sel), ptr(n_sel), stream()))
+    if restart:
+        check(lib().nrx_ldpc_recover_decode_merge_sel_f64(ptr(llr), n_tb, G, C.byref(cfg), nl, qm, int(n_iter), int(rows or 0),
+                                                          ptr(tb_out), ptr(cb_ok), ptr(sel), ptr(n_sel), stream()))
+        return tb_out, cb_ok
+    marks = [int(v) for v in (stages or ()) if int(first_iter) < int(v) < int(n_iter)] + [int(n_iter)]
+    done = int(first_iter)
+    for k, upto in enumerate(marks):
+        last = k == len(marks) - 1
+        check(lib().nrx_ldpc_resume_decode_merge_sel_f64(n_tb, G, C.byref(cfg), nl, qm, upto - done, int(rows or 0), ptr(tb_out),
+                                                         ptr(cb_ok), ptr(sel), ptr(n_sel), ptr(state), 0 if last else 1, stream()))
+        done = upto
+        if not last:        # the blocks that still fail (a subset of the selection: the others' cb_ok is 1 now)
+            sel2 = torch.empty(n_cb, dtype=torch.int32, device=dev)
+            n_sel2 = torch.empty(1, dtype=torch.int32, device=dev)
+            check(lib().nrx_select_failed(ptr(cb_ok), n_cb, ptr(sel2), ptr(n_sel2), stream()))
+            sel, n_sel = sel2, n_sel2
     return tb_out, cb_ok
 
 

@@ -105,6 +105,27 @@ def test_engine_counters_at_metric_size(link, dev):
     assert rel <= 1e-5                        # north-star tolerance on float LLRs
 
 
+def test_multi_pass_schedule_at_metric_size(dev):
+    """The opt-in multi-pass schedule at the metric configuration (fused float64 entry, failing blocks continued from their
+    parked decoder state with the list kept on the device): at the waterfall, where blocks pass early, late and never, the CRC
+    verdicts and decoded transport blocks of every slot equal those of the reference schedule (a fixed 30 iterations here),
+    for one check and for several; the restart form of the host-compacted path is covered by the small-size engine test."""
+    import torch
+    import bench
+    import neoradium_amd as nr
+    ref = bench.build_link(nr, decoder="f64", num_iter=30)
+    want = ref.run(4, 3, 31.0, seed=21, details="verdicts")[1][0][1]
+    n_ok = int(want['cb_ok'].sum())
+    assert 0 < n_ok < want['cb_ok'].numel()
+    for marks in (6, (5, 12), (4, 9, 17)):
+        mp = bench.build_link(nr, decoder="f64", num_iter=30, firstPassIter=marks)
+        got = mp.run(4, 3, 31.0, seed=21, details="verdicts")[1][0][1]
+        assert torch.equal(got['cb_ok'], want['cb_ok']) and torch.equal(got['tb_out'], want['tb_out']), marks
+        del mp
+    with pytest.raises(ValueError):
+        bench.build_link(nr, decoder="f64", num_iter=30, firstPassIter=(9, 9))
+
+
 def test_cfg3_link_at_273_prb(dev):
     """BASELINE cfg3 through the engine at its full size: 273 PRB, 256-QAM, 4 layers, 4x4 CDL-D 300 ns, BG1 R = 0.75 =>
     TBS 950 984, 113 code blocks of Zc 384.  With perfect CSI (frequency-domain channel) the link is clean at

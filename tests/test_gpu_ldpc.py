@@ -347,11 +347,18 @@ def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_e
     tb3, ok3 = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, fi, rows=rows)      # one iteration short of what the clean block needs
     n3 = int(ok3.sum())
     assert n3 < n_ok, "want blocks that pass early (if any), blocks that pass late and blocks that never do"
-    tbt, okt = ops.ldpc_recover_decode_merge_two_pass(xd, cfg, nl, qm, fi, 12, rows=rows)
     pl = cfg.cb_len - 24
     early = ok3.bool()
     want_tb = torch.where(early[:, :, None], tb3.reshape(n_tb, cfg.C, pl), tb_out.reshape(n_tb, cfg.C, pl)).reshape(n_tb, -1)
-    assert torch.equal(okt, torch.where(early, ok3, ok)) and torch.equal(tbt, want_tb)
+    for restart in (True, False):       # from scratch / continued from the parked state: the same bits as one 12-iteration run
+        tbt, okt = ops.ldpc_recover_decode_merge_two_pass(xd, cfg, nl, qm, fi, 12, rows=rows, restart=restart)
+        assert torch.equal(okt, torch.where(early, ok3, ok)) and torch.equal(tbt, want_tb), restart
+    # ... and with checks in between (blocks that still fail park their state again): a block keeps the bits of the first check it passes
+    tb7, ok7 = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, 7, rows=rows)
+    mid = ok7.bool() & ~early
+    want3 = torch.where(mid[:, :, None], tb7.reshape(n_tb, cfg.C, pl), want_tb.reshape(n_tb, cfg.C, pl)).reshape(n_tb, -1)
+    tbs, oks = ops.ldpc_recover_decode_merge_two_pass(xd, cfg, nl, qm, fi, 12, rows=rows, stages=(7,))
+    assert torch.equal(oks, ok3 | ok7 | ok) and torch.equal(tbs, want3)
     sel = torch.empty(ok.numel(), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().nrx_select_failed(_lib.ptr(ok3), ok3.numel(), _lib.ptr(sel), _lib.ptr(cnt), _lib.stream()))

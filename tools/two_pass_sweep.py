@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch
 import neoradium_amd as nr
 import bench
-for fp in (6, 8, 10, 12, 14, 16):
+for fp in (8, 10, 12, (8, 16), (10, 20), (8, 16, 28), (10, 16, 24, 34), (6, 10, 16, 26)):
     link = bench.build_link(nr, decoder='f64', firstPassIter=fp)
     B = 256
     for snr in (31.0,):
