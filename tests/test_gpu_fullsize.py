@@ -122,6 +122,11 @@ def test_multi_pass_schedule_at_metric_size(dev):
         got = mp.run(4, 3, 31.0, seed=21, details="verdicts")[1][0][1]
         assert torch.equal(got['cb_ok'], want['cb_ok']) and torch.equal(got['tb_out'], want['tb_out']), marks
         del mp
+    # nothing fails the first check: the continuation launches find an empty list
+    mp = bench.build_link(nr, decoder="f64", num_iter=30, firstPassIter=(5, 12))
+    hi_ref = ref.run(0, 2, 60.0, seed=3, details="verdicts")[1][0][1]
+    hi = mp.run(0, 2, 60.0, seed=3, details="verdicts")[1][0][1]
+    assert bool(hi['cb_ok'].all()) and torch.equal(hi['cb_ok'], hi_ref['cb_ok']) and torch.equal(hi['tb_out'], hi_ref['tb_out'])
     with pytest.raises(ValueError):
         bench.build_link(nr, decoder="f64", num_iter=30, firstPassIter=(9, 9))
 
