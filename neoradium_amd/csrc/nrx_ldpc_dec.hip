@@ -389,6 +389,10 @@ int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int 
   const int n_wg = (n_cb + NS - 1) / NS;
   int grid = n_wg < 512 / NS ? n_wg : 512 / NS;
   if (EXACT) {
+    if (const char* e = getenv("NRX_LDPC_WS_GRID")) {          // developer switch: workgroups (= 2 x 494 KB workspace slices) in flight
+      const int gcap = atoi(e);
+      if (gcap >= 1 && gcap < grid) grid = gcap;
+    }
     const size_t per = ExactWs<T>::bytes(G::ROWS);
     NRX_REQUIRE(ws != nullptr && ws_bytes >= NS * per, NRX_E_ARG,
                 "nrx_ldpc_decode_f64: workspace of >= %zu bytes required", NS * per);
@@ -408,7 +412,7 @@ int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int 
 int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
                                     int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec2.hip
 int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                      int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec3.hip
+                                      int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes);  // nrx_ldpc_dec3.hip
 int32_t nrx_ldpc_decode_chipz_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
                                      int32_t n_rows, uint8_t* hard, hipStream_t st);   // nrx_ldpc_dec4.hip
 namespace {
@@ -441,7 +445,7 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
   if constexpr (EXACT) {
     // float64, hard decisions of the information bits, few enough rows: the whole working set fits on chip
     if (hard && !belief && out_cols == cfg->K) {
-      const int32_t rc = nrx_ldpc_decode_chip64_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream);
+      const int32_t rc = nrx_ldpc_decode_chip64_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream, ws, ws_bytes);
       if (rc != 1) return rc;      // 1 = no Zc = 384 instantiation for this (bg, Zc, rows)
     }
   }

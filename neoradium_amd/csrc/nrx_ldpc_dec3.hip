@@ -26,6 +26,12 @@
 #include "nrx_ldpc_graph.h"
 #include "nrx_common.h"
 
+#ifndef NRX_DEC3_HYB_RC
+#define NRX_DEC3_HYB_RC 12
+#endif
+#ifndef NRX_DEC3_HYB_PF
+#define NRX_DEC3_HYB_PF 2
+#endif
 namespace nrx_dec3 {
 using namespace nrx_ldpc;
 
@@ -258,6 +264,9 @@ struct FuseArgs {
   const int32_t* n_sel;
   // FUSED, MODE 1 / 2: where a code block's decoder state is parked between two launches (see StateLay), indexed by code block
   double* state;
+  // RC < RA (hybrid instantiations): the check-node state (pm1, pm2, extension posterior) of the rows >= RC streams through this
+  // workspace, [workgroup][slot][row - RC][3][Zc] doubles
+  double* ws;
 };
 // The kernel reads FuseArgs through the kernarg segment pointer at the two places that need it (initial fill, tail)
 // instead of through its parameter: as a parameter its ten scalars and two pointers stay live across the whole layer
@@ -292,7 +301,12 @@ template <int BG, int RA> struct StateLay {
   static constexpr int WORDS = REXT + NEXT;           // one 32-bit word per slot (low half)
   static constexpr int NF = WORDS + NW + NN;          // fields of Zc doubles
 };
-template <int BG, int ZI, int RA, bool FUSED, int NS = 2, int MODE = 0>
+// RC = rows whose check-node state stays in registers (default: all RA of them).  RC < RA: the HYBRID for more rows than fit --
+// rates below ~0.6, HARQ retransmissions, all 46 rows: everything of this kernel (rotated rows, unit x pm under EXEC, DS
+// immediates, the barrier plan) applies to every row, and the rows >= RC, the sparse ones, keep pm1 / pm2 / extension posterior in
+// a workspace instead: read two streamed layers ahead into a small register ring, written back when the layer has them (sign /
+// argmin words of all rows stay in registers).  Replaces the workspace kernel of nrx_ldpc_dec.hip for Zc = 384.
+template <int BG, int ZI, int RA, bool FUSED, int NS = 2, int MODE = 0, int RC = RA>
 __global__ void __launch_bounds__(NS * kZ.z[ZI], NS == 2 ? 3 : 1)
 ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint8_t* __restrict__ hard, mtab_t wtab,
                        FuseArgs /* read through fuse_args() */) {
@@ -328,6 +342,21 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   u32x2 uv = {0u, 0u};                                     // register pair of the +-1.0 / +-0.75 units: low word stays 0
   double c0 = 0.0;                                         // element z of column 0 (Lay::sigma: every layer meets it in its own lane)
   double f1 = 0.0;                                         // column 1 handed from a layer to its successor (Lay::fwd1)
+  static_assert(RC == RA || (!FUSED && MODE == 0 && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
+  constexpr bool HYB = RC < RA;
+  constexpr int PF = NRX_DEC3_HYB_PF;                      // streamed layers fetched ahead
+  static_assert(!HYB || (RA - RC > PF && (RA - RC) % PF == 0), "the ring slot of a streamed layer is (L - RC) mod PF in every iteration");
+  double pf_m1[PF] = {}, pf_m2[PF] = {}, pf_rx[PF] = {};
+  typedef double __attribute__((address_space(1))) * gD;
+  char* wsb = nullptr;                                     // this slot's streamed state
+  if constexpr (HYB) wsb = (char*)fuse_args()->ws + ((size_t)blockIdx.x * NS + slot) * (size_t)(RA - RC) * 3 * ZC * sizeof(double);
+  // (uniform base + compile-time offset) made an opaque SGPR pair first: `global_load/store v, v_lane_offset, s[base]`
+  auto wsL = [](char* base, size_t off, uint32_t lane_off) __attribute__((always_inline)) -> gD {
+    char* b = base + off;
+    asm volatile("" : "+s"(b));
+    return (gD)(b + (size_t)lane_off);
+  };
+  auto ws_off = [](int L, int a) constexpr -> size_t { return ((size_t)(L - RC) * 3 + a) * ZC * sizeof(double); };
 
 #ifdef NRX_DEC3_PROBE
   uint32_t pk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0, pk_rounds = 0;
@@ -433,22 +462,34 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         sgn[decltype(i)::value] = (uint32_t)__double_as_longlong(st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC]);
       });
     } else {
-      double xs[B::CORE - 2 + NEXT];
+      double xs[B::CORE - 2 + NEXT];      // (the hybrid only touches the entries of its on-chip rows)
       static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
         xs[c] = in[addr(c * ZC, 0)];
       });
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
-        if constexpr (Y::has_ext(L)) xs[B::CORE - 2 + Y::ext_idx(L)] = in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))];   // element of row (z + sigma_L)
+        if constexpr (Y::has_ext(L) && L < RC) xs[B::CORE - 2 + Y::ext_idx(L)] = in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))];   // element of row (z + sigma_L)
       });
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (HYB) {       // streamed rows: zero minima, the extension LLR (or 0 beyond the rows that run) straight to the workspace
+        const uint32_t zo8 = 8u * (uint32_t)zl;
+        static_for<RA - RC>([&](auto lc) __attribute__((always_inline)) {
+          constexpr int L = RC + decltype(lc)::value;
+          *wsL(wsb, ws_off(L, 0), zo8) = 0.0;
+          *wsL(wsb, ws_off(L, 1), zo8) = 0.0;
+          if constexpr (Y::has_ext(L)) {
+            const double e = clip10(in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))]) + 0.0;
+            *wsL(wsb, ws_off(L, 2), zo8) = L < rows_live ? e : 0.0;
+          }
+        });
+      }
       Ps[1 * ZS + zl] = 0.0;
       static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
         Ps[(c + 2) * ZS + zl] = value(xs[c], c * ZC, 0);
       });
-      static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
+      static_for<RC>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
         m1[L] = 0.0;
         m2[L] = 0.0;
@@ -465,6 +506,16 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     }
     __syncthreads();
 
+    if constexpr (HYB) {      // (the barrier above waited for the fill's stores)
+      int zq = z;
+      asm volatile("" : "+v"(zq));
+      static_for<PF>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, Lk = RC + k;
+        pf_m1[k] = *wsL(wsb, ws_off(Lk, 0), 8u * (uint32_t)zq);
+        pf_m2[k] = *wsL(wsb, ws_off(Lk, 1), 8u * (uint32_t)zq);
+        if constexpr (Y::has_ext(Lk)) pf_rx[k] = *wsL(wsb, ws_off(Lk, 2), 8u * (uint32_t)zq);
+      });
+    }
     // wrap masks of the layer about to run (SGPR pairs)
     uint64_t wcur[19];
     static_for<(Y::has_ext(0) ? Y::deg(0) - 1 : Y::deg(0))>([&](auto jc) __attribute__((always_inline)) {
@@ -484,6 +535,21 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         uint32_t wo = 0;   // opaque zero: keeps the layer's mask loads inside the layer
         asm volatile("" : "+v"(zbo), "+s"(wo));
         const mtab_t wml = (mtab_t)((const char __attribute__((address_space(4)))*)wm + __builtin_amdgcn_readfirstlane(wo));
+        // hybrid, streamed layer: its state out of the ring, and the ring slot refilled with the streamed layer PF ahead (of the
+        // next iteration at the end of this one).  Outside the `live` branch: inside it the values become phis at the join.
+        double cm1 = 0.0, cm2 = 0.0, crx = 0.0;
+        uint32_t zo8 = 0;
+        if constexpr (HYB && L >= RC) {
+          constexpr int k = (L - RC) % PF;
+          constexpr int Lp = L + PF < RA ? L + PF : RC + (L + PF - RA);
+          zo8 = zbo - sb;                                   // 8 * z
+          cm1 = pf_m1[k];
+          cm2 = pf_m2[k];
+          crx = pf_rx[k];
+          pf_m1[k] = *wsL(wsb, ws_off(Lp, 0), zo8);
+          pf_m2[k] = *wsL(wsb, ws_off(Lp, 1), zo8);
+          if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(wsb, ws_off(Lp, 2), zo8);
+        }
         // byte addresses of element z of column 0 of this slot: plain, wrapped (- Zc), and both + HI
         const uint32_t zb = zbo, zbw = zbo - zc8, zbh = zbo + HI, zbwh = zbo - zc8 + HI;
         if (__builtin_expect(live, 1)) {
@@ -514,7 +580,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           __builtin_amdgcn_sched_barrier(0);
           // ---- old state: pm1 / pm2 (scaled minima carrying the row parity), and the sign / argmin word: argmin in the low
           // bits of its field, above it the signs of the t_j of the previous iteration, edge 0 highest
-          const double om1 = m1[L], om2 = m2[L];
+          double om1, om2;
+          if constexpr (L < RC) { om1 = m1[L]; om2 = m2[L]; } else { om1 = cm1; om2 = cm2; }
           uint32_t word, oidx;
           int top;   // left shift that brings the highest sign bit of the field to bit 31
           if constexpr (WIDE) {
@@ -529,7 +596,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           }
           // ---- pass 1b: t_j = r_j - msg_old_j = fma(-u_j, argmin ? pm2 : pm1, r_j)  (ldpc.py:1550-1553); the extension
           // column's r comes from its register
-          if constexpr (EXT) t[D - 1] = rext[Y::ext_idx(L)];
+          if constexpr (EXT) t[D - 1] = L < RC ? rext[Y::ext_idx(L)] : crx;
           uint32_t wrun = word << (top - (D - 1));           // sign of edge 0 at bit 31; doubled per edge
           static_for<D>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
@@ -575,8 +642,13 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // sign: +-96 is built from the population count of the collected signs
           const double c96 = c96_of(uv, nsg);
           const double nm1 = a1 * c96, nm2 = a2 * c96;
-          m1[L] = nm1;
-          m2[L] = nm2;
+          if constexpr (L < RC) {
+            m1[L] = nm1;
+            m2[L] = nm2;
+          } else {
+            *wsL(wsb, ws_off(L, 0), zo8) = nm1;
+            *wsL(wsb, ws_off(L, 1), zo8) = nm2;
+          }
           PROBE_STAMP(WIDE ? 1 : 5);
           // ---- pass 2: r_j = t_j + msg_new_j = fma(u_j, first argmin ? pm2 : pm1, t_j), written back to the element it was
           // read from.  The FIRST entry equal to min1 gets min2 (np.argmin, ldpc.py:1558-1570).
@@ -594,7 +666,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
               else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
             } else {
-              rext[Y::ext_idx(L)] = t[j];
+              if constexpr (L < RC) rext[Y::ext_idx(L)] = t[j];
+              else *wsL(wsb, ws_off(L, 2), zo8) = t[j];
             }
           };
           if (__builtin_expect(!tie_quirk, 1)) {
@@ -732,8 +805,12 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
 
 __constant__ WrapTab kWrap1_384_r13 = make_wrap<1, zindex_c(384), 13>();
 __constant__ WrapTab kWrap1_384_r15 = make_wrap<1, zindex_c(384), 15>();
+__constant__ WrapTab kWrap1_384_r31 = make_wrap<1, zindex_c(384), 31>();
+__constant__ WrapTab kWrap1_384_r46 = make_wrap<1, zindex_c(384), 46>();
+// rows of the hybrid instantiations whose state stays in registers (RA - RC a multiple of the prefetch depth)
+constexpr int HYB_RC46 = NRX_DEC3_HYB_RC, HYB_RC31 = NRX_DEC3_HYB_RC - 1;
 
-struct DevTab { const uint64_t* p[2]; bool ok; };
+struct DevTab { const uint64_t* p[4]; bool ok; };
 
 // wrap-mask table of the instantiation that serves n_rows (13 or 15 rows), resolved per device
 int32_t wrap_table(int n_rows, const uint64_t** out) {
@@ -744,14 +821,15 @@ int32_t wrap_table(int n_rows, const uint64_t** out) {
   std::lock_guard<std::mutex> lock(mu);
   DevTab& dt = tabs[dev];
   if (!dt.ok) {
-    void* p[2] = {};
-    const hipError_t e[2] = {hipGetSymbolAddress(&p[0], HIP_SYMBOL(kWrap1_384_r13)), hipGetSymbolAddress(&p[1], HIP_SYMBOL(kWrap1_384_r15))};
-    for (int i = 0; i < 2; ++i)
+    void* p[4] = {};
+    const hipError_t e[4] = {hipGetSymbolAddress(&p[0], HIP_SYMBOL(kWrap1_384_r13)), hipGetSymbolAddress(&p[1], HIP_SYMBOL(kWrap1_384_r15)),
+                             hipGetSymbolAddress(&p[2], HIP_SYMBOL(kWrap1_384_r31)), hipGetSymbolAddress(&p[3], HIP_SYMBOL(kWrap1_384_r46))};
+    for (int i = 0; i < 4; ++i)
       NRX_REQUIRE(e[i] == hipSuccess && p[i], NRX_E_HIP, "nrx_ldpc_decode_f64: hipGetSymbolAddress(wrap masks) failed");
-    for (int i = 0; i < 2; ++i) dt.p[i] = (const uint64_t*)p[i];
+    for (int i = 0; i < 4; ++i) dt.p[i] = (const uint64_t*)p[i];
     dt.ok = true;
   }
-  *out = dt.p[n_rows <= 13 ? 0 : 1];
+  *out = dt.p[n_rows <= 13 ? 0 : (n_rows <= 15 ? 1 : (n_rows <= 31 ? 2 : 3))];
   return NRX_OK;
 }
 
@@ -766,8 +844,33 @@ bool chip64_covers(const nrx_ldpc_cfg* cfg, int n_rows, int max_rows = 15) {
 // Called by nrx_ldpc_decode_rows_f64 (nrx_ldpc_dec.hip) for hard decisions of the K information bits.
 // Returns 1 when no on-chip instantiation covers (bg, Zc, n_rows): the caller then runs the workspace kernel.
 int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                      int32_t n_rows, uint8_t* hard, hipStream_t st) {
+                                      int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes) {
   using namespace nrx_dec3;
+  if (chip64_covers(cfg, n_rows, 46) && n_rows > 15 && getenv("NRX_LDPC_NOHYBRID") == nullptr) {
+    // more rows than fit on chip: the hybrid -- the first 31 or all 46 rows of the graph run (the ones beyond n_rows as exact
+    // no-ops on zeroed extension LLRs), the state of the sparse rows streams through the caller's workspace
+    constexpr int ZI384 = zindex_c(384);
+    const int ra = n_rows <= 31 ? 31 : 46, rc_rows = n_rows <= 31 ? HYB_RC31 : HYB_RC46;
+    const size_t per_slot = sizeof(double) * (size_t)(ra - rc_rows) * 3 * 384;
+    const int n_wg = (n_cb + 1) / 2;
+    int grid = n_wg < 256 ? n_wg : 256;
+    if (ws == nullptr || ws_bytes < 2 * per_slot) return 1;          // no workspace: the workspace kernel reports it
+    if ((size_t)grid > ws_bytes / (2 * per_slot)) grid = (int)(ws_bytes / (2 * per_slot));
+    const uint64_t* wt = nullptr;
+    const int32_t rc = wrap_table(ra, &wt);
+    if (rc) return rc;
+    FuseArgs fa{};
+    fa.g.rows_live = n_rows;
+    fa.ws = (double*)ws;
+    if (ra == 31)
+      hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 31, false, 2, 0, HYB_RC31>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard,
+                         (mtab_t)wt, fa);
+    else
+      hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 46, false, 2, 0, HYB_RC46>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard,
+                         (mtab_t)wt, fa);
+    NRX_CHECK_LAUNCH("nrx_ldpc_decode_f64(hybrid)");
+    return NRX_OK;
+  }
   if (!chip64_covers(cfg, n_rows)) return 1;
   const uint64_t* wt = nullptr;
   const int32_t rc = wrap_table(n_rows, &wt);

@@ -474,3 +474,34 @@ def test_onchip_decoder_every_lifting_size(dev, bg):
         if zc <= 40 or zc in (88, 208):
             o = oc.decode(llr[:4], bg, ils, zc, num_iter=9, rows=rows)
             assert np.array_equal(o, got[:4].cpu().numpy()), (bg, zc, rows)
+
+
+@pytest.mark.parametrize("rows", [16, 31, 32, 46])
+def test_hybrid_decoder_for_more_than_15_rows(dev, rows):
+    """More than 15 rows at Zc = 384 (rates below ~0.6, HARQ retransmissions, all 46 rows): the hybrid instantiations of
+    nrx_ldpc_dec3.hip -- 31 or 46 rows of the graph, the sparse rows' check-node state streamed through the workspace -- give the
+    bits of the workspace kernel (NRX_LDPC_NOHYBRID, read at every call) on a ragged batch with filler LLRs and exact zeros,
+    and the oracle's bits."""
+    import os
+    import torch
+    from neoradium_amd import ops, _lib
+    from oracle import coding as oc
+    cfg = _lib.ldpc_config(1, 25000 + 24)
+    assert cfg.Zc == 384
+    rng = np.random.default_rng(500 + rows)
+    n_cb = 7
+    llr = 2 / 0.85 ** 2 + (2 / 0.85) * rng.standard_normal((n_cb, cfg.N))
+    llr[:, (22 + rows - 4) * 384 - 100:] = 0.0                 # nothing received beyond the rows that run
+    llr[rng.random(llr.shape) < 0.002] = 0.0
+    llr[:, 20 * 384 - 150:20 * 384] = 1e20                    # fillers at the end of the information columns
+    x = torch.from_numpy(llr).to(dev)
+    assert 'NRX_LDPC_NOHYBRID' not in os.environ
+    got = ops.ldpc_decode(x, cfg, 11, rows=rows)
+    os.environ['NRX_LDPC_NOHYBRID'] = '1'
+    try:
+        ref = ops.ldpc_decode(x, cfg, 11, rows=rows)
+    finally:
+        del os.environ['NRX_LDPC_NOHYBRID']
+    assert torch.equal(got, ref)
+    o = oc.decode(llr[:2], 1, 1, 384, num_iter=11, rows=rows)
+    assert np.array_equal(o, got[:2].cpu().numpy())
