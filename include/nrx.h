@@ -138,6 +138,14 @@ int32_t nrx_ldpc_decode_rows_f32(const float* llr, int32_t n_cb, const nrx_ldpc_
                                  uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream);
 int32_t nrx_ldpc_decode_rows_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
                                  uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream);
+/* ... of a selection of the code blocks: sel[0 .. *n_sel) index the n_cb rows of llr / hard_out, list and count on the DEVICE
+ * (the launch covers the worst case; nothing is read by the host, e.g. nrx_select_failed of a flag vector); the other rows of
+ * hard_out are left untouched.  NRX_E_UNSUPPORTED outside BG1 / Zc 384 (the kernels of nrx_ldpc_dec3.hip).  Used by the batched
+ * HARQ loop: new transport blocks (rv 0 alone in the buffer: <= 15 rows) and retransmissions (all rows) of one round in two
+ * launches over the same buffers. */
+int32_t nrx_ldpc_decode_rows_sel_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
+                                     uint8_t* hard_out, void* ws, size_t ws_bytes, const int32_t* sel, const int32_t* n_sel,
+                                     void* stream);
 
 /* ldpc.py:1330-1418 recoverRate (first transmission: rv 0, no HARQ soft buffer, no LBRM, no wrap-around repetition)
  * + ldpc.py:1495-1581 decode + ldpc.py:1584-1619 checkCrcAndMerge (C > 1: CRC24B per code block) in ONE launch (SURVEY 7

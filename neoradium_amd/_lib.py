@@ -105,6 +105,7 @@ SIGNATURES.update({
     'nrx_effective_channel_prg_f64': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_ldpc_decode_rows_f32': (i32, [vp, i32, _cfgp, i32, i32, vp, vp, u64, vp]),
     'nrx_ldpc_decode_rows_f64': (i32, [vp, i32, _cfgp, i32, i32, vp, vp, u64, vp]),
+    'nrx_ldpc_decode_rows_sel_f64': (i32, [vp, i32, _cfgp, i32, i32, vp, vp, u64, vp, vp, vp]),
     'nrx_polar_encode': (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     'nrx_polar_rate_match': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'nrx_polar_rate_recover_f64': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),

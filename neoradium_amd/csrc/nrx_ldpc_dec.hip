@@ -412,14 +412,16 @@ int32_t launch(const T* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int 
 int32_t nrx_ldpc_decode_fast_launch(const float* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
                                     int32_t n_rows, uint8_t* hard, hipStream_t st);  // nrx_ldpc_dec2.hip
 int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                      int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes);  // nrx_ldpc_dec3.hip
+                                      int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes,
+                                      const int32_t* sel, const int32_t* n_sel);  // nrx_ldpc_dec3.hip
 int32_t nrx_ldpc_decode_chipz_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
                                      int32_t n_rows, uint8_t* hard, hipStream_t st);   // nrx_ldpc_dec4.hip
 namespace {
 
 template <typename T, bool EXACT>
 int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t out_cols,
-                     uint8_t* hard, T* belief, void* ws, size_t ws_bytes, void* stream, int32_t n_rows = 0) {
+                     uint8_t* hard, T* belief, void* ws, size_t ws_bytes, void* stream, int32_t n_rows = 0,
+                     const int32_t* sel = nullptr, const int32_t* n_sel = nullptr) {
   NRX_REQUIRE(llr && cfg, NRX_E_ARG, "nrx_ldpc_decode: NULL llr/cfg");
   NRX_REQUIRE(hard || belief, NRX_E_ARG, "nrx_ldpc_decode: need hard_out or belief_out");
   NRX_REQUIRE(cfg->bg == 1 || cfg->bg == 2, NRX_E_ARG, "nrx_ldpc_decode: bg must be 1|2");
@@ -445,9 +447,14 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
   if constexpr (EXACT) {
     // float64, hard decisions of the information bits, few enough rows: the whole working set fits on chip
     if (hard && !belief && out_cols == cfg->K) {
-      const int32_t rc = nrx_ldpc_decode_chip64_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream, ws, ws_bytes);
+      const int32_t rc = nrx_ldpc_decode_chip64_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream, ws, ws_bytes,
+                                                       sel, n_sel);
       if (rc != 1) return rc;      // 1 = no Zc = 384 instantiation for this (bg, Zc, rows)
     }
+  }
+  if (sel) {
+    ::nrx::set_error("nrx_ldpc_decode_rows_sel: selections are built for the float64 Zc = 384 kernels of nrx_ldpc_dec3.hip");
+    return NRX_E_UNSUPPORTED;
   }
   int zi = -1;
   for (int i = 0; i < 51; ++i)
@@ -498,4 +505,13 @@ extern "C" int32_t nrx_ldpc_decode_rows_f64(const double* llr, int32_t n_cb, con
                                             int32_t n_rows, uint8_t* hard_out, void* ws, size_t ws_bytes, void* stream) {
   NRX_REQUIRE(cfg, NRX_E_ARG, "nrx_ldpc_decode_rows: NULL cfg");
   return decode_entry<double, true>(llr, n_cb, cfg, n_iter, cfg->K, hard_out, nullptr, ws, ws_bytes, stream, n_rows);
+}
+
+// ... of a selection of the code blocks: sel[0 .. *n_sel) index the n_cb rows of llr / hard_out, list and count on the device
+// (the launch covers the worst case, nothing is read by the host); the other rows of hard_out are left untouched.
+extern "C" int32_t nrx_ldpc_decode_rows_sel_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
+                                                int32_t n_rows, uint8_t* hard_out, void* ws, size_t ws_bytes, const int32_t* sel,
+                                                const int32_t* n_sel, void* stream) {
+  NRX_REQUIRE(cfg && sel && n_sel, NRX_E_ARG, "nrx_ldpc_decode_rows_sel: NULL cfg / selection");
+  return decode_entry<double, true>(llr, n_cb, cfg, n_iter, cfg->K, hard_out, nullptr, ws, ws_bytes, stream, n_rows, sel, n_sel);
 }

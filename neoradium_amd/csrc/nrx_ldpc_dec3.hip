@@ -362,7 +362,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   uint32_t pk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0, pk_rounds = 0;
 #endif
   const int32_t* sel = nullptr;
-  if constexpr (FUSED) {
+  {
     const fargs_t fa0 = fuse_args();
     sel = fa0->sel;
     if (sel) n_cb = *fa0->n_sel;                            // (wave-uniform; a workgroup beyond the count leaves at once)
@@ -374,7 +374,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     asm volatile("" : "+s"(one));                          // keeps the per-layer `if (live)` a real branch (see dec2)
     const bool live = cbi < n_cb && one != 0;
     const int cbl = live ? cbi : n_cb - 1;                  // (a wave without a code block loads an existing one)
-    const int cbq = (FUSED && sel) ? sel[cbl] : cbl;        // the code block itself
+    const int cbq = sel ? sel[cbl] : cbl;                   // the code block itself
     const int cb = cbq;
     const double* in = FUSED ? llr : llr + (size_t)cbq * N;
     int fE = 0, foff = 0;                                  // FUSED: E_r and the offset of the block in the LLR stream
@@ -844,7 +844,8 @@ bool chip64_covers(const nrx_ldpc_cfg* cfg, int n_rows, int max_rows = 15) {
 // Called by nrx_ldpc_decode_rows_f64 (nrx_ldpc_dec.hip) for hard decisions of the K information bits.
 // Returns 1 when no on-chip instantiation covers (bg, Zc, n_rows): the caller then runs the workspace kernel.
 int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                      int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes) {
+                                      int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes,
+                                      const int32_t* sel, const int32_t* n_sel) {
   using namespace nrx_dec3;
   if (chip64_covers(cfg, n_rows, 46) && n_rows > 15 && getenv("NRX_LDPC_NOHYBRID") == nullptr) {
     // more rows than fit on chip: the hybrid -- the first 31 or all 46 rows of the graph run (the ones beyond n_rows as exact
@@ -862,6 +863,8 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
     FuseArgs fa{};
     fa.g.rows_live = n_rows;
     fa.ws = (double*)ws;
+    fa.sel = sel;
+    fa.n_sel = n_sel;
     if (ra == 31)
       hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 31, false, 2, 0, HYB_RC31>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard,
                          (mtab_t)wt, fa);
@@ -878,6 +881,8 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
   constexpr int ZI384 = zindex_c(384);
   FuseArgs fa{};
   fa.g.rows_live = n_rows;
+  fa.sel = sel;
+  fa.n_sel = n_sel;
   const int n_wg = (n_cb + 1) / 2;
   const int grid = n_wg < 1024 ? n_wg : 1024;
   if (n_rows <= 13)

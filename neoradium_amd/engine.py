@@ -304,6 +304,33 @@ class PdschLink:
                 det.append((sel, d))
         return (counters, det) if details else counters
 
+    def _harq_decode(self, rr, ccfg, rows_new, new_flags):
+        """Hard bits of one HARQ round's code blocks: processes that start a new transport block decode with the rows rv 0
+        reaches (exact no-ops beyond), retransmissions with all rows.  Where the kernels take a work list (float64, Zc 384)
+        the two groups are listed on the device and each is one launch over the whole batch -- no host read, no gathered
+        copies of the LLRs; elsewhere one small host read (n_proc flags) splits the batch."""
+        C = ccfg.C
+        if rr.dtype == torch.float64:
+            dec = torch.empty((rr.shape[0], ccfg.K), dtype=torch.uint8, device=rr.device)
+            is_new = new_flags.to(torch.uint8).reshape(-1, 1).expand(-1, C).reshape(-1).contiguous()
+            s_re, n_re = ops.select_zero(is_new)                              # retransmissions
+            s_nw, n_nw = ops.select_zero(1 - is_new)                          # new blocks
+            if ops.ldpc_decode_selected(rr, ccfg, self.numIter, 46 if ccfg.bg == 1 else 42, s_re, n_re, dec) and \
+                    ops.ldpc_decode_selected(rr, ccfg, self.numIter, rows_new, s_nw, n_nw, dec):
+                return dec
+        fresh = new_flags.to(torch.bool).cpu()
+        cbs = torch.arange(rr.shape[0], device=rr.device).reshape(-1, C)
+        dec = None
+        for idx, rws in ((cbs[fresh].reshape(-1), rows_new), (cbs[~fresh].reshape(-1), None)):
+            if idx.numel() == 0:
+                continue
+            part = ops.ldpc_decode(rr if idx.numel() == rr.shape[0] else rr.index_select(0, idx), ccfg, self.numIter, rows=rws)
+            if idx.numel() == rr.shape[0]:
+                return part
+            dec = torch.empty((rr.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device) if dec is None else dec
+            dec.index_copy_(0, idx, part)
+        return dec
+
     def _channel_chain(self, slots, n, slots_dev):
         """Path gains, timing offset, channel matrix (where the link needs it), precoder(s) and -- time-domain link with a
         wideband precoder -- the gains with the precoder folded in, of the slots of one batch."""
@@ -450,21 +477,7 @@ class PdschLink:
                 # ... of the retransmissions.  A process that starts a new block holds rv 0 alone in a fresh buffer, which is
                 # the single-shot case: the rows whose parity is punctured are exact no-ops there as well, and the truncated
                 # graph has the on-chip float64 instantiation.  One small host read per round (n_proc flags) splits the batch.
-                fresh = harq[q][2].to(torch.bool).cpu()
-                cbs = torch.arange(rr.shape[0], device=rr.device).reshape(-1, ccfg.C)
-                i_new, i_re = cbs[fresh].reshape(-1), cbs[~fresh].reshape(-1)
-                dec = None
-                for idx, rws in ((i_new, cw['rows']), (i_re, None)):
-                    if idx.numel() == 0:
-                        continue
-                    part = ops.ldpc_decode(rr if idx.numel() == rr.shape[0] else rr.index_select(0, idx), ccfg, self.numIter,
-                                           rows=rws)
-                    if idx.numel() == rr.shape[0]:
-                        dec = part
-                    else:
-                        dec = torch.empty((rr.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device) \
-                            if dec is None else dec
-                        dec.index_copy_(0, idx, part)
+                dec = self._harq_decode(rr, ccfg, cw['rows'], harq[q][2])
                 tb_out, cb_ok, _ = ops.ldpc_crc_merge(dec, ccfg, want_tb_crc=False)
             elif self.firstPassIter is None:
                 dec = ops.ldpc_decode(rr, ccfg, self.numIter, rows=rows)

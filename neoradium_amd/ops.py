@@ -196,6 +196,35 @@ def ldpc_decode(llr, cfg, n_iter=5, only_info=True, belief=False, rows=None):
     return bel if belief else hard
 
 
+def select_zero(flags):
+    """Indices of the zero entries of a uint8 flag vector, ascending, and their number: (sel int32 (n,), n_sel int32 (1,)), both
+    on the device (nrx_select_failed): the work list of the *_sel entries, never read by the host."""
+    flags = _u8(flags).reshape(-1)
+    n = flags.numel()
+    dev = _dev(flags)
+    sel = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    n_sel = torch.empty(1, dtype=torch.int32, device=dev)
+    check(lib().nrx_select_failed(ptr(flags), n, ptr(sel), ptr(n_sel), stream()))
+    return sel, n_sel
+
+
+def ldpc_decode_selected(llr, cfg, n_iter, rows, sel, n_sel, out):
+    """ldpc_decode(rows=...) of the code blocks sel[0 .. n_sel) only (device list, device count), hard bits written into the
+    matching rows of ``out`` (n_cb, K) uint8.  False when this configuration has no selection-capable kernel (float64,
+    BG1, Zc 384): the caller then gathers and decodes the rows itself."""
+    if llr.dtype != torch.float64 or not (cfg.bg == 1 and cfg.Zc == 384):
+        return False
+    llr = llr.contiguous()
+    n_cb = llr.shape[0]
+    ws = _decode_ws(cfg, _dev(llr))
+    rc = lib().nrx_ldpc_decode_rows_sel_f64(ptr(llr), n_cb, C.byref(cfg), int(n_iter), int(rows), ptr(out), ptr(ws), ws.numel(),
+                                            ptr(sel), ptr(n_sel), stream())
+    if rc == -3:
+        return False
+    check(rc)
+    return True
+
+
 def ldpc_recover_decode_merge(llr, cfg, nl, qm, n_iter, rows=0):
     """recoverRate (first transmission) + decode + checkCrcAndMerge in one launch (nrx_ldpc_recover_decode_merge_f64):
     (n_tb, G) float64 LLRs in the per-code-block de-interleaved layout of ``qam_demap(code_blocks=(C, nl))`` ->
