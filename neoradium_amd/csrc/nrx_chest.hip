@@ -140,6 +140,52 @@ chest_ls_kernel(const cx<T>* __restrict__ rx, const cx<T>* __restrict__ pilots, 
 }
 
 
+// The estimate at the DMRS time groups for the fused estimate + equalise path (chest_ls_kernel<double, false, true> with
+// hk_only): one lane per (item, subcarrier, port) walks the receive antennas, so the segment search and the two centres -- which
+// depend on (subcarrier, port) only -- are done once instead of once per antenna (the kernel is bound by its instruction count:
+// ~700 per lane in the general form).  Same expressions in the same order: the same bits.
+__global__ void __launch_bounds__(256)
+chest_ls_hk_kernel(const int32_t* __restrict__ port_ks, ChestGeom g, cd* __restrict__ hk, int n_batch, const double* __restrict__ pol) {
+  const int n_j = g.n_k / g.k_cdm, n_g = g.n_ds / g.l_cdm;
+  const uint32_t per_b = (uint32_t)g.K * (uint32_t)g.P;
+  const uint32_t total = (uint32_t)n_batch * per_b;
+  const int64_t per = (int64_t)g.K * g.nr * g.P;
+  for (uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += gridDim.x * blockDim.x) {
+    const int b = (int)(gi / per_b);
+    const uint32_t e0 = gi - (uint32_t)b * per_b;
+    const int k = (int)(e0 / (uint32_t)g.P), p = (int)(e0 - (uint32_t)k * (uint32_t)g.P);
+    const int32_t* ks = port_ks + (size_t)p * g.n_k;
+    auto centre = [&](int j) {  // mean subcarrier index of CDM group j (grid.py:795-796)
+      double s = 0;
+      for (int q = 0; q < g.k_cdm; ++q) s += (double)ks[j * g.k_cdm + q];
+      return s / (double)g.k_cdm;
+    };
+    int j = 1;
+    if (n_j > 1) {
+      const double c0 = centre(0), cN = centre(n_j - 1);
+      int lo = cN > c0 ? (int)(((double)k - c0) / (cN - c0) * (double)(n_j - 1)) : 0;
+      lo = lo < 0 ? 0 : (lo > n_j - 1 ? n_j - 1 : lo);
+      while (lo < n_j && centre(lo) < (double)k) ++lo;
+      while (lo > 0 && centre(lo - 1) >= (double)k) --lo;
+      j = lo < 1 ? 1 : (lo > n_j - 1 ? n_j - 1 : lo);
+    }
+    const double x0 = n_j > 1 ? centre(j - 1) : 0.0, x1 = n_j > 1 ? centre(j) : 1.0;
+    for (int tg = 0; tg < n_g; ++tg)
+      for (int r = 0; r < g.nr; ++r) {
+        const double* q = pol + ((((size_t)b * n_g + tg) * g.nr + r) * g.P + p) * (size_t)n_j * 2;
+        cd v;
+        if (n_j == 1) {
+          v = cd(q[0], q[1]);
+        } else {
+          const cd y0(q[2 * (j - 1)], q[2 * (j - 1) + 1]), y1(q[2 * j], q[2 * j + 1]);
+          const cd sl((y1.re - y0.re) / (x1 - x0), (y1.im - y0.im) / (x1 - x0));
+          v = cd(sl.re * ((double)k - x0) + y0.re, sl.im * ((double)k - x0) + y0.im);
+        }
+        hk[((size_t)b * n_g + tg) * per + ((size_t)k * g.nr + r) * g.P + p] = v;
+      }
+  }
+}
+
 // ---- polar interpolation, step 1 (utils.py:39): angle and magnitude of every CDM-group estimate.
 // pol[row][j] = (atan2(im, re), hypot(re, im)), row = ((b*n_g + tg)*nr + r)*P + p.  POLAR = false leaves (re, im) in the
 // same layout: the CDM-group means themselves, input of the tap-table interpolators (nrx_interp_taps_f64).
@@ -443,9 +489,13 @@ static int32_t chest_ls_mmse_impl(const void* rx, const void* pilots, const int3
   if (nr == NR && P == NL) {                                                                                             \
     hipLaunchKernelGGL(chest_polar_prep_kernel<false>, dim3(nrx::stream_grid(mrows * n_j, 256)), dim3(256), 0, st,        \
                        (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, means, n_batch);                           \
-    hipLaunchKernelGGL((chest_ls_kernel<double, false, true>), dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)),  \
-                       dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (cd*)hk_ws, n_batch, 1,  \
-                       (cd*)nullptr, (const double*)means);                                                             \
+    if ((int64_t)n_batch * K * P < (1ll << 31))                                                                          \
+      hipLaunchKernelGGL(chest_ls_hk_kernel, dim3(nrx::stream_grid((long)n_batch * K * P, 256)), dim3(256), 0, st, port_ks, g, \
+                         (cd*)hk_ws, n_batch, (const double*)means);                                                    \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((chest_ls_kernel<double, false, true>), dim3(nrx::stream_grid((long)n_batch * K * nr * P, 256)), \
+                         dim3(256), 0, st, (const cd*)rx, (const cd*)pilots, pil_set, port_ks, g, (cd*)hk_ws, n_batch, 1, \
+                         (cd*)nullptr, (const double*)means);                                                           \
     hipLaunchKernelGGL((mmse_interp_kernel<NR, NL>), grid2, dim3(128), 0, st, (const cd*)rx, (const cd*)hk_ws, g,        \
                        noise_var, nv_stride, (cd*)eq, scale, n_batch, sym_mask);                                         \
     NRX_CHECK_LAUNCH("nrx_chest_ls_mmse");                                                                               \
