@@ -427,6 +427,20 @@ int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_t n_tx, int
                                int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
                                const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens, void* y,
                                void* stream);
+/* ... and, from the same pass, the power sums of y over its CP-stripped samples (Waveform.getRePower, waveform.py:107-117: the
+ * nfft samples of every symbol from round(cpLen/2) on, all Nr rows): pow_acc (n_items, *n_part, 3) float64 = (sum re, sum im,
+ * sum |y|^2) per wave, no atomics; pow_capacity = doubles available.  The last of the n_sets spans is the tail beyond the
+ * slot and carries no symbol.  nrx_noise_level_finish_f64 turns the sums into the variance / sigma / noise variance of
+ * nrx_noise_level_f64 with count = Nr * (n_sets-1) * nfft.  NRX_E_UNSUPPORTED when the geometry has no register-tiled
+ * instantiation (filter length != 16 or Nr > 4): call nrx_apply_td_paths_f64 and nrx_noise_level_f64 then. */
+int32_t nrx_apply_td_paths_pow_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                                   int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
+                                   const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
+                                   void* y, int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part,
+                                   void* stream);
+int32_t nrx_noise_level_finish_f64(const double* acc, int32_t n_part, int64_t count, int32_t n_batch, void* var_out,
+                                   const double* snr_lin, int32_t snr_stride, double mult, void* sigma_out, void* nv_out,
+                                   double nv_mult, void* stream);
 
 /* grid.py:505-516 Grid.precode with ONE precoder for all subcarriers, moved behind the modulator: out
  * (n_items,n_sets,n_rx,n_layers,n_paths) = sum_t gains1[.,.,r,t,p] * F[.,t,l] (F: (n_tx,n_layers) complex128 per item,

@@ -314,10 +314,11 @@ template <int NR>
 __global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS, 4)   // four waves per SIMD (two workgroups per CU): <= 128 VGPRs
 apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ gains1, int n_paths,
                        const double* __restrict__ taps, const int32_t* __restrict__ tap_off, int hist, TdGeom g,
-                       cd* __restrict__ y) {
+                       cd* __restrict__ y, double* __restrict__ pow_acc, int pow_nfft) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* xs = (cd*)smem;  // [nt][R][Q]
   constexpr int R = TDP_R;
+  constexpr int PW = TDP_TILE / 64;      // waves of antenna group 0 = power-sum partials per workgroup
 #ifdef NRX_TD_CLOCK_PROBE
   unsigned long long pt0, pr0;
   asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(pt0), "=s"(pr0)::"memory");
@@ -326,7 +327,10 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
   const int set = blockIdx.x / g.tiles_per_set, tile = blockIdx.x % g.tiles_per_set;
   const int n0 = g.start[set] + tile * (TDP_TILE * R);
   const int n_end = g.start[set + 1];
-  if (n0 >= n_end) return;
+  if (n0 >= n_end) {
+    if (pow_acc && threadIdx.x < 3 * PW) pow_acc[((size_t)b * gridDim.x + blockIdx.x) * 3 * PW + threadIdx.x] = 0.0;
+    return;
+  }
   const int span = TDP_TILE * R + hist;   // hist is a multiple of R (host)
   const int Q = span / R;
   for (int i = threadIdx.x; i < nt * span; i += blockDim.x) {
@@ -392,6 +396,39 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
 #pragma unroll
       for (int j = 0; j < R; ++j)
         if (n + j < n_end) y[((size_t)b * NR + r) * ns + n + j] = cd(ar[r][j], ai[r][j]);
+  }
+  // Power sums of the received signal over the CP-stripped samples (Waveform.getRePower, waveform.py:107-117: the nfft samples
+  // of every symbol from half its cyclic prefix on; np.var needs sum x and sum |x|^2) while the samples are in registers: one
+  // (sum re, sum im, sum |x|^2) triple per WAVE of antenna group 0 -- no barrier, no atomics -- into pow_acc[item][workgroup]
+  // [wave][3], summed in that order by var_finish_kernel (reproducible).  Saves the separate pass over the waveform.
+  if (pow_acc && grp == 0) {
+    double sr = 0, si = 0, s2 = 0;
+    if (n < n_end && set < g.n_sets - 1) {                  // (the last gain set is the tail beyond the slot: no symbol)
+      const int s0 = g.start[set];
+      const int off = (int)rint((double)(n_end - s0 - pow_nfft) * 0.5);      // np.round(cpLen * 0.5)
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int pos = n + j - s0;
+          if (n + j < n_end && pos >= off && pos < off + pow_nfft) {
+            sr += ar[r][j];
+            si += ai[r][j];
+            s2 += ar[r][j] * ar[r][j] + ai[r][j] * ai[r][j];
+          }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      sr += __shfl_xor(sr, o, 64);
+      si += __shfl_xor(si, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      double* o3 = pow_acc + (((size_t)b * gridDim.x + blockIdx.x) * PW + (threadIdx.x >> 6)) * 3;
+      o3[0] = sr;
+      o3[1] = si;
+      o3[2] = s2;
+    }
   }
 #ifdef NRX_TD_CLOCK_PROBE
   unsigned long long pt1, pr1;
@@ -1075,10 +1112,10 @@ static int32_t td_geom(const int32_t* set_lens, int32_t n_sets, int64_t ns, TdGe
   return NRX_OK;
 }
 
-extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
-                                          int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
-                                          const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
-                                          void* y, void* stream) {
+static int32_t apply_td_paths_impl(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                                   int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
+                                   const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
+                                   void* y, void* stream, double* pow_acc, int32_t pow_nfft, int64_t pow_capacity, int32_t* n_part) {
   NRX_REQUIRE(x && gains1 && taps && tap_off && set_lens && y, NRX_E_ARG, "nrx_apply_td_paths: NULL buffer");
   NRX_REQUIRE(n_sets >= 1 && n_sets <= 16 && n_tx >= 1 && n_paths >= 1 && flen >= 1 && hist >= 0 && ns > 0 && n_items >= 0,
               NRX_E_ARG, "nrx_apply_td_paths: bad sizes");
@@ -1100,11 +1137,16 @@ extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_
       g4.tiles_per_set = (maxlen + TDP_TILE * TDP_R - 1) / (TDP_TILE * TDP_R);
       if (g4.tiles_per_set < 1) g4.tiles_per_set = 1;
       const dim3 grid4(g4.tiles_per_set * n_sets, n_items);
+      if (pow_acc) {
+        const int64_t need = (int64_t)n_items * grid4.x * (TDP_TILE / 64) * 3;
+        NRX_REQUIRE(pow_capacity >= need, NRX_E_SHAPE, "nrx_apply_td_paths_pow: pow_acc needs %lld doubles", (long long)need);
+        *n_part = (int32_t)(grid4.x * (TDP_TILE / 64));
+      }
 #define NRX_TDP4_CASE(NR)                                                                                                  \
   case NR:                                                                                                                 \
     (void)hipFuncSetAttribute((const void*)apply_td_paths4_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
     hipLaunchKernelGGL(apply_td_paths4_kernel<NR>, grid4, dim3(TDP_TILE * TDP_GROUPS), lds4, st, (const cd*)x, n_tx, ns,  \
-                       (const cd*)gains1, n_paths, taps, tap_off, hist4, g4, (cd*)y);                                      \
+                       (const cd*)gains1, n_paths, taps, tap_off, hist4, g4, (cd*)y, pow_acc, pow_nfft);                   \
     break;
       switch (n_rx) {
         NRX_TDP4_CASE(1)
@@ -1115,6 +1157,10 @@ extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_
       NRX_CHECK_LAUNCH("nrx_apply_td_paths");
       return NRX_OK;
     }
+  }
+  if (pow_acc) {
+    ::nrx::set_error("nrx_apply_td_paths_pow: power sums come with the register-tiled kernel only (16-tap filters, Nr <= 4)");
+    return NRX_E_UNSUPPORTED;       // the caller runs nrx_apply_td_paths_f64 + nrx_noise_level_f64
   }
   const size_t lds = sizeof(cd) * (size_t)n_tx * (TD_TILE + hist);
   NRX_REQUIRE(lds <= 160 * 1024, NRX_E_UNSUPPORTED, "nrx_apply_td_paths: Nt*delay too large for LDS staging (%zu B)", lds);
@@ -1134,6 +1180,28 @@ extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_
 #undef NRX_TDP_CASE
   NRX_CHECK_LAUNCH("nrx_apply_td_paths");
   return NRX_OK;
+}
+
+extern "C" int32_t nrx_apply_td_paths_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                                          int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
+                                          const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
+                                          void* y, void* stream) {
+  return apply_td_paths_impl(x, n_items, n_tx, ns, gains1, n_sets, n_rx, n_paths, taps, tap_off, flen, hist, set_lens, y, stream,
+                             nullptr, 0, 0, nullptr);
+}
+
+// ... and the power sums of its output over the CP-stripped samples (see the kernel): pow_acc (n_items, *n_part, 3) float64,
+// to be finished by nrx_noise_level_finish_f64.  NRX_E_UNSUPPORTED when the geometry has no register-tiled instantiation.
+extern "C" int32_t nrx_apply_td_paths_pow_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                                              int32_t n_sets, int32_t n_rx, int32_t n_paths, const double* taps,
+                                              const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
+                                              void* y, int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part,
+                                              void* stream) {
+  NRX_REQUIRE(pow_acc && n_part && nfft > 0, NRX_E_ARG, "nrx_apply_td_paths_pow: NULL pow_acc / n_part");
+  for (int i = 0; i + 1 < n_sets; ++i)
+    NRX_REQUIRE(set_lens && set_lens[i] > nfft, NRX_E_ARG, "nrx_apply_td_paths_pow: a symbol (%d samples) is not longer than nfft", set_lens[i]);
+  return apply_td_paths_impl(x, n_items, n_tx, ns, gains1, n_sets, n_rx, n_paths, taps, tap_off, flen, hist, set_lens, y, stream,
+                             pow_acc, nfft, pow_capacity, n_part);
 }
 
 extern "C" int32_t nrx_fold_precoder_f64(const void* gains, const void* F, int64_t f_stride, int32_t n_items, int32_t n_sets,

@@ -284,6 +284,36 @@ __global__ void var_finish_kernel(const double* __restrict__ acc, int n_part, do
   }
 }
 
+// The same with one wave per item for many partials (lane l sums partials l, l+64, ...; then a fixed shuffle tree: reproducible).
+__global__ void __launch_bounds__(64)
+var_finish_wave_kernel(const double* __restrict__ acc, int n_part, double n, double* __restrict__ var_out,
+                       const double* __restrict__ snr_lin, int snr_stride, double mult, double* __restrict__ sigma_out,
+                       double* __restrict__ nv_out, double nv_mult) {
+  const int b = blockIdx.x;
+  double sr = 0, si = 0, s2 = 0;
+  for (int k = threadIdx.x; k < n_part; k += 64) {
+    const double* p = acc + ((size_t)b * n_part + k) * 3;
+    sr += p[0];
+    si += p[1];
+    s2 += p[2];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sr += __shfl_xor(sr, o, 64);
+    si += __shfl_xor(si, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (threadIdx.x) return;
+  const double mr = sr / n, mi = si / n;
+  double var = s2 / n - (mr * mr + mi * mi);
+  if (var < 0) var = 0;
+  if (var_out) var_out[b] = var;
+  if (snr_lin) {
+    const double sg = sqrt(var * mult / snr_lin[(size_t)b * snr_stride]);
+    if (sigma_out) sigma_out[b] = sg;
+    if (nv_out) nv_out[b] = sg * sg * nv_mult;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- noise
 // out = x + (sigma[b]/sqrt(2)) * z   with z = standard-normal pairs supplied by the caller (host PCG64 stream
 // in parity mode: random.py:203 awgn = normal(0, sigma/sqrt(2), shape+(2,))).
@@ -448,6 +478,18 @@ static int32_t noise_level_entry(const void* x, int64_t n_per, int64_t x_stride,
   hipLaunchKernelGGL(var_finish_kernel<T>, dim3((n_batch + 63) / 64), dim3(64), 0, st, acc_ws, gx, (double)n, n_batch,
                      (T*)var_out, snr_lin, snr_stride, mult, (T*)sigma_out, (T*)nv_out, nv_mult);
   NRX_CHECK_LAUNCH("nrx_noise_level");
+  return NRX_OK;
+}
+// The second half of nrx_noise_level_f64 on partial sums that another kernel left (nrx_apply_td_paths_pow_f64): acc (n_batch,
+// n_part, 3) = (sum re, sum im, sum |x|^2) over `count` samples per item.
+extern "C" int32_t nrx_noise_level_finish_f64(const double* acc, int32_t n_part, int64_t count, int32_t n_batch, void* var_out,
+                                              const double* snr_lin, int32_t snr_stride, double mult, void* sigma_out, void* nv_out,
+                                              double nv_mult, void* stream) {
+  NRX_REQUIRE(acc && n_part >= 1 && count > 0 && n_batch >= 0, NRX_E_ARG, "nrx_noise_level_finish: bad argument");
+  if (n_batch == 0) return NRX_OK;
+  hipLaunchKernelGGL(var_finish_wave_kernel, dim3(n_batch), dim3(64), 0, (hipStream_t)stream, acc, n_part, (double)count,
+                     (double*)var_out, snr_lin, snr_stride, mult, (double*)sigma_out, (double*)nv_out, nv_mult);
+  NRX_CHECK_LAUNCH("nrx_noise_level_finish");
   return NRX_OK;
 }
 extern "C" int32_t nrx_noise_level_f32(const void* x, int64_t n_per, int64_t x_stride, const int32_t* gather, int64_t n_gather, int32_t n_batch, double* acc_ws, void* var_out, const double* snr_lin, int32_t snr_stride, double mult, void* sigma_out, void* nv_out, double nv_mult, void* stream) { return noise_level_entry<float>(x, n_per, x_stride, gather, n_gather, n_batch, acc_ws, var_out, snr_lin, snr_stride, mult, sigma_out, nv_out, nv_mult, stream); }

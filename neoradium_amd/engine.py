@@ -16,6 +16,7 @@ everything that depends only on (configuration, slot number in frame) is precomp
 Slots are independent given their absolute slot index (channel time, DMRS/scrambling by slotNoInFrame), so a
 sweep shards over GPUs by slot range with no data-path communication; only the 4 error counters are reduced.
 """
+import os
 import numpy as np
 import torch
 
@@ -222,6 +223,7 @@ class PdschLink:
         self.slot_len = [int(v[:-1].sum()) for v in self.sym_lens]
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
+        self._sep_power = bool(int(os.environ.get('NRX_SEPARATE_POWER', '0')))     # developer switch: noise level in its own pass
         # gain instants on the device (no host -> device copy per batch: such a copy from pageable memory waits for the
         # stream to drain, i.e. for the previous batch's decoder, and the GPU then idles while the host prepares the next one)
         spsf = bwp.slotsPerSubFrame
@@ -419,11 +421,17 @@ class PdschLink:
             cps = [int(v) for v in (self.sym_lens[sis][:-1] - self.nfft)]
             w = Waveform.windowLength(cps, self.window, self.bwp)
             tx = ops.ofdm_modulate(grid, self.nfft, cps, window_len=w, pad=self.max_delay)      # layers (wideband) | ports (PRG)
-            ry = ops.apply_td_paths(tx, gains1 if self.prg else gfold, self.taps, self.tap_off,
-                                    [int(v) for v in self.sym_lens[sis]], hist=self.td_hist)
-            width = ry.shape[-1]
-            _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=self.nfft / (12.0 * self.bwp.numRbs),
-                                           nv_mult=float(self.nfft), gather=self._cp_gather(sis, width))
+            lens = [int(v) for v in self.sym_lens[sis]]
+            mult = self.nfft / (12.0 * self.bwp.numRbs)
+            # the filter leaves the power sums of its output (getRePower) where its kernel supports that ...
+            got = None if self._sep_power else ops.apply_td_paths(tx, gains1 if self.prg else gfold, self.taps, self.tap_off, lens,
+                                                                  hist=self.td_hist, power=(self.nfft, snr_lin, mult, float(self.nfft)))
+            if got is not None:
+                ry, sigma, nv = got
+            else:           # ... else a second pass over the waveform
+                ry = ops.apply_td_paths(tx, gains1 if self.prg else gfold, self.taps, self.tap_off, lens, hist=self.td_hist)
+                _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=mult, nv_mult=float(self.nfft),
+                                               gather=self._cp_gather(sis, ry.shape[-1]))
             if noise is not None:
                 rxg = ops.ofdm_demodulate(ops.add_noise(ry, noise.to(dev), sigma), self.nfft, cps, self.K, t_off=off)
             else:       # the noise is generated while the demodulator loads its samples (= ops.awgn, then demodulate)

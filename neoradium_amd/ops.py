@@ -1033,7 +1033,7 @@ def path_taps(coeff, filter_len=16):
     return taps, offs
 
 
-def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None):
+def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None, power=None):
     """ChannelModel.applyToSignal, path form: x (n,Nt,ns), gains1 (n,nc+1,Nr,Nt,P), taps (P,flen), tap_off (P) -> (n,Nr,ns)."""
     x = x.to(torch.complex128).contiguous()
     gains1 = gains1.to(torch.complex128).contiguous()
@@ -1053,6 +1053,26 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None):
     elif host_off is not None and (host_off.min() < 0 or hist < int(host_off.max()) + flen - 1):
         raise ValueError("hist must cover the longest path: max(tap_off) + flen - 1")
     y = torch.empty((n, nr, ns), dtype=torch.complex128, device=dev)
+    if power is not None:
+        # ... and the noise level of the output over its CP-stripped samples from the same pass (Waveform.getRePower,
+        # waveform.py:107-117, then grid.py:1040-1046): power = (nfft, snr_lin, mult, nv_mult) -> (y, sigma, nv).
+        nfft, snr_lin, mult, nv_mult = power
+        cap = 3 * n * (-(-max(int(v) for v in set_lens) // 512) + 1) * len(set_lens) * 4
+        acc = torch.empty(cap, dtype=torch.float64, device=dev)
+        n_part = C.c_int32(0)
+        rc = lib().nrx_apply_td_paths_pow_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off),
+                                              flen, hist, _host_i32(set_lens), ptr(y), int(nfft), ptr(acc), cap,
+                                              C.byref(n_part), stream())
+        if rc == -3:                 # NRX_E_UNSUPPORTED: no register-tiled instantiation; the caller takes the two entries
+            return None
+        check(rc)
+        snr = torch.as_tensor(snr_lin, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+        sigma = torch.empty(n, dtype=torch.float64, device=dev)
+        nv = torch.empty(n, dtype=torch.float64, device=dev)
+        check(lib().nrx_noise_level_finish_f64(ptr(acc), n_part.value, nr * (len(set_lens) - 1) * int(nfft), n, None, ptr(snr),
+                                               0 if snr.numel() == 1 else 1, float(mult), ptr(sigma), ptr(nv), float(nv_mult),
+                                               stream()))
+        return y, sigma, nv
     check(lib().nrx_apply_td_paths_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen,
                                        hist, _host_i32(set_lens), ptr(y), stream()))
     return y

@@ -254,6 +254,23 @@ def test_tdl_chain(dev):
     for b in range(n):
         ref_y = op.apply_td(x[b], ref_g[b], coeff, cps + nfft)
         assert rel(y[b], ref_y) < 1e-11 and rel(y2[b], ref_y) < 1e-11
+    # the filter that also leaves the noise level of its output over the CP-stripped samples (nrx_apply_td_paths_pow_f64 +
+    # nrx_noise_level_finish_f64) against the separate pass (nrx_noise_level_f64 with the gather table) and against NumPy
+    # (Waveform.getRePower, waveform.py:107-117; grid.py:1040-1046)
+    snr = np.array([3.0, 40.0])
+    got = ops.apply_td_paths(T(x, dev), gains, T(taps, dev), offs, list(cps + nfft), power=(nfft, snr, nfft / (12.0 * 25), float(nfft)))
+    assert got is not None, "16-tap filter, Nr = 2: the register-tiled kernel applies"
+    y5, sg5, nv5 = got
+    assert np.array_equal(y5.cpu().numpy(), y2)
+    starts = np.concatenate([[0], np.cumsum((cps + nfft)[:-1])])
+    o = np.int64(np.round(cps[:-1] * 0.5))
+    idx = (starts[:-1, None] + o[:, None] + np.arange(nfft)[None]).reshape(-1)
+    var_ref = np.array([np.var(y2[b][:, idx]) for b in range(n)])
+    sg_ref = np.sqrt(var_ref * nfft / (12.0 * 25) / snr)
+    assert rel(sg5.cpu().numpy(), sg_ref) < 1e-12 and rel(nv5.cpu().numpy(), sg_ref ** 2 * nfft) < 1e-12
+    g_idx = (np.arange(nr)[:, None] * ns + idx[None]).reshape(-1)
+    _, sg6, _ = ops.noise_level(T(y2, dev), snr_lin=snr, mult=nfft / (12.0 * 25), nv_mult=float(nfft), gather=np.int32(g_idx))
+    assert rel(sg5.cpu().numpy(), sg6.cpu().numpy()) < 1e-13
     # a wideband precoder folded into the gains (nrx_fold_precoder_f64): filtering the Nl layer signals with the folded gains
     # == filtering the Nt precoded signals (the time-domain link modulates layers, grid.py:505-516 + channelmodel.py:431-447)
     nl = 3
