@@ -438,6 +438,14 @@ int32_t nrx_apply_td_paths_pow_f64(const void* x, int32_t n_items, int32_t n_tx,
                                    const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
                                    void* y, int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part,
                                    void* stream);
+/* The float32 waveform chain's filter (opt-in fast mode; the reference computes in complex128): x, y, gains1 complex64, taps
+ * float32, packed float32 arithmetic.  pow_acc may be NULL (no power sums; nfft, pow_capacity, n_part then unused).
+ * NRX_E_UNSUPPORTED for filter lengths other than 16 or Nr not in {1, 2, 4}: convert and call the float64 entry. */
+int32_t nrx_apply_td_paths_pow_f32(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                                   int32_t n_sets, int32_t n_rx, int32_t n_paths, const float* taps,
+                                   const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
+                                   void* y, int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part,
+                                   void* stream);
 int32_t nrx_noise_level_finish_f64(const double* acc, int32_t n_part, int64_t count, int32_t n_batch, void* var_out,
                                    const double* snr_lin, int32_t snr_stride, double mult, void* sigma_out, void* nv_out,
                                    double nv_mult, void* stream);

@@ -441,6 +441,152 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
 #endif
 }
 
+// The same filter in float32 for the float32 waveform chain (the opt-in fast mode; the reference computes in complex128, so this
+// is NOT the parity path).  A complex sample is one 64-bit register pair and every multiply-add a packed one (v_pk_fma_f32: both
+// halves per instruction): tap x sample = 1 instruction, gain x filtered sample = 2 (g.re * (fr, fi) + g.im * (-fi, fr)) -- 96
+// per (tx antenna, path) term and 4 outputs against 192 in float64 -- and the window reads are 8 bytes.  Same tiling, same
+// transposed LDS tile, same group split; the groups' partial sums cross LDS in one phase (a sample is 8 bytes).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef nrx::cx<float> cf;
+
+template <int NR>
+__device__ __forceinline__ void tdp4f_term(const char* __restrict__ q0, const char* __restrict__ q1, const char* __restrict__ q2,
+                                           const char* __restrict__ q3, const float* __restrict__ c, const f2* __restrict__ gv,
+                                           int gstride, f2 (&acc)[NR][TDP_R]) {
+  constexpr int R = TDP_R, W = TDP_FLEN + R - 1;
+  f2 w[W];
+#pragma unroll
+  for (int m = 0; m < W; ++m) {
+    const char* qk = (m & 3) == 0 ? q0 : ((m & 3) == 1 ? q1 : ((m & 3) == 2 ? q2 : q3));
+    w[m] = *(const f2*)(qk + (m >> 2) * (int)sizeof(f2));
+  }
+  f2 f[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) f[j] = (f2)(0.0f);
+#pragma unroll
+  for (int k = 0; k < TDP_FLEN; ++k) {
+    const float ck = c[k];
+#pragma unroll
+    for (int j = 0; j < R; ++j) f[j] = __builtin_elementwise_fma((f2)(ck), w[TDP_FLEN - 1 + j - k], f[j]);
+  }
+  f2 fs[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) fs[j] = (f2){-f[j].y, f[j].x};
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const f2 g = gv[(size_t)r * gstride];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      acc[r][j] = __builtin_elementwise_fma((f2)(g.x), f[j], acc[r][j]);
+      acc[r][j] = __builtin_elementwise_fma((f2)(g.y), fs[j], acc[r][j]);
+    }
+  }
+}
+
+template <int NR>
+__global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS, 4)
+apply_td_paths4f_kernel(const f2* __restrict__ x, int nt, int64_t ns, const f2* __restrict__ gains1, int n_paths,
+                        const float* __restrict__ taps, const int32_t* __restrict__ tap_off, int hist, TdGeom g,
+                        f2* __restrict__ y, double* __restrict__ pow_acc, int pow_nfft) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f2* xs = (f2*)smem;  // [nt][R][Q]
+  constexpr int R = TDP_R;
+  constexpr int PW = TDP_TILE / 64;
+  const int b = blockIdx.y;
+  const int set = blockIdx.x / g.tiles_per_set, tile = blockIdx.x % g.tiles_per_set;
+  const int n0 = g.start[set] + tile * (TDP_TILE * R);
+  const int n_end = g.start[set + 1];
+  if (n0 >= n_end) {
+    if (pow_acc && threadIdx.x < 3 * PW) pow_acc[((size_t)b * gridDim.x + blockIdx.x) * 3 * PW + threadIdx.x] = 0.0;
+    return;
+  }
+  const int span = TDP_TILE * R + hist;   // hist is a multiple of R (host)
+  const int Q = span / R;
+  for (int i = threadIdx.x; i < nt * span; i += blockDim.x) {
+    const int t = i / span, j = i - t * span;
+    const int64_t n = (int64_t)n0 - hist + j;
+    xs[(t * R + (j & (R - 1))) * Q + (j >> 2)] = (n >= 0 && n < ns) ? x[((size_t)b * nt + t) * ns + n] : (f2)(0.0f);
+  }
+  __syncthreads();
+  const int ts = (int)threadIdx.x % TDP_TILE;
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / TDP_TILE);
+  const int n = n0 + R * ts;
+  f2 acc[NR][R];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[r][j] = (f2)(0.0f);
+  const f2* gb = gains1 + ((size_t)b * g.n_sets + set) * NR * nt * n_paths;
+  if (n < n_end) {
+    const char* xl = (const char*)(xs + ts);
+    for (int t = grp; t < nt; t += TDP_GROUPS) {
+      for (int p = 0; p < n_paths; ++p) {
+        const int u = hist - tap_off[p] - (TDP_FLEN - 1);
+        const float* c = taps + (size_t)p * TDP_FLEN;
+        const int o0 = ((t * R + ((u + 0) & 3)) * Q + ((u + 0) >> 2)) * (int)sizeof(f2);
+        const int o1 = ((t * R + ((u + 1) & 3)) * Q + ((u + 1) >> 2)) * (int)sizeof(f2);
+        const int o2 = ((t * R + ((u + 2) & 3)) * Q + ((u + 2) >> 2)) * (int)sizeof(f2);
+        const int o3 = ((t * R + ((u + 3) & 3)) * Q + ((u + 3) >> 2)) * (int)sizeof(f2);
+        tdp4f_term<NR>(xl + o0, xl + o1, xl + o2, xl + o3, c, gb + (size_t)t * n_paths + p, nt * n_paths, acc);
+      }
+    }
+  }
+  f2* part = (f2*)smem;   // [GROUPS - 1][NR * R][TDP_TILE]: the staged tile is dead now
+  __syncthreads();
+  if (grp > 0) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int j = 0; j < R; ++j) part[((grp - 1) * NR * R + r * R + j) * TDP_TILE + ts] = acc[r][j];
+  }
+  __syncthreads();
+  if (grp != 0) return;
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+#pragma unroll
+      for (int q = 0; q < TDP_GROUPS - 1; ++q) acc[r][j] += part[(q * NR * R + r * R + j) * TDP_TILE + ts];
+    }
+  if (n < n_end) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (n + j < n_end) y[((size_t)b * NR + r) * ns + n + j] = acc[r][j];
+  }
+  if (pow_acc) {   // power sums over the CP-stripped samples, in double, one triple per wave (see the float64 kernel)
+    double sr = 0, si = 0, s2 = 0;
+    if (n < n_end && set < g.n_sets - 1) {
+      const int s0 = g.start[set];
+      const int off = (int)rint((double)(n_end - s0 - pow_nfft) * 0.5);
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int pos = n + j - s0;
+          if (n + j < n_end && pos >= off && pos < off + pow_nfft) {
+            const double vr = acc[r][j].x, vi = acc[r][j].y;
+            sr += vr;
+            si += vi;
+            s2 += vr * vr + vi * vi;
+          }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      sr += __shfl_xor(sr, o, 64);
+      si += __shfl_xor(si, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      double* o3 = pow_acc + (((size_t)b * gridDim.x + blockIdx.x) * PW + (threadIdx.x >> 6)) * 3;
+      o3[0] = sr;
+      o3[1] = si;
+      o3[2] = s2;
+    }
+  }
+}
+
 int ilog2(int n) {
   int l = 0;
   while ((1 << l) < n) ++l;
@@ -1202,6 +1348,59 @@ extern "C" int32_t nrx_apply_td_paths_pow_f64(const void* x, int32_t n_items, in
     NRX_REQUIRE(set_lens && set_lens[i] > nfft, NRX_E_ARG, "nrx_apply_td_paths_pow: a symbol (%d samples) is not longer than nfft", set_lens[i]);
   return apply_td_paths_impl(x, n_items, n_tx, ns, gains1, n_sets, n_rx, n_paths, taps, tap_off, flen, hist, set_lens, y, stream,
                              pow_acc, nfft, pow_capacity, n_part);
+}
+
+// float32 waveform chain (fast mode): x (n_items, n_tx, ns) / y (n_items, n_rx, ns) complex64, gains1 complex64, taps float32.
+// pow_acc may be NULL (no power sums).  Register-tiled kernel only: NRX_E_UNSUPPORTED for filter lengths other than 16 or
+// Nr > 4 (the caller converts and takes the float64 entry).
+extern "C" int32_t nrx_apply_td_paths_pow_f32(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1,
+                                              int32_t n_sets, int32_t n_rx, int32_t n_paths, const float* taps,
+                                              const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
+                                              void* y, int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part,
+                                              void* stream) {
+  NRX_REQUIRE(x && gains1 && taps && tap_off && set_lens && y, NRX_E_ARG, "nrx_apply_td_paths_pow_f32: NULL buffer");
+  NRX_REQUIRE(n_sets >= 1 && n_sets <= 16 && n_tx >= 1 && n_paths >= 1 && flen >= 1 && hist >= 0 && ns > 0 && n_items >= 0,
+              NRX_E_ARG, "nrx_apply_td_paths_pow_f32: bad sizes");
+  NRX_REQUIRE(!pow_acc || (n_part && nfft > 0), NRX_E_ARG, "nrx_apply_td_paths_pow_f32: power sums need n_part and nfft");
+  if (pow_acc)
+    for (int i = 0; i + 1 < n_sets; ++i)
+      NRX_REQUIRE(set_lens[i] > nfft, NRX_E_ARG, "nrx_apply_td_paths_pow_f32: a symbol (%d samples) is not longer than nfft", set_lens[i]);
+  if (n_items == 0) return NRX_OK;
+  TdGeom g;
+  td_geom(set_lens, n_sets, ns, &g);
+  const int hist4 = (hist + TDP_R - 1) / TDP_R * TDP_R;
+  size_t lds4 = sizeof(f2) * (size_t)n_tx * (TDP_TILE * TDP_R + hist4);
+  const size_t part4 = sizeof(f2) * (TDP_GROUPS - 1) * (size_t)n_rx * TDP_R * TDP_TILE;
+  if (lds4 < part4) lds4 = part4;
+  if (!(flen == TDP_FLEN && lds4 <= 80 * 1024 && (n_rx == 1 || n_rx == 2 || n_rx == 4))) {
+    ::nrx::set_error("nrx_apply_td_paths_pow_f32: built for 16-tap filters and Nr in {1, 2, 4} (flen %d, Nr %d)", flen, n_rx);
+    return NRX_E_UNSUPPORTED;
+  }
+  int maxlen = 0;
+  for (int i = 0; i < g.n_sets; ++i) maxlen = g.start[i + 1] - g.start[i] > maxlen ? g.start[i + 1] - g.start[i] : maxlen;
+  g.tiles_per_set = (maxlen + TDP_TILE * TDP_R - 1) / (TDP_TILE * TDP_R);
+  if (g.tiles_per_set < 1) g.tiles_per_set = 1;
+  const dim3 grid4(g.tiles_per_set * n_sets, n_items);
+  if (pow_acc) {
+    const int64_t need = (int64_t)n_items * grid4.x * (TDP_TILE / 64) * 3;
+    NRX_REQUIRE(pow_capacity >= need, NRX_E_SHAPE, "nrx_apply_td_paths_pow_f32: pow_acc needs %lld doubles", (long long)need);
+    *n_part = (int32_t)(grid4.x * (TDP_TILE / 64));
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define NRX_TDP4F_CASE(NR)                                                                                                 \
+  case NR:                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)apply_td_paths4f_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
+    hipLaunchKernelGGL(apply_td_paths4f_kernel<NR>, grid4, dim3(TDP_TILE * TDP_GROUPS), lds4, st, (const f2*)x, n_tx, ns,  \
+                       (const f2*)gains1, n_paths, taps, tap_off, hist4, g, (f2*)y, pow_acc, nfft);                        \
+    break;
+  switch (n_rx) {
+    NRX_TDP4F_CASE(1)
+    NRX_TDP4F_CASE(2)
+    NRX_TDP4F_CASE(4)
+  }
+#undef NRX_TDP4F_CASE
+  NRX_CHECK_LAUNCH("nrx_apply_td_paths_pow_f32");
+  return NRX_OK;
 }
 
 extern "C" int32_t nrx_fold_precoder_f64(const void* gains, const void* F, int64_t f_stride, int32_t n_items, int32_t n_sets,

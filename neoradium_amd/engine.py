@@ -106,7 +106,13 @@ def gain_times(tables, slots):
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
                  decoder="f64", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
-                 skipPuncturedRows=True):
+                 skipPuncturedRows=True, waveform="f64"):
+        if waveform not in ("f32", "f64"):
+            raise ValueError("waveform must be 'f64' (the reference's complex128 waveforms, default) or 'f32' (time-domain link only: "
+                             "Tx grid, OFDM, channel filter and received grid in complex64 -- not the parity path)")
+        if waveform == "f32" and (freqDomain or pdsch.numCW != 1):
+            raise ValueError("waveform='f32' is built for the one-codeword time-domain link")
+        self.waveform = waveform
         if pdsch.dmrs is None:
             raise ValueError("PdschLink: the PDSCH needs a DMRS configuration (pdsch.setDMRS)")
         if chanEst not in ("LS", "Perfect"):
@@ -150,6 +156,7 @@ class PdschLink:
         self.tbs = tb_['cw'][0]['tbs']
         self.port_ks, self.dmrs_syms = tb_['port_ks'], tb_['dmrs_syms']
         self.templates = D(tb_['templates'])                   # (S, Nl, L, K) complex128
+        self.templates32 = None                                # complex64 copy for waveform="f32", made on first use
         self.pilots = D(tb_['pilots'])                         # (S, P, nDs, nK)
         self.l_cdm, self.k_cdm = tb_['l_cdm'], tb_['k_cdm']
         self.port_ks_d = D(np.ascontiguousarray(np.int32(self.port_ks)))
@@ -403,7 +410,10 @@ class PdschLink:
             if grid is None:    # one codeword: template + scramble + modulate + layer/RE map in one pass over the grid
                 if self.re_planes is None:
                     self.re_planes = ops.layer_planes(self.re_inv, self.templates.shape[1])
-                grid = ops.pdsch_populate(bits, cw['qm'], cw['scr'], self.re_inv, self.templates, sif, planes=self.re_planes)
+                if self.waveform == "f32" and self.templates32 is None:
+                    self.templates32 = self.templates.to(torch.complex64)
+                grid = ops.pdsch_populate(bits, cw['qm'], cw['scr'], self.re_inv,
+                                          self.templates32 if self.waveform == "f32" else self.templates, sif, planes=self.re_planes)
             else:
                 ops.qam_map(bits, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], out=grid)
         tb = tbs_in[0]
@@ -436,6 +446,8 @@ class PdschLink:
                 rxg = ops.ofdm_demodulate(ops.add_noise(ry, noise.to(dev), sigma), self.nfft, cps, self.K, t_off=off)
             else:       # the noise is generated while the demodulator loads its samples (= ops.awgn, then demodulate)
                 rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off, awgn=(sigma, seed, 2, int(slots[0]), ids))
+            if rxg.dtype != torch.complex128:       # waveform="f32": the estimator / equaliser / demapper run in float64
+                rxg = rxg.to(torch.complex128)
 
         # ---- Rx
         hest = None

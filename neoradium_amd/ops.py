@@ -1035,6 +1035,14 @@ def path_taps(coeff, filter_len=16):
 
 def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None, power=None):
     """ChannelModel.applyToSignal, path form: x (n,Nt,ns), gains1 (n,nc+1,Nr,Nt,P), taps (P,flen), tap_off (P) -> (n,Nr,ns)."""
+    if x.dtype == torch.complex64:          # float32 waveform chain (fast mode)
+        got = _apply_td_paths_f32(x, gains1, taps, tap_off, set_lens, hist, power)
+        if got is not NotImplemented:
+            return got
+        got = apply_td_paths(x.to(torch.complex128), gains1, taps, tap_off, set_lens, hist=hist, power=power)
+        if got is None:
+            return None
+        return (got[0].to(torch.complex64),) + tuple(got[1:]) if power is not None else got.to(torch.complex64)
     x = x.to(torch.complex128).contiguous()
     gains1 = gains1.to(torch.complex128).contiguous()
     n, nt, ns = x.shape
@@ -1076,6 +1084,49 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None, power=None):
     check(lib().nrx_apply_td_paths_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen,
                                        hist, _host_i32(set_lens), ptr(y), stream()))
     return y
+
+
+def _apply_td_paths_f32(x, gains1, taps, tap_off, set_lens, hist, power):
+    """apply_td_paths on a complex64 waveform with packed float32 arithmetic (nrx_apply_td_paths_pow_f32); sigma / nv stay
+    float64.  NotImplemented when the geometry has no float32 instantiation."""
+    x = x.contiguous()
+    n, nt, ns = x.shape
+    if gains1.shape[0] != n or gains1.shape[3] != nt or gains1.shape[1] != len(set_lens):
+        raise ValueError("The number of transmit antennas in the signal does not match the channel.")
+    dev = _dev(x)
+    gains1 = gains1.to(torch.complex64).contiguous()
+    nr, P = gains1.shape[2], gains1.shape[4]
+    taps = taps.to(device=dev, dtype=torch.float32).contiguous()
+    host_off = None if isinstance(tap_off, torch.Tensor) and tap_off.is_cuda else np.asarray(tap_off)
+    tap_off = _i32(tap_off, dev)
+    if taps.shape[0] != P or tap_off.numel() != P:
+        raise ValueError("tap table / path count mismatch")
+    flen = taps.shape[1]
+    if hist is None:
+        hist = int(tap_off.max()) + flen - 1
+    elif host_off is not None and (host_off.min() < 0 or hist < int(host_off.max()) + flen - 1):
+        raise ValueError("hist must cover the longest path: max(tap_off) + flen - 1")
+    y = torch.empty((n, nr, ns), dtype=torch.complex64, device=dev)
+    acc, cap, nfft = None, 0, 0
+    if power is not None:
+        nfft = int(power[0])
+        cap = 3 * n * (-(-max(int(v) for v in set_lens) // 512) + 1) * len(set_lens) * 4
+        acc = torch.empty(cap, dtype=torch.float64, device=dev)
+    n_part = C.c_int32(0)
+    rc = lib().nrx_apply_td_paths_pow_f32(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(taps), ptr(tap_off), flen, hist,
+                                          _host_i32(set_lens), ptr(y), nfft, ptr(acc), cap, C.byref(n_part), stream())
+    if rc == -3:                 # NRX_E_UNSUPPORTED
+        return NotImplemented
+    check(rc)
+    if power is None:
+        return y
+    _, snr_lin, mult, nv_mult = power
+    snr = torch.as_tensor(snr_lin, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+    sigma = torch.empty(n, dtype=torch.float64, device=dev)
+    nv = torch.empty(n, dtype=torch.float64, device=dev)
+    check(lib().nrx_noise_level_finish_f64(ptr(acc), n_part.value, nr * (len(set_lens) - 1) * nfft, n, None, ptr(snr),
+                                           0 if snr.numel() == 1 else 1, float(mult), ptr(sigma), ptr(nv), float(nv_mult), stream()))
+    return y, sigma, nv
 
 
 def fold_precoder(gains1, f):

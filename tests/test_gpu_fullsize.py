@@ -86,6 +86,7 @@ def test_ofdm_round_trip_and_filter_linearity(link, dev):
 def test_engine_counters_at_metric_size(link, dev):
     """Whole slots at the metric configuration: counters do not depend on how a slot range is batched (the basis of the
     multi-GPU sharding), clean at very high SNR, and the float64 decoder reaches the same CRC verdicts there."""
+    import torch
     import bench
     import neoradium_amd as nr
     whole = link.run(10, 4, 33.0, seed=7).cpu().numpy()
@@ -103,6 +104,17 @@ def test_engine_counters_at_metric_size(link, dev):
     assert int((a != b).sum()) <= 2
     rel = float((d32[0][1]['llr'].double() - d64[0][1]['llr']).abs().max() / d64[0][1]['llr'].abs().max())
     assert rel <= 1e-5                        # north-star tolerance on float LLRs
+    # waveform="f32" (opt-in, with the float32 decoder = the bench's fast mode): Tx grid, OFDM, channel filter and received grid in
+    # complex64.  Same generator keys, so the same transport blocks and noise draws: the equalised LLRs stay within float32
+    # accuracy of the float64 chain's and the verdicts within the fast mode's disagreement rate.
+    lw = bench.build_link(nr, decoder="f32", num_iter=20, waveform="f32")
+    _, dw = lw.run(3, 2, 36.0, seed=11, details=True)
+    c = dw[0][1]['cb_ok'].cpu().numpy()
+    assert int((c != b).sum()) <= 2
+    scale = float(d64[0][1]['llr'].abs().max())
+    err = (dw[0][1]['llr'].double() - d64[0][1]['llr']).abs()
+    assert float(err.max()) <= 2e-3 * scale and float(err.mean()) <= 1e-4 * scale, (float(err.max()) / scale, float(err.mean()) / scale)
+    assert torch.equal(lw.run(10, 4, 33.0, seed=7), lw.run(10, 1, 33.0, seed=7) + lw.run(11, 3, 33.0, seed=7))
 
 
 def test_multi_pass_schedule_at_metric_size(dev):

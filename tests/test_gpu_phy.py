@@ -271,6 +271,15 @@ def test_tdl_chain(dev):
     g_idx = (np.arange(nr)[:, None] * ns + idx[None]).reshape(-1)
     _, sg6, _ = ops.noise_level(T(y2, dev), snr_lin=snr, mult=nfft / (12.0 * 25), nv_mult=float(nfft), gather=np.int32(g_idx))
     assert rel(sg5.cpu().numpy(), sg6.cpu().numpy()) < 1e-13
+    # the float32 waveform chain's filter (nrx_apply_td_paths_pow_f32, packed float32 arithmetic; opt-in fast mode, not the parity
+    # path): float32 accuracy against the float64 result, noise level from its own output
+    import torch
+    got32 = ops.apply_td_paths(T(x, dev).to(torch.complex64), gains, T(taps, dev), offs, list(cps + nfft),
+                               power=(nfft, snr, nfft / (12.0 * 25), float(nfft)))
+    y7, sg7, _ = got32
+    assert y7.dtype == torch.complex64 and rel(y7.cpu().numpy(), y2) < 2e-6 and rel(sg7.cpu().numpy(), sg_ref) < 1e-6
+    y8 = ops.apply_td_paths(T(x, dev).to(torch.complex64), gains, T(taps, dev), offs, list(cps + nfft))
+    assert torch.equal(y8, y7)
     # a wideband precoder folded into the gains (nrx_fold_precoder_f64): filtering the Nl layer signals with the folded gains
     # == filtering the Nt precoded signals (the time-domain link modulates layers, grid.py:505-516 + channelmodel.py:431-447)
     nl = 3
