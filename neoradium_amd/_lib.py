@@ -78,6 +78,7 @@ for _t in ('f32', 'f64'):
 for _t in ('f32', 'f64', 'f64o32'):
     SIGNATURES['nrx_qam_demap_' + _t] = (i32, [vp, i64, vp, vp, i32, vp, i32, vp, i32, vp, i64, i32, i32, f64, vp])
     SIGNATURES['nrx_qam_demap_cb_' + _t] = (i32, [vp, i64, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp, i64, i32, f64, vp])
+    SIGNATURES['nrx_qam_demap_rr_' + _t] = (i32, [vp, i64, vp, vp, i32, vp, i32, vp, i32, _cfgp, i32, i32, vp, i32, f64, vp])
 SIGNATURES.update({
     'nrx_cdl_gains_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'nrx_cdl_gains_items_f64': (i32, [vp, vp, vp, f64, vp, i32, i32, i32, i32, i32, i32, vp, vp]),

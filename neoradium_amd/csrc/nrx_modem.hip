@@ -186,11 +186,14 @@ pdsch_populate_qp_kernel(const uint8_t* __restrict__ bits, int64_t bits_stride, 
 // reference's divisions so that it stays bit-identical to NumPy.
 // Code-block de-interleaving done by the demapper's stores (nrx_qam_demap_cb_*): E_r = e_small for the first n_small blocks,
 // e_small + f for the others (ldpc.py:846-856); e_small = 0: plain symbol-major output.
+// pitch > 0 (nrx_qam_demap_rr_*): block r starts at r * pitch instead of offset_r and positions >= sys_len move up by the F
+// filler positions -- the rate-recovered layout of a first transmission (rv 0, no repetition: ldpc.py:1330-1418 with k0 = 0).
 struct DeintGeom {
   int e_small, n_small, f;
+  int pitch, sys_len, F;
 };
 
-template <typename T, typename TL, int QM>
+template <typename T, typename TL, int QM, bool RR = false>
 __global__ void __launch_bounds__(256)
 qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __restrict__ scales,
                  const T* __restrict__ noise_var, int nv_stride, const uint8_t* __restrict__ scr, double scale,
@@ -236,19 +239,25 @@ qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __
       // QM values of a symbol, consecutive symbols = consecutive lanes = consecutive addresses)
       TL* dst = llr + (size_t)b * llr_stride + (size_t)i * QM;
       int dq = 1;
+      int fill_from = 0x7fffffff;
       if (dg.e_small > 0) {
         const int ss = dg.e_small / QM, split = dg.n_small * ss;
         int r, sidx, off;
         if (i < split) { r = i / ss; sidx = i - r * ss; dq = ss; off = r * dg.e_small; }
         else { dq = (dg.e_small + dg.f) / QM; r = (i - split) / dq; sidx = (i - split) - r * dq; off = dg.n_small * dg.e_small + r * (dg.e_small + dg.f); }
         dst = llr + (size_t)b * llr_stride + off + sidx;
+        if constexpr (RR) {
+          const int rg = i < split ? r : dg.n_small + r;
+          dst = llr + (size_t)b * llr_stride + (size_t)rg * dg.pitch + sidx;
+          fill_from = dg.sys_len - sidx;      // value q sits at position sidx + q*dq: behind the fillers iff q*dq >= fill_from
+        }
       }
       if constexpr (QM == 1) {
         const double d0 = ((double)y.re - scale) * ((double)y.re - scale) + ((double)y.im - scale) * ((double)y.im - scale);
         const double d1 = ((double)y.re + scale) * ((double)y.re + scale) + ((double)y.im + scale) * ((double)y.im + scale);
         double l = (-d0 / nv) - (-d1 / nv);
         if (scr) l *= (double)(1 - 2 * (int)(sbits & 1u));
-        dst[0] = (TL)(l * sc);
+        dst[RR && 0 >= fill_from ? dg.F : 0] = (TL)(l * sc);
       } else {
         TL out[QM];
 #pragma unroll
@@ -283,7 +292,7 @@ qam_demap_kernel(const cx<T>* __restrict__ syms, int64_t sym_stride, const T* __
           }
         }
 #pragma unroll
-        for (int q = 0; q < QM; ++q) dst[(size_t)q * dq] = out[q];
+        for (int q = 0; q < QM; ++q) dst[(size_t)q * dq + (RR && q * dq >= fill_from ? dg.F : 0)] = out[q];
       }
       src = src_next;
     }
@@ -406,13 +415,32 @@ int32_t populate_entry(const uint8_t* bits, int64_t bits_stride, const uint8_t* 
   return NRX_OK;
 }
 
+// nrx_qam_demap_rr_*: what the demapper's stores did not reach of the first n_fill code-word positions of every block --
+// zeros behind the E_r transmitted positions, LARGE_LLR on the fillers (ldpc.py:1401-1418).
+template <typename TL>
+__global__ void __launch_bounds__(256)
+rr_tail_kernel(TL* __restrict__ llr, int64_t llr_stride, DeintGeom dg, int C, int n_fill) {
+  const int b = blockIdx.x / C, r = blockIdx.x - b * C;
+  const int E = r < dg.n_small ? dg.e_small : dg.e_small + dg.f;
+  const int nE = E < dg.sys_len ? E : E + dg.F;
+  TL* dst = llr + (size_t)b * llr_stride + (size_t)r * dg.pitch;
+  for (int n = nE + (int)threadIdx.x; n < n_fill; n += blockDim.x) dst[n] = (n >= dg.sys_len && n < dg.sys_len + dg.F) ? (TL)1e20 : (TL)0;
+  if (nE > dg.sys_len)
+    for (int n = dg.sys_len + (int)threadIdx.x; n < dg.sys_len + dg.F && n < n_fill; n += blockDim.x) dst[n] = (TL)1e20;
+}
+
 template <typename T, typename TL>
 int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var, int32_t nv_stride,
                     const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym, void* llr,
                     int64_t llr_stride, int32_t n_batch, int32_t exact, double nv_floor, void* stream,
-                    int32_t n_code_blocks = 0, int32_t n_layers = 0) {
+                    int32_t n_code_blocks = 0, int32_t n_layers = 0, const nrx_ldpc_cfg* rr = nullptr, int32_t rr_cols = 0) {
   NRX_REQUIRE(syms && noise_var && llr, NRX_E_ARG, "nrx_qam_demap: NULL buffer");
-  DeintGeom dg{0, 0, 0};
+  DeintGeom dg{0, 0, 0, 0, 0, 0};
+  if (rr) {
+    dg.pitch = rr->N;
+    dg.sys_len = rr->K - 2 * rr->Zc - rr->F;
+    dg.F = rr->F;
+  }
   if (n_code_blocks > 0) {      // per-code-block de-interleaved output (E_r split as nrx_ldpc_cb_lens, ldpc.py:846-856)
     NRX_REQUIRE(!exact && n_layers >= 1, NRX_E_UNSUPPORTED, "nrx_qam_demap_cb: max-log LLRs only, n_layers >= 1");
     const int f = n_layers * qm, G = n_sym * qm, gb = (G + f - 1) / f;
@@ -422,7 +450,7 @@ int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, co
     dg.f = f;
   }
   NRX_REQUIRE(qm_ok(qm), NRX_E_ARG, "nrx_qam_demap: unsupported modulation order %d", qm);
-  NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && llr_stride >= (int64_t)n_sym * qm, NRX_E_SHAPE, "nrx_qam_demap: bad sizes");
+  NRX_REQUIRE(n_sym >= 0 && n_batch >= 0 && llr_stride >= (rr ? (int64_t)rr->C * rr->N : (int64_t)n_sym * qm), NRX_E_SHAPE, "nrx_qam_demap: bad sizes");
   NRX_REQUIRE(!scr || qm == 1 || ((uintptr_t)scr & 1u) == 0, NRX_E_ARG, "nrx_qam_demap: the scrambling sequence must be 2-byte aligned");
   if (n_sym == 0 || n_batch == 0) return NRX_OK;
   const dim3 grid = sym_batch_grid(n_sym, n_batch);
@@ -433,9 +461,14 @@ int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, co
   else {
 #define NRX_DEMAP_CASE(Q)                                                                                              \
   case Q:                                                                                                              \
-    hipLaunchKernelGGL((qam_demap_kernel<T, TL, Q>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,      \
-                       sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qam_scale(Q), re_index,      \
-                       n_sym, (TL*)llr, llr_stride, n_batch, nv_floor, dg);                                            \
+    if (rr)                                                                                                            \
+      hipLaunchKernelGGL((qam_demap_kernel<T, TL, Q, true>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms, \
+                         sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qam_scale(Q), re_index,    \
+                         n_sym, (TL*)llr, llr_stride, n_batch, nv_floor, dg);                                          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((qam_demap_kernel<T, TL, Q>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)syms,    \
+                         sym_stride, (const T*)scales, (const T*)noise_var, nv_stride, scr, qam_scale(Q), re_index,    \
+                         n_sym, (TL*)llr, llr_stride, n_batch, nv_floor, dg);                                          \
     break;
     switch (qm) {
       NRX_DEMAP_CASE(1)
@@ -449,6 +482,11 @@ int32_t demap_entry(const void* syms, int64_t sym_stride, const void* scales, co
 #undef NRX_DEMAP_CASE
   }
   NRX_CHECK_LAUNCH("nrx_qam_demap");
+  if (rr) {
+    hipLaunchKernelGGL(rr_tail_kernel<TL>, dim3(n_batch * rr->C), dim3(256), 0, (hipStream_t)stream, (TL*)llr, llr_stride, dg, rr->C,
+                       rr_cols * rr->Zc);
+    NRX_CHECK_LAUNCH("nrx_qam_demap_rr");
+  }
   return NRX_OK;
 }
 
@@ -487,6 +525,28 @@ NRX_DEMAP(nrx_qam_demap_f64o32, double, float)
 NRX_DEMAP_CB(nrx_qam_demap_cb_f32, float, float)
 NRX_DEMAP_CB(nrx_qam_demap_cb_f64, double, double)
 NRX_DEMAP_CB(nrx_qam_demap_cb_f64o32, double, float)
+// The demapper whose stores do the whole rate recovery of a FIRST transmission (rv 0, no wrap-around repetition: E_r <= N - F
+// for every block): llr = the (n_batch * C, N) buffer nrx_ldpc_rate_recover_* would write, columns [0, n_cols) of the punctured
+// code word only (n_cols * Zc positions; what lies behind is left untouched -- pass the columns the decoder will read).
+#define NRX_DEMAP_RR(NAME, T, TL)                                                                                  \
+  extern "C" int32_t NAME(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,         \
+                          int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym, \
+                          const nrx_ldpc_cfg* cfg, int32_t n_layers, int32_t n_cols, void* llr, int32_t n_batch,   \
+                          double nv_floor, void* stream) {                                                         \
+    NRX_REQUIRE(cfg && cfg->C >= 1 && n_layers >= 1 && qm >= 1, NRX_E_ARG, "nrx_qam_demap_rr: bad configuration"); \
+    NRX_REQUIRE(n_cols >= 1 && n_cols * cfg->Zc <= cfg->N, NRX_E_ARG, "nrx_qam_demap_rr: n_cols outside the code word"); \
+    const int f_ = n_layers * qm, gb_ = (n_sym * qm + f_ - 1) / f_;                                                \
+    const int e_max = ((gb_ + cfg->C - 1) / cfg->C) * f_;                                                          \
+    if (e_max > cfg->N - cfg->F) {                                                                                 \
+      ::nrx::set_error("nrx_qam_demap_rr: E_r = %d wraps around the %d-position buffer (repetition): use nrx_ldpc_rate_recover", e_max, cfg->N - cfg->F); \
+      return NRX_E_UNSUPPORTED;                                                                                    \
+    }                                                                                                              \
+    return demap_entry<T, TL>(syms, sym_stride, scales, noise_var, nv_stride, scr, qm, re_index, n_sym, llr,       \
+                              (int64_t)cfg->C * cfg->N, n_batch, 0, nv_floor, stream, cfg->C, n_layers, cfg, n_cols); \
+  }
+NRX_DEMAP_RR(nrx_qam_demap_rr_f32, float, float)
+NRX_DEMAP_RR(nrx_qam_demap_rr_f64, double, double)
+NRX_DEMAP_RR(nrx_qam_demap_rr_f64o32, double, float)
 
 extern "C" int32_t nrx_pdsch_populate_f32(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, int32_t planes, void* stream) { return populate_entry<float>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, planes, stream); }
 extern "C" int32_t nrx_pdsch_populate_f64(const uint8_t* bits, int64_t bits_stride, const uint8_t* scr, int32_t qm, const int32_t* re_inv, const void* templ, const int64_t* templ_sel, int64_t elems, void* out, int32_t n_batch, int32_t planes, void* stream) { return populate_entry<double>(bits, bits_stride, scr, qm, re_inv, templ, templ_sel, elems, out, n_batch, planes, stream); }

@@ -230,6 +230,7 @@ class PdschLink:
         self.slot_len = [int(v[:-1].sum()) for v in self.sym_lens]
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
+        self._sep_rr = bool(int(os.environ.get('NRX_SEPARATE_RATE_RECOVERY', '0')))    # developer switch: demap, then rate recovery
         self._sep_power = bool(int(os.environ.get('NRX_SEPARATE_POWER', '0')))     # developer switch: noise level in its own pass
         # gain instants on the device (no host -> device copy per batch: such a copy from pageable memory waits for the
         # stream to drain, i.e. for the previous batch's decoder, and the GPU then idles while the host prepares the next one)
@@ -472,9 +473,17 @@ class PdschLink:
             # writes every code block's LLRs de-interleaved.  With details=True the LLRs are wanted in the reference's order.
             fuse = (harq is None and self.decoder == "f64" and self.useMax and details is not True
                     and ops.ldpc_fused_supported(ccfg, cw['nl'], cw['qm'], cw['G'], cw['rows']))
-            llr = ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
-                                exact=not self.useMax, llr_dtype=torch.float32 if self.decoder == "f32" else torch.float64,
-                                code_blocks=(ccfg.C, cw['nl']) if fuse else None)
+            # ... and where no fused entry applies, a first transmission without repetition needs no rate-recovery pass either: the
+            # demapper's stores put every LLR where the decoder reads it (nrx_qam_demap_rr_*; None when E_r wraps around)
+            ldt = torch.float32 if self.decoder == "f32" else torch.float64
+            rr = None
+            if not fuse and harq is None and self.useMax and details is not True and not self._sep_rr:
+                n_cols = min(ccfg.N // ccfg.Zc, ccfg.K // ccfg.Zc - 2 + ops.ldpc_rows_read(ccfg, cw['rows'], self.decoder == "f32"))
+                rr = ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
+                                   llr_dtype=ldt, rate_recovered=(ccfg, cw['nl'], n_cols))
+            llr = None if rr is not None else \
+                ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
+                              exact=not self.useMax, llr_dtype=ldt, code_blocks=(ccfg.C, cw['nl']) if fuse else None)
             if fuse and self.firstPassIter is not None:     # two passes, both on the fused entry, the failing blocks' list on the device
                 fused = ops.ldpc_recover_decode_merge_two_pass(llr, ccfg, cw['nl'], cw['qm'], self.firstPassIter, self.numIter,
                                                                rows=cw['rows'], stages=self.passStages)
@@ -488,7 +497,9 @@ class PdschLink:
                     ops.count_errors(cb_ok, tb_out, tbs_in[q], counters)
                 per_cw.append(dict(tb=tbs_in[q], cb_ok=cb_ok, tb_out=tb_out, llr=llr))
                 continue
-            if harq is None:
+            if rr is not None:
+                pass
+            elif harq is None:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'])
             else:
                 rr = ops.ldpc_rate_recover(llr, ccfg, cw['nl'], cw['qm'], rv=harq[q][0], circ=harq[q][1], reset=harq[q][2])

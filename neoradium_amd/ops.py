@@ -438,8 +438,21 @@ def pdsch_populate(bits, qm, scr, re_inv, templates, templ_sel, planes=None):
     return out
 
 
+def ldpc_rows_read(cfg, rows, f32):
+    """Base-graph rows whose extension LLRs the decoder entries READ for a request of ``rows`` rows: the row count of the
+    instantiation that runs (BG1, Zc = 384: 13 / 15 / 16 / 22 / 31 / all in float32, 13 / 15 / 31 / all in float64, see
+    nrx_ldpc_decode_rows_*), all rows for every other graph -- a superset is always safe."""
+    total = 46 if cfg.bg == 1 else 42
+    rows = total if not rows else int(rows)
+    if cfg.bg == 1 and cfg.Zc == 384:
+        for r in ((13, 15, 16, 22, 31) if f32 else (13, 15, 31)):
+            if rows <= r:
+                return r
+    return total
+
+
 def qam_demap(syms, noise_var, qm, n_sym=None, scr=None, re_index=None, scales=None, exact=False, nv_floor=0.0,
-              llr_dtype=None, code_blocks=None):
+              llr_dtype=None, code_blocks=None, rate_recovered=None):
     """Modem.getLLRsFromSymbols / PDSCH.getLLRsFromGrid: (n, E) complex -> (n, n_sym*qm) LLRs.
     ``code_blocks`` = (C, n_layers): write every code block's LLRs de-interleaved (nrx_qam_demap_cb_*: the input layout of
     :func:`ldpc_recover_decode_merge`) instead of symbol-major."""
@@ -470,6 +483,19 @@ def qam_demap(syms, noise_var, qm, n_sym=None, scr=None, re_index=None, scales=N
         sfx = 'f64o32'
     elif llr_dtype != rt:
         raise ValueError("unsupported LLR dtype for this input type")
+    if rate_recovered is not None:
+        # (cfg, n_layers, n_cols): the demapper's stores do the rate recovery of a first transmission (nrx_qam_demap_rr_*) ->
+        # (n * C, N), columns [0, n_cols) of the punctured code word initialised; None when E_r wraps around the buffer
+        cfg, n_layers, n_cols = rate_recovered
+        if exact:
+            raise ValueError("rate_recovered: max-log LLRs only")
+        out = torch.empty((n * cfg.C, cfg.N), dtype=llr_dtype, device=dev)
+        rc = getattr(lib(), 'nrx_qam_demap_rr_' + sfx)(ptr(flat), E, ptr(sc), ptr(nv), 0 if nv.numel() == 1 else 1, ptr(scr_t), qm, ptr(ri),
+                                                       n_sym, C.byref(cfg), int(n_layers), int(n_cols), ptr(out), n, float(nv_floor), stream())
+        if rc == -3:                 # NRX_E_UNSUPPORTED
+            return None
+        check(rc)
+        return out
     llr = torch.empty((n, n_sym * qm), dtype=llr_dtype, device=dev)
     if code_blocks is not None:
         if exact:

@@ -376,6 +376,22 @@ def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_e
     for E in lens:
         assert np.array_equal(dei[:, off:off + E], std[:, off:off + E].reshape(2, E // qm, qm).transpose(0, 2, 1).reshape(2, E))
         off += E
+    # ... and the rate-recovering option (nrx_qam_demap_rr_*) the whole of nrx_ldpc_rate_recover_* for a first transmission: the
+    # columns asked for equal rate recovery of the symbol-major LLRs bit for bit (transmitted positions, zeros, LARGE_LLR fillers),
+    # for every in/out type, a configuration with filler bits and unequal block lengths included
+    for c_, G_, nl_, qm_ in ((cfg, G, nl, qm), (_lib.ldpc_config(1, 20000), 3 * 6600 + 12, 2, 6), (_lib.ldpc_config(2, 3000), 2 * 3000, 1, 4)):
+        ns_ = G_ // qm_
+        sy = torch.from_numpy(rng.standard_normal((3, ns_)) + 1j * rng.standard_normal((3, ns_))).to(dev)
+        for dt_in, dt_out in ((torch.complex128, torch.float64), (torch.complex128, torch.float32), (torch.complex64, torch.float32)):
+            want = ops.ldpc_rate_recover(ops.qam_demap(sy.to(dt_in), 0.3, qm_, llr_dtype=dt_out), c_, nl_, qm_)
+            for n_cols in (c_.N // c_.Zc, c_.K // c_.Zc - 2 + 15):
+                got = ops.qam_demap(sy.to(dt_in), 0.3, qm_, llr_dtype=dt_out, rate_recovered=(c_, nl_, n_cols))
+                assert got.shape == want.shape and got.dtype == want.dtype
+                assert torch.equal(got[:, :n_cols * c_.Zc], want[:, :n_cols * c_.Zc]), (c_.Zc, c_.F, dt_in, dt_out, n_cols)
+    # repetition (E_r beyond the circular buffer) is declined, not approximated
+    c3 = _lib.ldpc_config(2, 300)
+    sy = torch.zeros((1, 2 * c3.N // 2), dtype=torch.complex128, device=dev)
+    assert ops.qam_demap(sy, 0.3, 2, rate_recovered=(c3, 1, c3.N // c3.Zc)) is None
 
 
 @pytest.mark.parametrize("bg,zc,n_tx_cols,all_rows", [(1, 384, 35, False), (1, 384, 35, True), (1, 352, 40, True), (2, 64, 20, True)])
