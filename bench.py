@@ -383,11 +383,20 @@ def main():
             fl = build_link(nr, decoder='f32')
             fdt, fc, fdec = timed_steps(fl, ops, B, K, W, args.snr, slot_base, None, sync)
             fc = fc.cpu().numpy()
-            out["fast_mode"] = {"decoder": "f32 LLRs + ldpc_dec_fast_kernel", "value": B * K / fdt, "unit": "slots/s",
+            out["fast_mode"] = {"decoder": "f32 LLRs + ldpc_dec_fast_kernel", "waveform": "f64", "value": B * K / fdt, "unit": "slots/s",
                                 "ms_per_step": fdt / K * 1e3, "decoder_launch_ms": fdec, "exact": False,
                                 "block_errors": int(fc[0]), "blocks": int(fc[1]),
                                 "block_error_count_delta": int(fc[0]) - int(c[0])}
             del fl
+            # ... and with the waveform chain in complex64 as well (Tx grid, OFDM, channel filter with packed float32 arithmetic,
+            # received grid; estimator / equaliser / demapper stay float64): PdschLink(decoder='f32', waveform='f32')
+            fw = build_link(nr, decoder='f32', waveform='f32')
+            wdt, wc, wdec = timed_steps(fw, ops, B, K, W, args.snr, slot_base, None, sync)
+            wc = wc.cpu().numpy()
+            out["fast_mode"]["f32_waveform"] = {"value": B * K / wdt, "unit": "slots/s", "ms_per_step": wdt / K * 1e3,
+                                                "decoder_launch_ms": wdec, "exact": False, "block_errors": int(wc[0]),
+                                                "blocks": int(wc[1]), "block_error_count_delta": int(wc[0]) - int(c[0])}
+            del fw
         if not args.stub and world == 1 and not args.no_twopass and f64:
             # OPT-IN schedule, reported beside `value`, never instead of it: every code block gets `first_pass_iter` iterations,
             # the blocks whose CRC fails continue (from their parked decoder state: no iteration twice) to the next check and

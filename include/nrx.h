@@ -363,6 +363,16 @@ int32_t nrx_ofdm_demodulate_awgn_f64(const void* wave, int64_t wave_stride, int6
                                      const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride,
                                      uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid,
                                      void* stream);
+/* float32 waveform and transform, complex128 grid out: where the float32 waveform chain (fast mode) hands over to the float64
+ * estimator.  The values are those of the _f32 entries converted to double. */
+int32_t nrx_ofdm_demodulate_f32o64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
+                                   int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
+                                   const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream);
+int32_t nrx_ofdm_demodulate_awgn_f32o64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off,
+                                        int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft,
+                                        const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride,
+                                        uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids,
+                                        void* grid, void* stream);
 /* Grid.precode (wideband F, grid.py:505-516) fused into the modulator's load: layers (n_items, n_layers, n_sym, K),
  * f: per item (f_stride = n_ports*n_layers) or shared (f_stride = 0) n_ports x n_layers; wave rows = item*n_ports+port.
  * Same arithmetic as nrx_precode_* followed by nrx_ofdm_modulate_*; the precoded grid is never materialised.

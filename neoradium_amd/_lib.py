@@ -75,6 +75,9 @@ for _t in ('f32', 'f64'):
                                                  i64, vp, vp, vp]),
         'nrx_chest_ls_' + _t: (i32, [vp, vp, vp, vp, _i32p, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     })
+SIGNATURES['nrx_ofdm_demodulate_f32o64'] = (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, f64, vp, vp])
+SIGNATURES['nrx_ofdm_demodulate_awgn_f32o64'] = (i32, [vp, i64, i64, vp, i32, i32, i32, i32, i32, _i32p, i32, vp, i32, u64_, u64_,
+                                                      i64, vp, vp, vp])
 for _t in ('f32', 'f64', 'f64o32'):
     SIGNATURES['nrx_qam_demap_' + _t] = (i32, [vp, i64, vp, vp, i32, vp, i32, vp, i32, vp, i64, i32, i32, f64, vp])
     SIGNATURES['nrx_qam_demap_cb_' + _t] = (i32, [vp, i64, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp, i64, i32, f64, vp])

@@ -126,11 +126,11 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
 // No-window variant is the same kernel with w = 0 (tail/head loops vanish).
 
 // One FFT per (item, antenna, symbol); workgroups loop over tasks so the twiddle table is built once.
-template <typename T>
+template <typename T, typename TO = T>       // TO: element type of the grid written (float32 transform, float64 grid: _f32o64)
 __global__ void __launch_bounds__(256, 2)   // two 68 KB workgroups per CU = two waves per SIMD: 256 registers each
 ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t wave_len,
                   const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
-                  cx<T>* __restrict__ grid, int n_tasks, const cx<double>* __restrict__ tw,
+                  cx<TO>* __restrict__ grid, int n_tasks, const cx<double>* __restrict__ tw,
                   const T* __restrict__ sigma, int sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset,
                   const int64_t* __restrict__ item_ids, double cp_offset_ratio) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -195,11 +195,12 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
     nrx::fft_dif_lds(buf, tw, nfft, log2n, false);
 #endif
     OFDM_STAMP(10);
-    cx<T>* dst = grid + ((size_t)row * g.n_sym + l) * K;
+    cx<TO>* dst = grid + ((size_t)row * g.n_sym + l) * K;
 #pragma unroll 4
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
       const int q = (k - K / 2 + nfft) & (nfft - 1);  // fftshift + centre K bins (waveform.py:514-520)
-      dst[k] = buf[nrx::fft_idx(nrx::fft_bitrev(q, log2n))];
+      const cx<T> v = buf[nrx::fft_idx(nrx::fft_bitrev(q, log2n))];
+      dst[k] = cx<TO>((TO)v.re, (TO)v.im);
     }
 #ifdef NRX_OFDM_PROBE
     OFDM_STAMP(11);
@@ -398,7 +399,7 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
   return NRX_OK;
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride,
                     int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym,
                     void* grid, void* stream, const void* sigma = nullptr, int32_t sigma_stride = 0, uint64_t seed = 0,
@@ -420,11 +421,11 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
   const cx<double>* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_ofdm_demodulate: FFT twiddle table unavailable");
   const size_t lds = sizeof(cx<T>) * nrx::fft_lds_elems((size_t)nfft);
-  auto kern = ofdm_demod_kernel<T>;
+  auto kern = ofdm_demod_kernel<T, TO>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid_dim = n_tasks < 4096 ? n_tasks : 4096;
   hipLaunchKernelGGL(kern, dim3(grid_dim), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)wave, wave_stride, wave_len,
-                     t_off, t_off_stride, n_ant, K, nfft, ilog2(nfft), g, (cx<T>*)grid, n_tasks, tw, (const T*)sigma,
+                     t_off, t_off_stride, n_ant, K, nfft, ilog2(nfft), g, (cx<TO>*)grid, n_tasks, tw, (const T*)sigma,
                      sigma_stride, seed, stream_id, batch_offset, item_ids, cp_offset_ratio);
   NRX_CHECK_LAUNCH("nrx_ofdm_demodulate");
   return NRX_OK;
@@ -433,6 +434,9 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
 }  // namespace
 
 extern "C" int32_t nrx_ofdm_demodulate_awgn_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset, item_ids); }
+// float32 waveform and transform, complex128 grid out (the float32 waveform chain hands over to the float64 estimator here)
+extern "C" int32_t nrx_ofdm_demodulate_awgn_f32o64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<float, double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset, item_ids); }
+extern "C" int32_t nrx_ofdm_demodulate_f32o64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream) { return demod_entry<float, double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, nullptr, 0, 0, 0, 0, nullptr, cp_offset_ratio); }
 extern "C" int32_t nrx_ofdm_demodulate_awgn_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, const void* sigma, int32_t sigma_stride, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids, void* grid, void* stream) { NRX_REQUIRE(sigma, NRX_E_ARG, "nrx_ofdm_demodulate_awgn: NULL sigma"); return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, sigma, sigma_stride, seed, stream_id, batch_offset, item_ids); }
 extern "C" int32_t nrx_ofdm_modulate_f32(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<float>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }
 extern "C" int32_t nrx_ofdm_modulate_f64(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, int32_t window_len, void* wave, int64_t wave_stride, void* stream) { return mod_entry<double>(grid, n_rows, K, nfft, cp_lens, n_sym, window_len, wave, wave_stride, stream); }

@@ -444,11 +444,10 @@ class PdschLink:
                 _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=mult, nv_mult=float(self.nfft),
                                                gather=self._cp_gather(sis, ry.shape[-1]))
             if noise is not None:
-                rxg = ops.ofdm_demodulate(ops.add_noise(ry, noise.to(dev), sigma), self.nfft, cps, self.K, t_off=off)
+                rxg = ops.ofdm_demodulate(ops.add_noise(ry, noise.to(dev), sigma), self.nfft, cps, self.K, t_off=off, grid64=True)
             else:       # the noise is generated while the demodulator loads its samples (= ops.awgn, then demodulate)
-                rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off, awgn=(sigma, seed, 2, int(slots[0]), ids))
-            if rxg.dtype != torch.complex128:       # waveform="f32": the estimator / equaliser / demapper run in float64
-                rxg = rxg.to(torch.complex128)
+                rxg = ops.ofdm_demodulate(ry, self.nfft, cps, self.K, t_off=off, awgn=(sigma, seed, 2, int(slots[0]), ids),
+                                          grid64=True)     # (waveform="f32": the estimator / equaliser / demapper run in float64)
 
         # ---- Rx
         hest = None

@@ -659,12 +659,16 @@ def ofdm_modulate(grid, nfft, cp_lens, window_len=0, pad=0, f=None):
     return wave
 
 
-def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None, cp_offset_ratio=0.5):
+def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None, cp_offset_ratio=0.5, grid64=False):
     """Waveform.sync(t_off).ofdmDemodulate: (n,Nr,S_in) -> (n,Nr,L,K).
 
-    ``awgn`` = (sigma, seed, stream_id, batch_offset[, item_ids]): add the noise of :func:`awgn` while loading (same values)."""
+    ``awgn`` = (sigma, seed, stream_id, batch_offset[, item_ids]): add the noise of :func:`awgn` while loading (same values).
+    ``grid64`` with a complex64 waveform: float32 transform, complex128 grid (the values of ``.to(complex128)`` afterwards)."""
     wave = wave.contiguous()
     sfx, _ = _ct(wave)
+    out64 = bool(grid64) and wave.dtype == torch.complex64
+    if out64:
+        sfx = 'f32o64' 
     n, nr, S_in = wave.shape
     L = len(cp_lens)
     dev = _dev(wave)
@@ -673,7 +677,7 @@ def ofdm_demodulate(wave, nfft, cp_lens, K, t_off=None, awgn=None, cp_offset_rat
         to = to.reshape(-1)
         if to.numel() not in (1, n):
             raise ValueError("one timing offset per batch item expected")
-    grid = torch.empty((n, nr, L, K), dtype=wave.dtype, device=dev)
+    grid = torch.empty((n, nr, L, K), dtype=torch.complex128 if out64 else wave.dtype, device=dev)
     if awgn is not None:
         if cp_offset_ratio != 0.5:
             raise ValueError("the fused AWGN + demodulation entry uses cpOffsetRatio = 0.5")

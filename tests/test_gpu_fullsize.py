@@ -73,6 +73,15 @@ def test_ofdm_round_trip_and_filter_linearity(link, dev):
     assert w.shape[-1] == link.slot_len[0] == 61440
     y = ops.ofdm_demodulate(w, 4096, cps, 3276)
     assert float((y - x).abs().max()) <= 1e-12 * float(x.abs().max())
+    # float32 waveform chain: complex64 modulator / demodulator to float32 accuracy, and the demodulator's complex128 output
+    # option (float32 transform, float64 grid: the hand-over to the float64 estimator) = the complex64 grid converted
+    w32 = ops.ofdm_modulate(x.to(torch.complex64), 4096, cps, window_len=0)
+    y32 = ops.ofdm_demodulate(w32, 4096, cps, 3276)
+    assert y32.dtype == torch.complex64 and float((y32.to(torch.complex128) - x).abs().max()) <= 2e-5 * float(x.abs().max())
+    assert torch.equal(ops.ofdm_demodulate(w32, 4096, cps, 3276, grid64=True), y32.to(torch.complex128))
+    sg = torch.tensor([0.1, 0.2], dtype=torch.float64, device=dev)
+    assert torch.equal(ops.ofdm_demodulate(w32, 4096, cps, 3276, awgn=(sg, 5, 2, 7), grid64=True),
+                       ops.ofdm_demodulate(w32, 4096, cps, 3276, awgn=(sg, 5, 2, 7)).to(torch.complex128))
     times = torch.from_numpy(link.gain_times(np.arange(2))).to(dev)
     gains = ops.cdl_gains(link.A, link.nu, times, A_los=link.Alos, nu_los=link.nulos)
     sl = [int(v) for v in link.sym_lens[0]]
