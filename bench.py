@@ -255,6 +255,8 @@ def main():
     ap.add_argument('--snr', type=float, default=31.0)
     ap.add_argument('--decoder', default='f64', choices=['f32', 'f64'],
                     help="f64 (default): the reference's arithmetic end to end; f32: float32 LLRs + decoder (fast mode)")
+    ap.add_argument('--waveform', default='f64', choices=['f32', 'f64'],
+                    help="f32: complex64 waveform chain (with --decoder f32 = the fast_mode.f32_waveform figure as the main line; never the default)")
     ap.add_argument('--no-cpu', action='store_true', help="skip the CPU-oracle baseline leg")
     ap.add_argument('--no-fast', action='store_true', help="skip the extra float32 fast-mode measurement")
     ap.add_argument('--no-allrows', action='store_true', help="skip the extra all-46-rows measurement")
@@ -284,7 +286,7 @@ def main():
 
     import neoradium_amd as nr
     from neoradium_amd import ops
-    link = StubLink() if args.stub else build_link(nr, decoder=args.decoder)
+    link = StubLink() if args.stub else build_link(nr, decoder=args.decoder, **({'waveform': 'f32'} if args.waveform == 'f32' else {}))
     B, K, W = args.batch, args.steps, args.warmup
     dev = link.dev
     slot_base = rank * (K + W) * B                        # disjoint slot ranges per rank (weak scaling)
@@ -355,7 +357,8 @@ def main():
             "metric": "PDSCH slots/sec at 273 PRB 64-QAM 4x4 LDPC-BG1; BLER match vs CPU ref",
             "value": slots / dt, "unit": "slots/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if f64 else "f64 front end (grid/OFDM/channel/equaliser) + f32 LLR/LDPC decode",
+            "dtype": "f64" if f64 else ("f64 front end (grid/OFDM/channel/equaliser) + f32 LLR/LDPC decode" if args.waveform == 'f64' else
+                                        "f32 waveform chain (grid/OFDM/channel), f64 estimator/equaliser/demapper, f32 LLR/LDPC decode"),
             "data": "synthetic",
             "config": {"workload": WORKLOAD, "slots_per_step_per_gpu": B, "snr_db": args.snr,
                        "sharding": "slot ranges per rank, 1 all-reduce"},
