@@ -265,8 +265,8 @@ int32_t nrx_qam_demap_cb_f64o32(const void* syms, int64_t sym_stride, const void
 /* The demapper whose stores do the whole rate recovery of a FIRST transmission (ldpc.py:1330-1418 with rv 0 and no wrap-around
  * repetition, i.e. E_r <= N - F for every block; NRX_E_UNSUPPORTED otherwise): llr = the (n_batch * C, N) buffer
  * nrx_ldpc_rate_recover_* would write from nrx_qam_demap_*'s output -- transmitted positions from the symbols, zeros behind them,
- * LARGE_LLR on the fillers -- for the first n_cols columns (n_cols * Zc positions) of the punctured code word; what lies behind
- * is left untouched, so pass at least the columns the decoder reads (20 + the rows of the instantiation that runs on BG1). */
+ * LARGE_LLR on the fillers -- for the first n_cols columns (n_cols * Zc positions) of the punctured code word; behind them only
+ * the transmitted positions are written, so pass at least the columns the decoder reads (20 + the rows of the instantiation that runs on BG1). */
 int32_t nrx_qam_demap_rr_f32(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,
                              int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym,
                              const nrx_ldpc_cfg* cfg, int32_t n_layers, int32_t n_cols, void* llr, int32_t n_batch,

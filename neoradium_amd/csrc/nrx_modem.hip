@@ -527,7 +527,7 @@ NRX_DEMAP_CB(nrx_qam_demap_cb_f64, double, double)
 NRX_DEMAP_CB(nrx_qam_demap_cb_f64o32, double, float)
 // The demapper whose stores do the whole rate recovery of a FIRST transmission (rv 0, no wrap-around repetition: E_r <= N - F
 // for every block): llr = the (n_batch * C, N) buffer nrx_ldpc_rate_recover_* would write, columns [0, n_cols) of the punctured
-// code word only (n_cols * Zc positions; what lies behind is left untouched -- pass the columns the decoder will read).
+// code word only (n_cols * Zc positions; behind them only transmitted positions are written -- pass the columns the decoder will read).
 #define NRX_DEMAP_RR(NAME, T, TL)                                                                                  \
   extern "C" int32_t NAME(const void* syms, int64_t sym_stride, const void* scales, const void* noise_var,         \
                           int32_t nv_stride, const uint8_t* scr, int32_t qm, const int32_t* re_index, int32_t n_sym, \

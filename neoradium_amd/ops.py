@@ -484,12 +484,14 @@ def qam_demap(syms, noise_var, qm, n_sym=None, scr=None, re_index=None, scales=N
     elif llr_dtype != rt:
         raise ValueError("unsupported LLR dtype for this input type")
     if rate_recovered is not None:
-        # (cfg, n_layers, n_cols): the demapper's stores do the rate recovery of a first transmission (nrx_qam_demap_rr_*) ->
+        # (cfg, n_layers, n_cols[, out]): the demapper's stores do the rate recovery of a first transmission (nrx_qam_demap_rr_*) ->
         # (n * C, N), columns [0, n_cols) of the punctured code word initialised; None when E_r wraps around the buffer
-        cfg, n_layers, n_cols = rate_recovered
+        cfg, n_layers, n_cols = rate_recovered[:3]
         if exact:
             raise ValueError("rate_recovered: max-log LLRs only")
-        out = torch.empty((n * cfg.C, cfg.N), dtype=llr_dtype, device=dev)
+        out = rate_recovered[3] if len(rate_recovered) > 3 else torch.empty((n * cfg.C, cfg.N), dtype=llr_dtype, device=dev)
+        if out.shape != (n * cfg.C, cfg.N) or out.dtype != llr_dtype or not out.is_contiguous() or out.device != dev:
+            raise ValueError("rate_recovered: the output buffer must be a contiguous (n * C, N) tensor of the LLR type")
         rc = getattr(lib(), 'nrx_qam_demap_rr_' + sfx)(ptr(flat), E, ptr(sc), ptr(nv), 0 if nv.numel() == 1 else 1, ptr(scr_t), qm, ptr(ri),
                                                        n_sym, C.byref(cfg), int(n_layers), int(n_cols), ptr(out), n, float(nv_floor), stream())
         if rc == -3:                 # NRX_E_UNSUPPORTED

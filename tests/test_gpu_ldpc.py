@@ -388,6 +388,20 @@ def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_e
                 got = ops.qam_demap(sy.to(dt_in), 0.3, qm_, llr_dtype=dt_out, rate_recovered=(c_, nl_, n_cols))
                 assert got.shape == want.shape and got.dtype == want.dtype
                 assert torch.equal(got[:, :n_cols * c_.Zc], want[:, :n_cols * c_.Zc]), (c_.Zc, c_.F, dt_in, dt_out, n_cols)
+    # ops.ldpc_rows_read names the columns the decoder entries read for a row count: decoding the partially initialised buffer
+    # (everything behind those columns poisoned) gives the bits of the full one
+    sy = torch.from_numpy(rng.standard_normal((2, n_sym)) + 1j * rng.standard_normal((2, n_sym))).to(dev) * 0.3 + \
+        torch.from_numpy(rng.choice([-1.0, 1.0], (2, n_sym)) + 1j * rng.choice([-1.0, 1.0], (2, n_sym))).to(dev) * 0.46
+    for dt_out in (torch.float32, torch.float64):
+        full = ops.ldpc_rate_recover(ops.qam_demap(sy, 0.05, qm, llr_dtype=dt_out), cfg, nl, qm)
+        for r_ in (4, 13, 14, 15, 16, 17, 22, 23, 31, 32, 46):
+            n_cols = min(cfg.N // cfg.Zc, cfg.K // cfg.Zc - 2 + ops.ldpc_rows_read(cfg, r_, dt_out == torch.float32))
+            part = torch.full((2 * cfg.C, cfg.N), float('nan'), dtype=dt_out, device=dev)
+            assert ops.qam_demap(sy, 0.05, qm, llr_dtype=dt_out, rate_recovered=(cfg, nl, n_cols, part)) is part
+            assert not bool(torch.isnan(part[:, :n_cols * cfg.Zc]).any())
+            e_max = max(lens) + cfg.F          # behind the columns asked for only transmitted positions are written
+            assert n_cols * cfg.Zc >= min(e_max, cfg.N) or bool(torch.isnan(part[:, max(e_max, n_cols * cfg.Zc):]).all())
+            assert torch.equal(ops.ldpc_decode(part, cfg, 6, rows=r_), ops.ldpc_decode(full, cfg, 6, rows=r_)), (dt_out, r_)
     # repetition (E_r beyond the circular buffer) is declined, not approximated
     c3 = _lib.ldpc_config(2, 300)
     sy = torch.zeros((1, 2 * c3.N // 2), dtype=torch.complex128, device=dev)
