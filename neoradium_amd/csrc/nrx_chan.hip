@@ -310,7 +310,7 @@ extern "C" int32_t nrx_debug_td_probe(unsigned long long* out3) {
   return hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_td_probe), sizeof(unsigned long long) * 3) == hipSuccess ? 0 : -4;
 }
 #endif
-template <int NR>
+template <int NR, bool FLAT = false>      // FLAT: the groups share the (antenna, path) terms round robin (Nt not a multiple of GROUPS)
 __global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS, 4)   // four waves per SIMD (two workgroups per CU): <= 128 VGPRs
 apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ gains1, int n_paths,
                        const double* __restrict__ taps, const int32_t* __restrict__ tap_off, int hist, TdGeom g,
@@ -351,17 +351,27 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
   const cd* gb = gains1 + ((size_t)b * g.n_sets + set) * NR * nt * n_paths;
   if (n < n_end) {
     const char* xl = (const char*)(xs + ts);          // the thread's cell of sub-array 0 of antenna 0
-    for (int t = grp; t < nt; t += TDP_GROUPS) {
-      for (int p = 0; p < n_paths; ++p) {
-        const int u = hist - tap_off[p] - (TDP_FLEN - 1);   // window element m is sample  R*ts + u + m  of the tile
-        const double* c = taps + (size_t)p * TDP_FLEN;
-        // byte offsets (wave-uniform) of window elements 0..3: sub-array (u + k) & 3, cell (u + k) >> 2
-        const int o0 = ((t * R + ((u + 0) & 3)) * Q + ((u + 0) >> 2)) * (int)sizeof(cd);
-        const int o1 = ((t * R + ((u + 1) & 3)) * Q + ((u + 1) >> 2)) * (int)sizeof(cd);
-        const int o2 = ((t * R + ((u + 2) & 3)) * Q + ((u + 2) >> 2)) * (int)sizeof(cd);
-        const int o3 = ((t * R + ((u + 3) & 3)) * Q + ((u + 3) >> 2)) * (int)sizeof(cd);
-        const cd* gv = gb + (size_t)t * n_paths + p;
-        tdp4_term<NR>(xl + o0, xl + o1, xl + o2, xl + o3, c, gv, nt * n_paths, ar, ai);
+    auto term = [&](int t, int p) __attribute__((always_inline)) {
+      const int u = hist - tap_off[p] - (TDP_FLEN - 1);   // window element m is sample  R*ts + u + m  of the tile
+      const double* c = taps + (size_t)p * TDP_FLEN;
+      // byte offsets (wave-uniform) of window elements 0..3: sub-array (u + k) & 3, cell (u + k) >> 2
+      const int o0 = ((t * R + ((u + 0) & 3)) * Q + ((u + 0) >> 2)) * (int)sizeof(cd);
+      const int o1 = ((t * R + ((u + 1) & 3)) * Q + ((u + 1) >> 2)) * (int)sizeof(cd);
+      const int o2 = ((t * R + ((u + 2) & 3)) * Q + ((u + 2) >> 2)) * (int)sizeof(cd);
+      const int o3 = ((t * R + ((u + 3) & 3)) * Q + ((u + 3) >> 2)) * (int)sizeof(cd);
+      const cd* gv = gb + (size_t)t * n_paths + p;
+      tdp4_term<NR>(xl + o0, xl + o1, xl + o2, xl + o3, c, gv, nt * n_paths, ar, ai);
+    };
+    if constexpr (!FLAT) {           // a group takes whole transmit antennas
+      for (int t = grp; t < nt; t += TDP_GROUPS)
+        for (int p = 0; p < n_paths; ++p) term(t, p);
+    } else {
+      // fewer (or not a multiple of GROUPS) transmit antennas -- SISO, two layers: the groups share the (antenna, path) terms
+      // round robin instead, or all but nt of them would idle (cfg1: 7.3 ms of a 13.8 ms step with three groups idle)
+      const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)n_paths - 1) / (uint32_t)n_paths);   // q / n_paths = umulhi(q, magic) for q * n_paths < 2^32
+      for (int q = grp; q < nt * n_paths; q += TDP_GROUPS) {
+        const int t = (int)__umulhi((uint32_t)q, magic);
+        term(t, q - t * n_paths);
       }
     }
   }
@@ -483,7 +493,7 @@ __device__ __forceinline__ void tdp4f_term(const char* __restrict__ q0, const ch
   }
 }
 
-template <int NR>
+template <int NR, bool FLAT = false>
 __global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS, 4)
 apply_td_paths4f_kernel(const f2* __restrict__ x, int nt, int64_t ns, const f2* __restrict__ gains1, int n_paths,
                         const float* __restrict__ taps, const int32_t* __restrict__ tap_off, int hist, TdGeom g,
@@ -519,15 +529,23 @@ apply_td_paths4f_kernel(const f2* __restrict__ x, int nt, int64_t ns, const f2* 
   const f2* gb = gains1 + ((size_t)b * g.n_sets + set) * NR * nt * n_paths;
   if (n < n_end) {
     const char* xl = (const char*)(xs + ts);
-    for (int t = grp; t < nt; t += TDP_GROUPS) {
-      for (int p = 0; p < n_paths; ++p) {
-        const int u = hist - tap_off[p] - (TDP_FLEN - 1);
-        const float* c = taps + (size_t)p * TDP_FLEN;
-        const int o0 = ((t * R + ((u + 0) & 3)) * Q + ((u + 0) >> 2)) * (int)sizeof(f2);
-        const int o1 = ((t * R + ((u + 1) & 3)) * Q + ((u + 1) >> 2)) * (int)sizeof(f2);
-        const int o2 = ((t * R + ((u + 2) & 3)) * Q + ((u + 2) >> 2)) * (int)sizeof(f2);
-        const int o3 = ((t * R + ((u + 3) & 3)) * Q + ((u + 3) >> 2)) * (int)sizeof(f2);
-        tdp4f_term<NR>(xl + o0, xl + o1, xl + o2, xl + o3, c, gb + (size_t)t * n_paths + p, nt * n_paths, acc);
+    auto term = [&](int t, int p) __attribute__((always_inline)) {
+      const int u = hist - tap_off[p] - (TDP_FLEN - 1);
+      const float* c = taps + (size_t)p * TDP_FLEN;
+      const int o0 = ((t * R + ((u + 0) & 3)) * Q + ((u + 0) >> 2)) * (int)sizeof(f2);
+      const int o1 = ((t * R + ((u + 1) & 3)) * Q + ((u + 1) >> 2)) * (int)sizeof(f2);
+      const int o2 = ((t * R + ((u + 2) & 3)) * Q + ((u + 2) >> 2)) * (int)sizeof(f2);
+      const int o3 = ((t * R + ((u + 3) & 3)) * Q + ((u + 3) >> 2)) * (int)sizeof(f2);
+      tdp4f_term<NR>(xl + o0, xl + o1, xl + o2, xl + o3, c, gb + (size_t)t * n_paths + p, nt * n_paths, acc);
+    };
+    if constexpr (!FLAT) {
+      for (int t = grp; t < nt; t += TDP_GROUPS)
+        for (int p = 0; p < n_paths; ++p) term(t, p);
+    } else {      // (see the float64 kernel)
+      const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)n_paths - 1) / (uint32_t)n_paths);   // q / n_paths = umulhi(q, magic) for q * n_paths < 2^32
+      for (int q = grp; q < nt * n_paths; q += TDP_GROUPS) {
+        const int t = (int)__umulhi((uint32_t)q, magic);
+        term(t, q - t * n_paths);
       }
     }
   }
@@ -1288,11 +1306,13 @@ static int32_t apply_td_paths_impl(const void* x, int32_t n_items, int32_t n_tx,
         NRX_REQUIRE(pow_capacity >= need, NRX_E_SHAPE, "nrx_apply_td_paths_pow: pow_acc needs %lld doubles", (long long)need);
         *n_part = (int32_t)(grid4.x * (TDP_TILE / 64));
       }
+#define NRX_TDP4_LAUNCH(NR, FL)                                                                                           \
+    (void)hipFuncSetAttribute((const void*)apply_td_paths4_kernel<NR, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
+    hipLaunchKernelGGL((apply_td_paths4_kernel<NR, FL>), grid4, dim3(TDP_TILE * TDP_GROUPS), lds4, st, (const cd*)x, n_tx, ns, \
+                       (const cd*)gains1, n_paths, taps, tap_off, hist4, g4, (cd*)y, pow_acc, pow_nfft)
 #define NRX_TDP4_CASE(NR)                                                                                                  \
   case NR:                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)apply_td_paths4_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
-    hipLaunchKernelGGL(apply_td_paths4_kernel<NR>, grid4, dim3(TDP_TILE * TDP_GROUPS), lds4, st, (const cd*)x, n_tx, ns,  \
-                       (const cd*)gains1, n_paths, taps, tap_off, hist4, g4, (cd*)y, pow_acc, pow_nfft);                   \
+    if (n_tx % TDP_GROUPS == 0) { NRX_TDP4_LAUNCH(NR, false); } else { NRX_TDP4_LAUNCH(NR, true); }                        \
     break;
       switch (n_rx) {
         NRX_TDP4_CASE(1)
@@ -1300,6 +1320,7 @@ static int32_t apply_td_paths_impl(const void* x, int32_t n_items, int32_t n_tx,
         NRX_TDP4_CASE(4)
       }
 #undef NRX_TDP4_CASE
+#undef NRX_TDP4_LAUNCH
       NRX_CHECK_LAUNCH("nrx_apply_td_paths");
       return NRX_OK;
     }
@@ -1387,11 +1408,13 @@ extern "C" int32_t nrx_apply_td_paths_pow_f32(const void* x, int32_t n_items, in
     *n_part = (int32_t)(grid4.x * (TDP_TILE / 64));
   }
   hipStream_t st = (hipStream_t)stream;
+#define NRX_TDP4F_LAUNCH(NR, FL)                                                                                          \
+    (void)hipFuncSetAttribute((const void*)apply_td_paths4f_kernel<NR, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
+    hipLaunchKernelGGL((apply_td_paths4f_kernel<NR, FL>), grid4, dim3(TDP_TILE * TDP_GROUPS), lds4, st, (const f2*)x, n_tx, ns, \
+                       (const f2*)gains1, n_paths, taps, tap_off, hist4, g, (f2*)y, pow_acc, nfft)
 #define NRX_TDP4F_CASE(NR)                                                                                                 \
   case NR:                                                                                                                 \
-    (void)hipFuncSetAttribute((const void*)apply_td_paths4f_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
-    hipLaunchKernelGGL(apply_td_paths4f_kernel<NR>, grid4, dim3(TDP_TILE * TDP_GROUPS), lds4, st, (const f2*)x, n_tx, ns,  \
-                       (const f2*)gains1, n_paths, taps, tap_off, hist4, g, (f2*)y, pow_acc, nfft);                        \
+    if (n_tx % TDP_GROUPS == 0) { NRX_TDP4F_LAUNCH(NR, false); } else { NRX_TDP4F_LAUNCH(NR, true); }                      \
     break;
   switch (n_rx) {
     NRX_TDP4F_CASE(1)
@@ -1399,6 +1422,7 @@ extern "C" int32_t nrx_apply_td_paths_pow_f32(const void* x, int32_t n_items, in
     NRX_TDP4F_CASE(4)
   }
 #undef NRX_TDP4F_CASE
+#undef NRX_TDP4F_LAUNCH
   NRX_CHECK_LAUNCH("nrx_apply_td_paths_pow_f32");
   return NRX_OK;
 }
