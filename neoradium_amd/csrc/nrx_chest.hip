@@ -196,10 +196,24 @@ chest_polar_prep_kernel(const cd* __restrict__ rx, const cd* __restrict__ pilots
   const int n_j = g.n_k / g.k_cdm, n_g = g.n_ds / g.l_cdm, cdm = g.l_cdm * g.k_cdm;
   const int64_t total = (int64_t)n_batch * n_g * g.nr * g.P * n_j;
   for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * blockDim.x) {
-    const int j = (int)(gi % n_j);
-    const int64_t row = gi / n_j;
-    const int p = (int)(row % g.P), r = (int)((row / g.P) % g.nr), tg = (int)((row / ((int64_t)g.P * g.nr)) % n_g);
-    const int b = (int)(row / ((int64_t)g.P * g.nr * n_g));
+    int j, p, r, tg, b;
+    if (total < (1ll << 31)) {           // 32-bit index arithmetic where it fits (a 64-bit division is ~100 instructions)
+      const uint32_t g32 = (uint32_t)gi;
+      uint32_t row = g32 / (uint32_t)n_j;
+      j = (int)(g32 - row * (uint32_t)n_j);
+      uint32_t q = row / (uint32_t)g.P;
+      p = (int)(row - q * (uint32_t)g.P);
+      row = q;
+      q = row / (uint32_t)g.nr;
+      r = (int)(row - q * (uint32_t)g.nr);
+      b = (int)(q / (uint32_t)n_g);
+      tg = (int)(q - (uint32_t)b * (uint32_t)n_g);
+    } else {
+      j = (int)(gi % n_j);
+      const int64_t row = gi / n_j;
+      p = (int)(row % g.P), r = (int)((row / g.P) % g.nr), tg = (int)((row / ((int64_t)g.P * g.nr)) % n_g);
+      b = (int)(row / ((int64_t)g.P * g.nr * n_g));
+    }
     const int32_t* ks = port_ks + (size_t)p * g.n_k;
     const cd* pil = pilots + ((size_t)(pil_set ? pil_set[b] : 0) * g.P + p) * g.n_ds * g.n_k;
     const cd* rxb = rx + ((size_t)b * g.nr + r) * g.L * g.K;
