@@ -415,7 +415,7 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
                                       int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes,
                                       const int32_t* sel, const int32_t* n_sel);  // nrx_ldpc_dec3.hip
 int32_t nrx_ldpc_decode_chipz_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter,
-                                     int32_t n_rows, uint8_t* hard, hipStream_t st);   // nrx_ldpc_dec4.hip
+                                     int32_t n_rows, uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes);   // nrx_ldpc_dec4.hip
 namespace {
 
 template <typename T, bool EXACT>
@@ -464,7 +464,7 @@ int32_t decode_entry(const T* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_
   if constexpr (EXACT) {
     // ... any other lifting size, either base graph, <= 15 rows: the on-chip kernel with the lifting size at run time
     if (hard && !belief && out_cols == cfg->K) {
-      const int32_t rc = nrx_ldpc_decode_chipz_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream);
+      const int32_t rc = nrx_ldpc_decode_chipz_launch((const double*)llr, n_cb, cfg, n_iter, n_rows, hard, (hipStream_t)stream, ws, ws_bytes);
       if (rc != 1) return rc;      // 1 = more rows than fit on chip: workspace kernel below
     }
   }

@@ -143,13 +143,20 @@ __device__ __forceinline__ void sel_fma_first(double& x, uint32_t& idx, uint64_t
 }
 #define LAYER_PRIO(Q) __builtin_amdgcn_s_setprio(3 - (Q))
 
-template <int BG, int RA>
+// RC = rows whose check-node state stays in registers (default: all RA of them).  RC < RA: the HYBRID of nrx_ldpc_dec3.hip at a
+// run-time lifting size -- the rows >= RC (the sparse ones) keep pm1 / pm2 / extension posterior in the caller's workspace,
+// [workgroup][slot][row - RC][3][ZS] doubles, read PF streamed layers ahead into a register ring (slot (L - RC) mod PF, hence
+// RA - RC a multiple of PF) and written back when the layer has them; sign / argmin words of all rows stay in registers.
+template <int BG, int RA, int RC = RA>
 __global__ void __launch_bounds__(768, 3)
 ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint8_t* __restrict__ hard, ztab_t tab, int zc,
-                      int rows_live) {
+                      int rows_live, double* __restrict__ ws) {
   using B = GR<BG, RA>;
   using Y = Lay<BG, RA>;
   static_assert(Y::plan_rot.ok, "barrier placement leaves a column hazard");
+  constexpr bool HYB = RC < RA;
+  constexpr int PF = 2;                                    // streamed layers fetched ahead
+  static_assert(!HYB || (RC >= 4 && RA - RC > PF && (RA - RC) % PF == 0), "the ring slot of a streamed layer is (L - RC) mod PF in every iteration");
   extern __shared__ __attribute__((aligned(16))) double Praw[];     // [ZS padding][NS][CORE][ZS]
   const int ZS = (zc + 63) & ~63;
   const int NS = 12 / (ZS >> 6);
@@ -168,8 +175,19 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
   const bool lane_ok = z < zc;
   constexpr int NEXT = Y::n_ext() > 0 ? Y::n_ext() : 1;
 
-  double m1[B::ROWS], m2[B::ROWS];
+  double m1[RC], m2[RC];
   double rext[NEXT];
+  double pf_m1[PF] = {}, pf_m2[PF] = {}, pf_rx[PF] = {};
+  typedef double __attribute__((address_space(1))) * gD;
+  const uint32_t zs8 = 8u * (uint32_t)ZS;
+  char* wsb = nullptr;                                     // this slot's streamed state
+  if constexpr (HYB) wsb = (char*)ws + ((size_t)blockIdx.x * NS + slot) * (size_t)(RA - RC) * 3 * zs8;
+  // (uniform base + uniform offset) made an opaque SGPR pair first: `global_load/store v, v_lane_offset, s[base]`
+  auto wsL = [&](int L, int a, uint32_t lane_off) __attribute__((always_inline)) -> gD {
+    char* b = wsb + (size_t)((L - RC) * 3 + a) * zs8;
+    asm volatile("" : "+s"(b));
+    return (gD)(b + (size_t)lane_off);
+  };
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
   uint32_t sgn[(Y::n_narrow() + 1) / 2];
   u32x2 uv = {0u, 0u};
@@ -197,7 +215,7 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
         else if constexpr (c >= 2) Ps[c * ZS + zq] = fetch((c - 2) * zc, 0);
       });
     }
-    static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
+    static_for<RC>([&](auto lc) __attribute__((always_inline)) {
       constexpr int L = decltype(lc)::value;
       m1[L] = 0.0;
       m2[L] = 0.0;
@@ -206,10 +224,32 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
         rext[Y::ext_idx(L)] = L < rows_live ? rext[Y::ext_idx(L)] : 0.0;
       }
     });
+    if constexpr (HYB) {       // streamed rows: zero minima, the extension LLR (or 0 beyond the rows that run) straight to the workspace
+      const uint32_t zo8 = 8u * (uint32_t)zq;
+      static_for<RA - RC>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int L = RC + decltype(lc)::value;
+        *wsL(L, 0, zo8) = 0.0;
+        *wsL(L, 1, zo8) = 0.0;
+        if constexpr (Y::has_ext(L)) {
+          const double e = fetch((Y::ext_col(L) - 2) * zc, st[L]);
+          *wsL(L, 2, zo8) = L < rows_live ? e : 0.0;
+        }
+      });
+    }
     c0 = 0.0;
     static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
     static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
     __syncthreads();
+    if constexpr (HYB) {      // (the barrier above waited for the fill's stores)
+      int zr0 = z;
+      asm volatile("" : "+v"(zr0));
+      static_for<PF>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, Lk = RC + k;
+        pf_m1[k] = *wsL(Lk, 0, 8u * (uint32_t)zr0);
+        pf_m2[k] = *wsL(Lk, 1, 8u * (uint32_t)zr0);
+        if constexpr (Y::has_ext(Lk)) pf_rx[k] = *wsL(Lk, 2, 8u * (uint32_t)zr0);
+      });
+    }
 
     // wrap masks and offsets of the layer about to run (SGPRs)
     uint64_t wcur[19];
@@ -234,6 +274,21 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
         const mtab_t wml = (mtab_t)((const char __attribute__((address_space(4)))*)wm + wo_u);
         const otab_t otl = (otab_t)((const char __attribute__((address_space(4)))*)ot + wo_u);
         const uint32_t zb = zbo, zbw = zbo - zc8;
+        // hybrid, streamed layer: its state out of the ring, and the ring slot refilled with the streamed layer PF ahead (of the
+        // next iteration at the end of this one).  Outside the `live` branch: inside it the values become phis at the join.
+        double cm1 = 0.0, cm2 = 0.0, crx = 0.0;
+        uint32_t zo8 = 0;
+        if constexpr (HYB && L >= RC) {
+          constexpr int k = (L - RC) % PF;
+          constexpr int Lp = L + PF < RA ? L + PF : RC + (L + PF - RA);
+          zo8 = zbo - sb;                                   // 8 * z
+          cm1 = pf_m1[k];
+          cm2 = pf_m2[k];
+          crx = pf_rx[k];
+          pf_m1[k] = *wsL(Lp, 0, zo8);
+          pf_m2[k] = *wsL(Lp, 1, zo8);
+          if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(Lp, 2, zo8);
+        }
         if (__builtin_expect(live, 1)) {
           if (lane_ok) {
             // the wave's valid lanes.  (Read by an asm the compiler cannot see through: as ballot(true) it is a COPY of exec,
@@ -257,7 +312,8 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
               }
             });
             __builtin_amdgcn_sched_barrier(0);
-            const double om1 = m1[L], om2 = m2[L];
+            double om1, om2;
+            if constexpr (L < RC) { om1 = m1[L]; om2 = m2[L]; } else { om1 = cm1; om2 = cm2; }
             uint32_t word, oidx;
             int top;
             if constexpr (WIDE) {
@@ -271,7 +327,7 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
               top = (ni & 1) ? (31 - 20) : (31 - 4);
             }
             // ---- pass 1b: t_j = fma(-u_j, argmin ? pm2 : pm1, r_j)  (ldpc.py:1550-1553)
-            if constexpr (EXT) t[D - 1] = rext[Y::ext_idx(L)];
+            if constexpr (EXT) t[D - 1] = L < RC ? rext[Y::ext_idx(L)] : crx;
             uint32_t wrun = word << (top - (D - 1));
             static_for<D>([&](auto jc) __attribute__((always_inline)) {
               constexpr int j = decltype(jc)::value;
@@ -306,8 +362,13 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
             }
             const double c96 = c96_of(uv, nsg);
             const double nm1 = a1 * c96, nm2 = a2 * c96;
-            m1[L] = nm1;
-            m2[L] = nm2;
+            if constexpr (L < RC) {
+              m1[L] = nm1;
+              m2[L] = nm2;
+            } else {
+              *wsL(L, 0, zo8) = nm1;
+              *wsL(L, 1, zo8) = nm2;
+            }
             // ---- pass 2: r_j = fma(u_j, first argmin ? pm2 : pm1, t_j), back to the element it was read from
             uint32_t idx = 0;
             auto put = [&](auto jc2) __attribute__((always_inline)) {
@@ -321,7 +382,8 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
                 const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
                 *(double*)((char*)Praw + ((wraps ? zbw : zb) + (uint32_t)ocur[j])) = t[j];
               } else {
-                rext[Y::ext_idx(L)] = t[j];
+                if constexpr (L < RC) rext[Y::ext_idx(L)] = t[j];
+                else *wsL(L, 2, zo8) = t[j];
               }
             };
             if (__builtin_expect(!tie_quirk, 1)) {
@@ -380,7 +442,7 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
 }
 
 // device copy of the table of a (base graph, lifting size), built on first use, per device
-struct TabKey { int dev, bg, zc; };
+struct TabKey { int dev, bg, zc, ra; };
 struct TabEnt { TabKey k; ZTab* d; };
 static std::vector<TabEnt> g_tabs;
 static std::mutex g_mu;
@@ -390,7 +452,7 @@ template <int BG, int RA> static int32_t get_table(int zc, int ils, hipStream_t 
   NRX_REQUIRE(hipGetDevice(&dev) == hipSuccess, NRX_E_HIP, "nrx_ldpc_decode_f64: hipGetDevice failed");
   std::lock_guard<std::mutex> lock(g_mu);
   for (const TabEnt& e : g_tabs)
-    if (e.k.dev == dev && e.k.bg == BG && e.k.zc == zc) { *out = e.d; return NRX_OK; }
+    if (e.k.dev == dev && e.k.bg == BG && e.k.zc == zc && e.k.ra == RA) { *out = e.d; return NRX_OK; }
   ZTab* h = new ZTab();
   fill_table<BG, RA>(*h, zc, ils);
   ZTab* d = nullptr;
@@ -399,23 +461,30 @@ template <int BG, int RA> static int32_t get_table(int zc, int ils, hipStream_t 
   const hipError_t e = hipMemcpy(d, h, sizeof(ZTab), hipMemcpyHostToDevice);
   delete h;
   if (e != hipSuccess) { (void)hipFree(d); NRX_REQUIRE(false, NRX_E_HIP, "nrx_ldpc_decode_f64: table upload failed"); }
-  g_tabs.push_back({{dev, BG, zc}, d});
+  g_tabs.push_back({{dev, BG, zc, RA}, d});
   *out = d;
   return NRX_OK;
 }
 
-template <int BG, int RA>
-static int32_t launch(const double* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int n_rows, uint8_t* hard, hipStream_t st) {
-  const ZTab* tab = nullptr;
-  const int32_t rc = get_table<BG, RA>(cfg->Zc, cfg->iLS, st, &tab);
-  if (rc) return rc;
+template <int BG, int RA, int RC = RA>
+static int32_t launch(const double* llr, int n_cb, const nrx_ldpc_cfg* cfg, int n_iter, int n_rows, uint8_t* hard, hipStream_t st,
+                      void* ws = nullptr, size_t ws_bytes = 0) {
   const int zs = (cfg->Zc + 63) / 64 * 64, ns = 12 / (zs / 64);
   const size_t lds = sizeof(double) * ((size_t)zs + (size_t)ns * G<BG>::CORE * zs);
   const int n_wg = (n_cb + ns - 1) / ns;
-  const int grid = n_wg < 1024 ? n_wg : 1024;
-  auto kern = ldpc_dec_chipz_kernel<BG, RA>;
+  int grid = n_wg < 1024 ? n_wg : 1024;
+  if constexpr (RC < RA) {      // hybrid: one workgroup per CU is all that fits; its streamed state lives in the caller's workspace
+    const size_t per_wg = sizeof(double) * (size_t)(RA - RC) * 3 * (size_t)ns * zs;
+    if (grid > 256) grid = 256;
+    if (ws == nullptr || ws_bytes < per_wg) return 1;            // no workspace: the workspace kernel reports it
+    if ((size_t)grid > ws_bytes / per_wg) grid = (int)(ws_bytes / per_wg);
+  }
+  const ZTab* tab = nullptr;
+  const int32_t rc = get_table<BG, RA>(cfg->Zc, cfg->iLS, st, &tab);
+  if (rc) return rc;
+  auto kern = ldpc_dec_chipz_kernel<BG, RA, RC>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(ns * zs), lds, st, llr, n_cb, n_iter, hard, (ztab_t)tab, cfg->Zc, n_rows);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(ns * zs), lds, st, llr, n_cb, n_iter, hard, (ztab_t)tab, cfg->Zc, n_rows, (double*)ws);
   NRX_CHECK_LAUNCH("nrx_ldpc_decode_f64(on-chip, any lifting size)");
   return NRX_OK;
 }
@@ -423,11 +492,29 @@ static int32_t launch(const double* llr, int n_cb, const nrx_ldpc_cfg* cfg, int 
 }  // namespace nrx_dec4
 
 // Called by nrx_ldpc_decode_rows_f64 (nrx_ldpc_dec.hip) after nrx_ldpc_dec3.hip's Zc = 384 instantiations declined: hard decisions
-// of the K information bits with the first n_rows <= 15 rows, any lifting size.  Returns 1 when not covered (more rows).
+// of the K information bits, any lifting size.  <= 15 rows: everything on chip.  More rows: the hybrid instantiations (BG1: the
+// first 31 or all 46 rows, BG2: the first 22 or all 42; the rows beyond n_rows run as exact no-ops on zeroed extension LLRs) with
+// the sparse rows' state in the caller's workspace.  Returns 1 when not covered: the caller runs the workspace kernel.
+#ifndef NRX_DEC4_RC
+#define NRX_DEC4_RC 10
+#endif
 int32_t nrx_ldpc_decode_chipz_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
-                                     uint8_t* hard, hipStream_t st) {
+                                     uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes) {
   using namespace nrx_dec4;
-  if (getenv("NRX_LDPC_NOCHIP64") != nullptr || n_rows > 15 || n_rows < 4 || cfg->Zc < 2 || cfg->Zc > ZMAX) return 1;
+  if (getenv("NRX_LDPC_NOCHIP64") != nullptr || n_rows < 4 || cfg->Zc < 2 || cfg->Zc > ZMAX) return 1;
+  constexpr int RCH = NRX_DEC4_RC;
+  if (n_rows > 15) {
+    if (getenv("NRX_LDPC_NOHYBRID") != nullptr) return 1;
+    if (cfg->bg == 1) {
+      if (n_rows <= 31) return launch<1, 31, RCH + 1>(llr, n_cb, cfg, n_iter, n_rows, hard, st, ws, ws_bytes);
+      return launch<1, 46, RCH>(llr, n_cb, cfg, n_iter, n_rows, hard, st, ws, ws_bytes);
+    }
+    if (cfg->bg == 2) {
+      if (n_rows <= 22) return launch<2, 22, RCH>(llr, n_cb, cfg, n_iter, n_rows, hard, st, ws, ws_bytes);
+      return launch<2, 42, RCH>(llr, n_cb, cfg, n_iter, n_rows, hard, st, ws, ws_bytes);
+    }
+    return 1;
+  }
   if (cfg->bg == 1) return launch<1, 15>(llr, n_cb, cfg, n_iter, n_rows, hard, st);
   if (cfg->bg == 2) return launch<2, 15>(llr, n_cb, cfg, n_iter, n_rows, hard, st);
   return 1;

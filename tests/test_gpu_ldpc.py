@@ -506,6 +506,42 @@ def test_onchip_decoder_every_lifting_size(dev, bg):
             assert np.array_equal(o, got[:4].cpu().numpy()), (bg, zc, rows)
 
 
+@pytest.mark.parametrize("bg,zc,rows", [(1, 352, 16), (1, 352, 31), (1, 352, 46), (1, 208, 32), (1, 36, 46), (1, 2, 20),
+                                        (2, 256, 16), (2, 256, 21), (2, 256, 23), (2, 256, 42), (2, 320, 22), (2, 104, 30), (2, 13, 42)])
+def test_hybrid_decoder_at_any_lifting_size(dev, bg, zc, rows):
+    """More than 15 rows at lifting sizes other than 384 (BG2 at its usual rates, low-rate BG1 blocks): the hybrid instantiations of
+    nrx_ldpc_dec4.hip -- BG1 31 / 46 rows, BG2 22 / 42 rows, the sparse rows' state streamed through the workspace, lifting size at
+    run time, several code blocks per workgroup, partial last waves -- give the bits of the workspace kernel (NRX_LDPC_NOHYBRID,
+    read at every call) on a ragged batch with filler LLRs and exact zeros, and the oracle's bits."""
+    import os
+    import torch
+    from neoradium_amd import ops, _lib
+    from oracle import coding as oc
+    kb, ncols = (22, 68) if bg == 1 else (10, 52)
+    ils = next(i for i, b in enumerate((2, 3, 5, 7, 9, 11, 13, 15)) if zc % b == 0 and (zc // b) & (zc // b - 1) == 0)
+    cfg = _lib.LdpcCfg()
+    cfg.bg, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F, cfg.C, cfg.B, cfg.cb_len = bg, zc, ils, kb * zc, (ncols - 2) * zc, 0, 1, 0, 0
+    rng = np.random.default_rng(7000 + 100 * bg + zc + rows)
+    n_cb = 2 * (12 // -(-zc // 64)) + 1                        # two full workgroups and a lone block
+    llr = 2 / 0.9 ** 2 + (2 / 0.9) * rng.standard_normal((n_cb, cfg.N))
+    n_rx = (kb - 2 + rows) * zc - zc // 3                      # nothing received beyond the rows that run (last column partly)
+    llr[:, n_rx:] = 0.0
+    llr[rng.random(llr.shape) < 0.002] = 0.0
+    if zc >= 16:
+        llr[:, (kb - 2) * zc - zc // 3:(kb - 2) * zc] = 1e20   # fillers at the end of the information columns
+    x = torch.from_numpy(llr).to(dev)
+    assert 'NRX_LDPC_NOHYBRID' not in os.environ
+    got = ops.ldpc_decode(x, cfg, 9, rows=rows)
+    os.environ['NRX_LDPC_NOHYBRID'] = '1'
+    try:
+        ref = ops.ldpc_decode(x, cfg, 9, rows=rows)
+    finally:
+        del os.environ['NRX_LDPC_NOHYBRID']
+    assert torch.equal(got, ref)
+    o = oc.decode(llr[:2], bg, ils, zc, num_iter=9, rows=rows)
+    assert np.array_equal(o, got[:2].cpu().numpy())
+
+
 @pytest.mark.parametrize("rows", [16, 31, 32, 46])
 def test_hybrid_decoder_for_more_than_15_rows(dev, rows):
     """More than 15 rows at Zc = 384 (rates below ~0.6, HARQ retransmissions, all 46 rows): the hybrid instantiations of
