@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def build(nr, which, decoder):
+def build(nr, which, decoder, **kw):
     nr.random.setSeed(123)
     if which == 'cfg1':
         car = nr.Carrier(numRbs=25, spacing=15)
@@ -29,11 +29,11 @@ def build(nr, which, decoder):
         p = nr.PDSCH(bwp, numLayers=1, nID=car.cellId, modulation='QPSK')
         p.setDMRS(configType=1, additionalPos=1)
         ch = nr.TdlChannel(bwp, 'A', delaySpread=30, carrierFreq=4e9, dopplerShift=5)
-        return nr.PdschLink(p, ch, 0.35, baseGraphNo=2, numIter=20, freqDomain=False, chanEst="LS", decoder=decoder), \
+        return nr.PdschLink(p, ch, 0.35, baseGraphNo=2, numIter=20, freqDomain=False, chanEst="LS", decoder=decoder, **kw), \
             [0.0, 0.4, 0.8, 1.2, 1.6, 2.0]
     if which == 'metric':        # the bench configuration: 273 PRB, 64-QAM, 4 layers, 4x4 CDL-C, BG1, 50 iterations
         import bench
-        return bench.build_link(nr, decoder=decoder), [29.0, 32.0, 35.0]
+        return bench.build_link(nr, decoder=decoder, **kw), [29.0, 32.0, 35.0]
     car = nr.Carrier(numRbs=51, spacing=30)
     bwp = car.curBwp
     p = nr.PDSCH(bwp, numLayers=2, nID=car.cellId, modulation='16QAM')
@@ -41,7 +41,7 @@ def build(nr, which, decoder):
     ch = nr.CdlChannel(bwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
                        txAntenna=nr.AntennaPanel([1, 1], polarization="x"),
                        rxAntenna=nr.AntennaPanel([1, 1], polarization="x"))
-    return nr.PdschLink(p, ch, 490 / 1024, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS", decoder=decoder), \
+    return nr.PdschLink(p, ch, 490 / 1024, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS", decoder=decoder, **kw), \
         [9.5, 10.0, 10.5, 11.0, 11.5]
 
 
@@ -60,6 +60,7 @@ def main():
     for which in a.configs.split(','):
         link, snrs = build(nr, which, 'f32')
         link64, _ = build(nr, which, 'f64')
+        linkw, _ = build(nr, which, 'f32', waveform='f32')       # float32 decoder AND complex64 waveform chain (opt-in fast mode)
         if a.snrs:
             snrs = [float(v) for v in a.snrs.split(',')]
         st = olink.static_from_link(link, slots=range(0, 20 * len(snrs) + a.slots))
@@ -80,6 +81,8 @@ def main():
             # the float64 THROUGHPUT path (fused rate recovery + decode + CRC/merge where it applies) on the same slots
             _, dv = link64.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
             fused_ok = torch.cat([x['cb_ok'] for _, x in dv]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
+            dw = linkw.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
+            wave_ok = torch.cat([x['cb_ok'] for _, x in dw]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
             F = d['F'].cpu().numpy()
             t0 = time.time()
             jobs = [(st, slots0 + i, snr, tb[i].astype(np.int8), zc[i], F[i]) for i in range(n)]
@@ -91,6 +94,8 @@ def main():
             cpu_ok = np.array(cpu_ok)
             rows.append(dict(snr_db=snr, blocks=int(cpu_ok.size), cpu_block_errors=int((~cpu_ok).sum()),
                              gpu_f32_block_errors=int((~gpu_ok).sum()), gpu_f64_block_errors=int((~gpu64_ok).sum()),
+                             gpu_f32_waveform_block_errors=int((~wave_ok).sum()),
+                             f32_waveform_crc_vectors_differ_in=int((cpu_ok != wave_ok).sum()),
                              f32_crc_vectors_differ_in=int((cpu_ok != gpu_ok).sum()),
                              f64_crc_vectors_differ_in=int((cpu_ok != gpu64_ok).sum()),
                              f64_throughput_path_differs_from_f64_in=int((fused_ok != gpu64_ok).sum())))
