@@ -81,7 +81,7 @@ def main():
             # the float64 THROUGHPUT path (fused rate recovery + decode + CRC/merge where it applies) on the same slots
             _, dv = link64.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
             fused_ok = torch.cat([x['cb_ok'] for _, x in dv]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
-            dw = linkw.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
+            _, dw = linkw.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
             wave_ok = torch.cat([x['cb_ok'] for _, x in dw]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
             F = d['F'].cpu().numpy()
             t0 = time.time()
