@@ -39,6 +39,14 @@ def test_host_only_entry_points():
     fx = np.load(os.path.join(GOLD, 'phy.npz'))
     for ci in (32769, 1, 123456789):
         assert np.array_equal(_lib.gold_sequence(ci, 2000), fx[f'gold_{ci}'])
+    # rows whose extension LLRs the decoder entries read for a request (what the rate-recovering demapper must initialise): the row
+    # count of the instantiation that runs at (BG1, Zc 384), all rows elsewhere; never fewer than asked for
+    from neoradium_amd import ops
+    assert [ops.ldpc_rows_read(cfg, r, True) for r in (4, 13, 14, 15, 16, 17, 22, 23, 31, 32, 46, None)] == \
+        [13, 13, 15, 15, 16, 22, 22, 31, 31, 46, 46, 46]
+    assert [ops.ldpc_rows_read(cfg, r, False) for r in (4, 13, 14, 15, 16, 31, 32, None)] == [13, 13, 15, 15, 31, 31, 46, 46]
+    c2 = _lib.ldpc_config(2, 2408 + 16)
+    assert c2.Zc == 256 and ops.ldpc_rows_read(c2, 21, False) == 42 and ops.ldpc_rows_read(_lib.ldpc_config(1, 20000), 13, True) == 46
 
 
 def _build(c):
