@@ -206,14 +206,14 @@ def cpu_baseline(link, snr_db, n_single=2, n_procs=None):
 
 def decoder_isa(kernel_key):
     """VALU / total instruction count of one iteration of the decoder kernel whose mangled name contains ``kernel_key``, from
-    profiles/r3_decoder_isa.json (tools/isa_mix.py --json) when its SHA-256 is that of the library actually loaded; otherwise
+    neoradium_amd/libnrx.isa.json (written by the build: tools/isa_mix.py --json) when its SHA-256 is that of the library actually loaded; otherwise
     the tool is run on the loaded library now (a CPU child process: llvm-objdump on the code objects)."""
     import hashlib
     import tempfile
     from neoradium_amd import _lib
     lib = _lib._LIB_PATH
     sha = hashlib.sha256(open(lib, 'rb').read()).hexdigest()
-    src = 'profiles/r3_decoder_isa.json'
+    src = 'neoradium_amd/libnrx.isa.json'
     try:
         d = json.load(open(os.path.join(ROOT, src)))
         if d.get('sha256') != sha:
@@ -225,7 +225,7 @@ def decoder_isa(kernel_key):
         if r.returncode != 0:
             return None
         d = json.load(open(tmp))
-        src = 'tools/isa_mix.py run on the loaded library (committed profile is of another build)'
+        src = 'tools/isa_mix.py run on the loaded library (libnrx.isa.json is of another build)'
     for name, k in d['kernels'].items():
         if kernel_key in name:
             c = k['by_class']
@@ -322,10 +322,10 @@ def main():
         # What bounds the decoder is VALU issue, not HBM: a SIMD issues one wave64 VALU instruction per 4 cycles
         # whatever the mix (tools/ubench/issue_probe.hip, profiles/r3_issue_probe.txt: sustained v_fma_f64 77.5 TFLOP/s = 4.0
         # cycles, and the same 4.0 for VOP3 / mixed streams); the instruction count of an iteration is read from the ISA of
-        # the library that is loaded (profiles/r3_decoder_isa.json, checked by SHA-256)
+        # the library that is loaded (neoradium_amd/libnrx.isa.json, checked by SHA-256)
         N_SIMD, CLOCK, CYC_PER_VALU = 256 * 4, 2.4e9, 4.0
         if f64:
-            key = f"chip64_kernelILi1ELi50ELi{rows_run}ELb1E" if rows_run <= 15 else None
+            key = f"chip64_kernelILi1ELi50ELi{rows_run}ELb1ELi2ELi0E" if rows_run <= 15 else None      # <BG1, Zc 384, rows, FUSED, NS 2, MODE 0>
         else:
             key = f"fast_kernelILi1ELi50ELi2ELi{rows_run}E"
         isa = decoder_isa(key) if (key and not args.stub) else None

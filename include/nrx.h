@@ -184,6 +184,35 @@ int32_t nrx_ldpc_resume_decode_merge_sel_f64(int32_t n_tb, int32_t llr_len, cons
                                              const int32_t* sel, const int32_t* n_sel, void* state, int32_t park_again,
                                              void* stream);      /* park_again != 0: blocks that still fail park their state once more */
 
+/* ---- Certified early exit (opt-in schedule; never the headline measurement).  The reference runs a fixed number of iterations
+ * (ldpc.py:1545-1576) and has no early stop.  These entries stop a code block early ONLY where a certificate evaluated on its
+ * frozen decoder state proves that every later iteration of that same float64 recursion leaves every hard decision unchanged
+ * (statement and proof; oracle/certificate.py: the CPU restatement) -- the bits of a certified block ARE the
+ * bits ldpc.py:1578-1581 returns after numIter iterations.
+ *
+ * nrx_ldpc_cert_bounds (host only): a-priori magnitude bounds of ldpc.py:1546-1576 on the first n_rows rows, per unit of the
+ * LLR maxima: out3[0] bounds every |r| (prices the rounding-error budget), out3[1] the smallest |t| of a core row in units of
+ * the largest |LLR| over the core-parity + extension columns (prices the +1e5 quirk of ldpc.py:1563), out3[2] = the largest
+ * column degree.  Infinity = no bound (no certificate).
+ * nrx_ldpc_stage_decode_merge_f64: one stage = nrx_ldpc_recover_decode_merge_f64 for n_iter iterations (sel == NULL: from the
+ * LLRs, also leaving max|LLR| over the received non-filler positions and over the parity + extension columns in lam[2 cb],
+ * lam[2 cb + 1]) or the continuation of the selected blocks from their parked state; EVERY block that ran parks its state.
+ * nrx_ldpc_certify_f64: the certificate on the parked state of the selected blocks (all when sel == NULL) whose cb_ok is 1;
+ * exit_iter[cb] = min(iter_now, 255) where it holds, untouched elsewhere.  n_iter_total = the reference's numIter (the horizon
+ * of the error budget); flags: bit 0 / 1 skip the sign / closure conditions -- deliberately BROKEN certificates for the tests. */
+int32_t nrx_ldpc_cert_bounds(const nrx_ldpc_cfg* cfg, int32_t n_rows, double* out3);
+int32_t nrx_ldpc_stage_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
+                                        int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,
+                                        const int32_t* sel, const int32_t* n_sel, void* state, double* lam, void* stream);
+int32_t nrx_ldpc_certify_f64(const void* state, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm,
+                             int32_t n_rows, const int32_t* sel, const int32_t* n_sel, const uint8_t* cb_ok, const double* lam,
+                             int32_t iter_now, int32_t n_iter_total, int32_t max_sweeps, int32_t flags, uint8_t* exit_iter,
+                             void* stream);
+
+/* Developer hook (no reference counterpart): out16[k] = code blocks nrx_ldpc_certify_f64 certified in relaxation sweep k (k < 15),
+ * out16[15] = blocks it refused, since the last reset. */
+int32_t nrx_debug_cert_sweeps(unsigned long long* out16, int32_t reset);
+
 /* ldpc.py:1584-1619 checkCrcAndMerge (+ the TB-level checkCrc('24A') the harness applies).
  * dec: (n_tb*C) x K hard bits.  tb_out (nullable): n_tb x M bits, M = C*(cb_len - 24) for C>1 (>= B: the TB incl.
  * its CRC24A followed by the segmentation zero padding, exactly what the reference returns), M = B for C==1.

@@ -52,6 +52,10 @@ SIGNATURES = {
     'nrx_ldpc_fused_state_bytes': (i64, [_cfgp, i32, i32, i32, i32]),
     'nrx_ldpc_recover_decode_merge_park_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp]),
     'nrx_ldpc_resume_decode_merge_sel_f64': (i32, [i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    'nrx_ldpc_cert_bounds': (i32, [_cfgp, i32, vp]),
+    'nrx_ldpc_stage_decode_merge_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'nrx_ldpc_certify_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    'nrx_debug_cert_sweeps': (i32, [vp, i32]),
     'nrx_count_errors': (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
 }
 f64 = C.c_double

@@ -17,6 +17,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libnrx.so')
 STAMP = os.path.join(HERE, 'libnrx.stamp')
+ISA_JSON = os.path.join(HERE, 'libnrx.isa.json')      # instruction counts of the decoder kernels of THIS binary (tools/isa_mix.py), untracked
 FLAGS = ['-std=c++20', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-mllvm', '-amdgpu-sdwa-peephole=0', '-fPIC', '-Wno-comment',
          '-Wno-unused-value']
 
@@ -28,9 +29,35 @@ def _newer(src, dst, deps):
     return any(os.path.getmtime(d) > t for d in [src] + deps)
 
 
-def source_hash():
-    """SHA-256 over the compile flags and every source / header the library is built from."""
-    h = hashlib.sha256(' '.join(FLAGS).encode())
+def _hipcc():
+    return os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+_compiler_id = None
+
+
+def compiler_id():
+    """`hipcc --version` (the compiler is part of what produces the binary)."""
+    global _compiler_id
+    if _compiler_id is None:
+        try:
+            _compiler_id = subprocess.run([_hipcc(), '--version'], capture_output=True, text=True).stdout.strip()
+        except OSError:
+            _compiler_id = 'unknown'
+    return _compiler_id
+
+
+def flags_hash():
+    return hashlib.sha256((' '.join(FLAGS) + '\n' + compiler_id()).encode()).hexdigest()
+
+
+def lib_hash():
+    return hashlib.sha256(open(LIB, 'rb').read()).hexdigest() if os.path.exists(LIB) else ''
+
+
+def source_hash(with_compiler=True):
+    """SHA-256 over the compile flags, the compiler's version and every source / header the library is built from."""
+    h = hashlib.sha256((' '.join(FLAGS) + ('\n' + compiler_id() if with_compiler else '')).encode())
     for f in sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.h'))
                     + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))):
         h.update(os.path.basename(f).encode())
@@ -39,16 +66,21 @@ def source_hash():
 
 
 def build(force=False, verbose=True):
-    """Compile what is out of date (by modification time) and link.  `force` (or NRX_FORCE_BUILD=1 in the environment) recompiles
-    everything.  neoradium_amd/libnrx.stamp records the hash of the sources + flags the library was linked from: `stamp_ok()`
-    tells whether the library in the tree is the one these sources produce (a shipped binary can be checked against it)."""
+    """Compile what is out of date (by modification time; everything when the flags or the compiler changed) and link.  `force` (or
+    NRX_FORCE_BUILD=1 in the environment) recompiles everything.  neoradium_amd/libnrx.stamp records the hash of the sources + flags
+    + compiler the library was linked from AND the SHA-256 of libnrx.so itself: `stamp_ok()` tells whether the library in the tree
+    is the file that build produced from exactly these sources."""
     force = force or os.environ.get('NRX_FORCE_BUILD', '') not in ('', '0')
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
+    fh_path = os.path.join(OBJ, 'flags.hash')
+    if not force and stamp_ok():
+        return LIB          # the library in the tree was linked from exactly these sources, flags and compiler (objects may be absent: GPU box)
+    if not (os.path.exists(fh_path) and open(fh_path).read().strip() == flags_hash()):
+        force = True        # objects of other flags / another compiler (or of unknown origin) are not reused
+
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
     deps = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
-    if not force and stamp_ok():
-        return LIB          # the library in the tree was linked from exactly these sources and flags (objects may be absent: GPU box)
     jobs = []
     objs = []
     for s in srcs:
@@ -66,19 +98,34 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    open(fh_path, 'w').write(flags_hash() + '\n')
     if jobs or force or not os.path.exists(LIB) or not stamp_ok():
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
-        open(STAMP, 'w').write(source_hash() + '\n')
-        # the decoder's instruction counts of THIS binary, for bench.py's VALU-issue roofline (best effort: needs llvm-objdump)
+        open(STAMP, 'w').write(source_hash() + '\n' + lib_hash() + '\n')
+        # the decoder's instruction counts of THIS binary, for bench.py's VALU-issue roofline (best effort: needs llvm-objdump);
+        # written next to the library, not into profiles/ (a build must not touch tracked evidence)
         tool = os.path.join(HERE, '..', 'tools', 'isa_mix.py')
-        out = os.path.join(HERE, '..', 'profiles', 'r3_decoder_isa.json')
-        if os.path.exists(tool) and os.path.isdir(os.path.dirname(out)):
-            subprocess.run([sys.executable, tool, LIB, 'ldpc_dec', '--json', out], capture_output=True)
+        if os.path.exists(tool):
+            subprocess.run([sys.executable, tool, LIB, 'ldpc_dec', '--json', ISA_JSON], capture_output=True)
     return LIB
 
 
+def read_stamp():
+    """(source hash, library SHA-256) recorded by the last link, or ('', '')."""
+    if not os.path.exists(STAMP):
+        return '', ''
+    lines = open(STAMP).read().split()
+    return (lines + ['', ''])[0], (lines + ['', ''])[1]
+
+
 def stamp_ok():
-    return os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == source_hash()
+    """The library in the tree is the file the last link wrote (SHA-256) AND that link used exactly these sources, flags and
+    compiler.  (On a box without hipcc -- there is none without ROCm -- the compiler part of the hash cannot be formed and the
+    check falls back to sources + flags + the library's own hash.)"""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    src, so = read_stamp()
+    return so == lib_hash() and src == source_hash()
 
 
 if __name__ == '__main__':

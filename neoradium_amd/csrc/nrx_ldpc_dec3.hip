@@ -267,6 +267,10 @@ struct FuseArgs {
   // RC < RA (hybrid instantiations): the check-node state (pm1, pm2, extension posterior) of the rows >= RC streams through this
   // workspace, [workgroup][slot][row - RC][3][Zc] doubles
   double* ws;
+  // MODE bit 2 (stages of the certified early exit): lam[2 cb], lam[2 cb + 1] = the largest |LLR| of the code block over every
+  // received position that is not a filler, and over the core-parity + extension columns alone (written by the stage that fills
+  // from the LLRs; nrx_ldpc_certify_f64 prices its error budget and the +1e5 quirk with them)
+  double* lam;
 };
 // The kernel reads FuseArgs through the kernarg segment pointer at the two places that need it (initial fill, tail)
 // instead of through its parameter: as a parameter its ten scalars and two pointers stay live across the whole layer
@@ -291,16 +295,8 @@ __device__ __forceinline__ fargs_t fuse_args() {
 // state (posterior columns, check-node minima, sign / argmin words) in fa.state.  Bit 1 (resume): the initial fill is replaced by
 // reading that state back, and n_iter more iterations follow.  park(n1), then resume(n2) on the failing blocks, IS one run of
 // n1 + n2 iterations for them -- the continuation form of the multi-pass schedule: no pass repeats an earlier pass's iterations.
-template <int BG, int RA> struct StateLay {
-  using B = GR<BG, RA>;
-  using Y = Lay<BG, RA>;
-  static constexpr int NEXT = Y::n_ext() > 0 ? Y::n_ext() : 1;
-  static constexpr int NW = Y::n_wide() > 0 ? Y::n_wide() : 1, NN = (Y::n_narrow() + 1) / 2;
-  static constexpr int COL = 0;                       // columns 1 .. CORE-1 (column 0 lives in a register)
-  static constexpr int C0 = COL + B::CORE - 1, F1 = C0 + 1, M1 = F1 + 1, M2 = M1 + B::ROWS, REXT = M2 + B::ROWS;
-  static constexpr int WORDS = REXT + NEXT;           // one 32-bit word per slot (low half)
-  static constexpr int NF = WORDS + NW + NN;          // fields of Zc doubles
-};
+// Bit 2 (with bit 0): EVERY block parks its state, whatever its CRC says, and a launch that fills from the LLRs also leaves the
+// block's two LLR maxima in fa.lam: the stages of the certified early exit (ldpc_certify_kernel reads the parked state).
 // RC = rows whose check-node state stays in registers (default: all RA of them).  RC < RA: the HYBRID for more rows than fit --
 // rates below ~0.6, HARQ retransmissions, all 46 rows: everything of this kernel (rotated rows, unit x pm under EXEC, DS
 // immediates, the barrier plan) applies to every row, and the rows >= RC, the sparse ones, keep pm1 / pm2 / extension posterior in
@@ -485,9 +481,17 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         });
       }
       Ps[1 * ZS + zl] = 0.0;
+      double lmax_all = 0.0, lmax_pe = 0.0;      // MODE bit 2: largest |LLR| that is not a filler (all columns / parity + extension columns)
       static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        Ps[(c + 2) * ZS + zl] = value(xs[c], c * ZC, 0);
+        const double v = value(xs[c], c * ZC, 0);
+        Ps[(c + 2) * ZS + zl] = v;
+        if constexpr (FUSED && (MODE & 4) != 0) {
+          const bool filler = elem(0) >= fg.sys_len - c * ZC && elem(0) < fg.sys_len - c * ZC + fg.F;
+          const double av = filler ? 0.0 : __builtin_fabs(v);
+          lmax_all = __builtin_fmax(lmax_all, av);
+          if constexpr (c + 2 >= B::KB) lmax_pe = __builtin_fmax(lmax_pe, av);
+        }
       });
       static_for<RC>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -496,8 +500,23 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         if constexpr (Y::has_ext(L)) {
           rext[Y::ext_idx(L)] = value(xs[B::CORE - 2 + Y::ext_idx(L)], (Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L));
           if constexpr (!FUSED) rext[Y::ext_idx(L)] = L < rows_live ? rext[Y::ext_idx(L)] : 0.0;      // (wave-uniform)
+          if constexpr (FUSED && (MODE & 4) != 0) {
+            lmax_all = __builtin_fmax(lmax_all, __builtin_fabs(rext[Y::ext_idx(L)]));
+            lmax_pe = __builtin_fmax(lmax_pe, __builtin_fabs(rext[Y::ext_idx(L)]));
+          }
         }
       });
+      if constexpr (FUSED && (MODE & 4) != 0) {      // block maxima: shuffles inside the wave, the waves joined behind the fill's barrier
+        for (int k = 1; k < 64; k <<= 1) {
+          lmax_all = __builtin_fmax(lmax_all, __shfl_xor(lmax_all, k, 64));
+          lmax_pe = __builtin_fmax(lmax_pe, __shfl_xor(lmax_pe, k, 64));
+        }
+        double* redd = Praw + 16 + slot * 2 * (ZC / 64);      // (the padding in front of the columns is never addressed by a layer)
+        if ((zl & 63) == 0) {
+          redd[2 * (zl >> 6)] = lmax_all;
+          redd[2 * (zl >> 6) + 1] = lmax_pe;
+        }
+      }
     }
     if constexpr (!(FUSED && (MODE & 2))) {
       c0 = 0.0;                                            // punctured column (ldpc.py:1536-1538)
@@ -505,6 +524,19 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
     }
     __syncthreads();
+    if constexpr (FUSED && (MODE & 4) != 0 && (MODE & 2) == 0) {
+      if (z == 0 && live) {
+        const double* redd = Praw + 16 + slot * 2 * (ZC / 64);
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < ZC / 64; ++w) {
+          a = __builtin_fmax(a, redd[2 * w]);
+          b = __builtin_fmax(b, redd[2 * w + 1]);
+        }
+        double* lam = fuse_args()->lam;
+        lam[2 * (size_t)cb] = a;
+        lam[2 * (size_t)cb + 1] = b;
+      }
+    }
 
     if constexpr (HYB) {      // (the barrier above waited for the fill's stores)
       int zq = z;
@@ -761,7 +793,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       }
       if constexpr ((MODE & 1) != 0) {
         __syncthreads();
-        if (live && red[NS * (ZC / 64) + slot] == 0u) {      // CRC failed: park the state for the continuation launch
+        if (live && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u)) {      // CRC failed (bit 2: or not): park the state for the continuation launch
           using SL = StateLay<BG, RA>;
           double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
           static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
@@ -898,7 +930,8 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
 static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg,
                                          int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
                                          uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream,
-                                         int mode = 0, double* state = nullptr, size_t* state_bytes_per_cb = nullptr) {
+                                         int mode = 0, double* state = nullptr, size_t* state_bytes_per_cb = nullptr,
+                                         double* lam = nullptr, int* rows_run = nullptr) {
   using namespace nrx_dec3;
   NRX_REQUIRE(llr && cfg && tb_out && cb_ok, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: NULL buffer");
   NRX_REQUIRE(nl >= 1 && qm >= 1 && llr_len > 0 && n_tb >= 0 && n_iter >= 0, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: bad argument");
@@ -910,6 +943,8 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   fa.sel = sel;
   fa.n_sel = n_sel;
   fa.state = state;
+  fa.ws = nullptr;
+  fa.lam = lam;
   FuseGeom& fg = fa.g;
   fg.C = cfg->C; fg.f = f; fg.qm = qm; fg.F = cfg->F; fg.llr_len = llr_len; fg.cb_len = cfg->cb_len;
   fg.e_small = (gb / cfg->C) * f;
@@ -927,6 +962,7 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
     ::nrx::set_error("nrx_ldpc_recover_decode_merge: no fused instantiation for bg %d Zc %d C %d rows %d", cfg->bg, cfg->Zc, cfg->C, n_rows);
     return NRX_E_UNSUPPORTED;
   }
+  if (rows_run) *rows_run = n_rows <= 13 ? 13 : 15;          // (the rows of the instantiation that runs)
   if (state_bytes_per_cb) {          // (query: the size of a parked state for this configuration's instantiation)
     *state_bytes_per_cb = sizeof(double) * 384 * (size_t)(n_rows <= 13 ? StateLay<1, 13>::NF : StateLay<1, 15>::NF);
     return NRX_OK;
@@ -943,9 +979,11 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
 #define NRX_FUSED_LAUNCH(RA_, MODE_) \
   hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, RA_, true, 2, MODE_>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa)
   if (n_rows <= 13) {
-    if (mode == 0) NRX_FUSED_LAUNCH(13, 0); else if (mode == 1) NRX_FUSED_LAUNCH(13, 1); else if (mode == 2) NRX_FUSED_LAUNCH(13, 2); else NRX_FUSED_LAUNCH(13, 3);
+    if (mode == 0) NRX_FUSED_LAUNCH(13, 0); else if (mode == 1) NRX_FUSED_LAUNCH(13, 1); else if (mode == 2) NRX_FUSED_LAUNCH(13, 2); else if (mode == 3) NRX_FUSED_LAUNCH(13, 3);
+    else if (mode == 5) NRX_FUSED_LAUNCH(13, 5); else NRX_FUSED_LAUNCH(13, 7);
   } else {
-    if (mode == 0) NRX_FUSED_LAUNCH(15, 0); else if (mode == 1) NRX_FUSED_LAUNCH(15, 1); else if (mode == 2) NRX_FUSED_LAUNCH(15, 2); else NRX_FUSED_LAUNCH(15, 3);
+    if (mode == 0) NRX_FUSED_LAUNCH(15, 0); else if (mode == 1) NRX_FUSED_LAUNCH(15, 1); else if (mode == 2) NRX_FUSED_LAUNCH(15, 2); else if (mode == 3) NRX_FUSED_LAUNCH(15, 3);
+    else if (mode == 5) NRX_FUSED_LAUNCH(15, 5); else NRX_FUSED_LAUNCH(15, 7);
   }
 #undef NRX_FUSED_LAUNCH
   NRX_CHECK_LAUNCH("nrx_ldpc_recover_decode_merge_f64");
@@ -994,6 +1032,31 @@ extern "C" int32_t nrx_ldpc_resume_decode_merge_sel_f64(int32_t n_tb, int32_t ll
   NRX_REQUIRE(state && sel && n_sel, NRX_E_ARG, "nrx_ldpc_resume_decode_merge_sel: NULL state / selection");
   return recover_decode_merge_impl((const double*)state, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, sel, n_sel, stream,
                                    park_again ? 3 : 2, (double*)state);
+}
+
+// (for nrx_ldpc_cert.hip) the rows of the fused instantiation that serves this configuration; NRX_E_UNSUPPORTED when there is none
+int32_t nrx_ldpc_fused_rows_run(const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm, int32_t llr_len, int32_t n_rows, int* rows_run) {
+  size_t per = 0;
+  uint8_t dummy = 0;
+  const double d0 = 0;
+  return recover_decode_merge_impl(&d0, 1, llr_len, cfg, nl, qm, 1, n_rows, &dummy, &dummy, nullptr, nullptr, nullptr, 0, nullptr, &per, nullptr, rows_run);
+}
+
+// One STAGE of the certified schedule on the fused entry: n_iter iterations of every block (sel == NULL: from the LLRs, which
+// also leaves the two LLR maxima of every block in lam[2 n_cb]) or of the selected blocks (continued from their parked state;
+// llr is not read), and EVERY block that ran parks its complete decoder state, whatever its CRC says.
+extern "C" int32_t nrx_ldpc_stage_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
+                                                   int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,
+                                                   const int32_t* sel, const int32_t* n_sel, void* state, double* lam, void* stream) {
+  NRX_REQUIRE(state && lam, NRX_E_ARG, "nrx_ldpc_stage_decode_merge: NULL state / maxima");
+  NRX_REQUIRE((sel == nullptr) == (n_sel == nullptr), NRX_E_ARG, "nrx_ldpc_stage_decode_merge: selection list without its count");
+  if (sel == nullptr) {
+    NRX_REQUIRE(llr, NRX_E_ARG, "nrx_ldpc_stage_decode_merge: NULL llr");
+    return recover_decode_merge_impl(llr, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, nullptr, nullptr, stream, 5, (double*)state,
+                                     nullptr, lam);
+  }
+  return recover_decode_merge_impl((const double*)state, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, sel, n_sel, stream, 7,
+                                   (double*)state, nullptr, lam);
 }
 
 namespace {

@@ -256,6 +256,21 @@ template <int BG, int RA = G<BG>::ROWS> struct Lay {  // compile-time layer fact
   }
 };
 
+// Layout of a code block's parked decoder state (nrx_ldpc_dec3.hip parks and resumes it, nrx_ldpc_cert.hip reads it): NF fields of Zc
+// doubles -- posterior columns 1 .. CORE-1 (element order), column 0 (lane order = element order), the handed-over column 1, the scaled
+// minima pm1 / pm2 of every row, the extension posteriors, the sign / argmin words (low half of a double) -- all but the columns in
+// the decoder's lane frame (lane z of layer L = check row z + sigma_L).
+template <int BG, int RA> struct StateLay {
+  using B = GR<BG, RA>;
+  using Y = Lay<BG, RA>;
+  static constexpr int NEXT = Y::n_ext() > 0 ? Y::n_ext() : 1;
+  static constexpr int NW = Y::n_wide() > 0 ? Y::n_wide() : 1, NN = (Y::n_narrow() + 1) / 2;
+  static constexpr int COL = 0;                       // columns 1 .. CORE-1 (column 0 lives in a register)
+  static constexpr int C0 = COL + B::CORE - 1, F1 = C0 + 1, M1 = F1 + 1, M2 = M1 + B::ROWS, REXT = M2 + B::ROWS;
+  static constexpr int WORDS = REXT + NEXT;           // one 32-bit word per slot (low half)
+  static constexpr int NF = WORDS + NW + NN;          // fields of Zc doubles
+};
+
 constexpr int zindex_c(int zc) {
   for (int i = 0; i < NZ; ++i)
     if (kZ.z[i] == zc) return i;

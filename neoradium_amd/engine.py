@@ -106,7 +106,7 @@ def gain_times(tables, slots):
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
                  decoder="f64", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
-                 skipPuncturedRows=True, waveform="f64"):
+                 skipPuncturedRows=True, waveform="f64", certifiedExit=None, certFlags=0):
         if waveform not in ("f32", "f64"):
             raise ValueError("waveform must be 'f64' (the reference's complex128 waveforms, default) or 'f32' (time-domain link only: "
                              "Tx grid, OFDM, channel filter and received grid in complex64 -- not the parity path)")
@@ -134,6 +134,20 @@ class PdschLink:
         # block is assumed to be the code word the full run ends on as well.  Where the fused float64 entry exists the
         # failing blocks CONTINUE from their parked decoder state (no iteration is done twice) and the list of failing
         # blocks stays on the device; elsewhere they are decoded again from scratch after one host read per batch.
+        # Opt-in CERTIFIED early exit (off by default; the reference has no early stop, ldpc.py:1545): `certifiedExit` = an ascending
+        # list of iteration counts.  At each of them a block stops only if its CRC passes AND the stability certificate holds on
+        # its frozen decoder state (ops.ldpc_recover_decode_merge_certified): its bits are then provably those of the
+        # full `numIter` run.  Needs the fused float64 entry (else ValueError at the first batch).  `certFlags` != 0 breaks the
+        # certificate on purpose (tests).
+        if certifiedExit is not None:
+            marks = sorted({int(v) for v in (certifiedExit if isinstance(certifiedExit, (list, tuple)) else [certifiedExit])})
+            if firstPassIter is not None or decoder != "f64" or not marks or marks[0] < 1 or marks[-1] >= int(numIter):
+                raise ValueError("certifiedExit: ascending iteration counts in [1, numIter-1], float64 decoder, without firstPassIter")
+            self.certStages = tuple(marks)
+        else:
+            self.certStages = None
+        self.certFlags = int(certFlags)
+        self.last_exit_iter = None          # (n_cb,) uint8 of the last batch that ran the certified schedule
         if firstPassIter is None:
             self.firstPassIter, self.passStages = None, ()
         else:
@@ -483,7 +497,14 @@ class PdschLink:
             llr = None if rr is not None else \
                 ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
                               exact=not self.useMax, llr_dtype=ldt, code_blocks=(ccfg.C, cw['nl']) if fuse else None)
-            if fuse and self.firstPassIter is not None:     # two passes, both on the fused entry, the failing blocks' list on the device
+            if self.certStages is not None:
+                if not fuse:
+                    raise ValueError("certifiedExit needs the fused float64 decoder entry (BG1, Zc 384, first transmission, <= 15 rows, max-log LLRs)")
+                got = ops.ldpc_recover_decode_merge_certified(llr, ccfg, cw['nl'], cw['qm'], self.certStages, self.numIter, rows=cw['rows'],
+                                                              flags=self.certFlags)
+                fused = None if got is None else got[:2]
+                self.last_exit_iter = None if got is None else got[2]
+            elif fuse and self.firstPassIter is not None:     # two passes, both on the fused entry, the failing blocks' list on the device
                 fused = ops.ldpc_recover_decode_merge_two_pass(llr, ccfg, cw['nl'], cw['qm'], self.firstPassIter, self.numIter,
                                                                rows=cw['rows'], stages=self.passStages)
             else:

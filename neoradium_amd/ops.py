@@ -306,6 +306,74 @@ def ldpc_recover_decode_merge_two_pass(llr, cfg, nl, qm, first_iter, n_iter, row
     return tb_out, cb_ok
 
 
+def ldpc_cert_bounds(cfg, rows):
+    """nrx_ldpc_cert_bounds (host): (gamma, gamma1, dmax) of the first ``rows`` rows -- the a-priori magnitude bounds the
+    early-termination certificate prices its error budget with."""
+    out = (C.c_double * 3)()
+    check(lib().nrx_ldpc_cert_bounds(C.byref(cfg), int(rows), out))
+    return float(out[0]), float(out[1]), int(out[2])
+
+
+_cert_bufs = {}
+
+
+def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0, max_sweeps=8, flags=0):
+    """The CERTIFIED early exit on the fused entry (opt-in; the reference has no early stop, ldpc.py:1545).  ``stages`` = ascending
+    iteration counts at which the blocks still running are checked: a block whose CRC24B passes AND whose frozen decoder state holds
+    the stability certificate (nrx_ldpc_certify_f64: every later iteration provably leaves its hard decisions unchanged) stops there;
+    every other block continues from its parked state, the last ones to ``n_iter``.  Work lists stay on the device.
+    -> (tb_out, cb_ok, exit_iter uint8 (n_cb,): the iteration a block was certified at, 0 = ran all n_iter), or None when the
+    configuration has no fused instantiation.  ``flags`` != 0 breaks the certificate on purpose (tests only)."""
+    if llr.dtype != torch.float64 or llr.dim() != 2 or not (cfg.bg == 1 and cfg.Zc == 384 and cfg.C > 1):
+        return None
+    llr = llr.contiguous()
+    n_tb, G = llr.shape
+    dev = _dev(llr)
+    n_cb = n_tb * cfg.C
+    per = int(lib().nrx_ldpc_fused_state_bytes(C.byref(cfg), nl, qm, G, int(rows or 0)))
+    if per == -3:
+        return None
+    if per < 0:
+        check(per)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    state = _fused_state.get(key)
+    if state is None or state.numel() < n_cb * per:
+        state = _fused_state[key] = torch.empty(n_cb * per, dtype=torch.uint8, device=dev)
+    bufs = _cert_bufs.get(key)
+    if bufs is None or bufs[0].numel() < 2 * n_cb:
+        bufs = _cert_bufs[key] = (torch.empty(2 * n_cb, dtype=torch.float64, device=dev), torch.empty(n_cb, dtype=torch.int32, device=dev),
+                                  torch.empty(n_cb, dtype=torch.int32, device=dev), torch.empty(2, dtype=torch.int32, device=dev))
+    lam, sel_a, sel_b, cnt = bufs
+    tb_out = torch.empty((n_tb, cfg.C * (cfg.cb_len - 24)), dtype=torch.uint8, device=dev)
+    cb_ok = torch.empty((n_tb, cfg.C), dtype=torch.uint8, device=dev)
+    exit_iter = torch.zeros(n_cb, dtype=torch.uint8, device=dev)
+    marks = sorted({int(v) for v in stages if 0 < int(v) < int(n_iter)})
+    if not marks:
+        raise ValueError("stages must hold at least one iteration count below n_iter")
+    L = lib()
+    cfgp, r = C.byref(cfg), int(rows or 0)
+    check(L.nrx_ldpc_stage_decode_merge_f64(ptr(llr), n_tb, G, cfgp, nl, qm, marks[0], r, ptr(tb_out), ptr(cb_ok), None, None,
+                                            ptr(state), ptr(lam), stream()))
+    check(L.nrx_ldpc_certify_f64(ptr(state), n_tb, G, cfgp, nl, qm, r, None, None, ptr(cb_ok), ptr(lam), marks[0], int(n_iter),
+                                 int(max_sweeps), int(flags), ptr(exit_iter), stream()))
+    done = marks[0]
+    sels = (sel_a, sel_b)
+    for k, upto in enumerate(marks[1:] + [int(n_iter)]):
+        last = k == len(marks) - 1
+        sel, n_sel = sels[k & 1], cnt[(k & 1):(k & 1) + 1]
+        check(L.nrx_select_failed(ptr(exit_iter), n_cb, ptr(sel), ptr(n_sel), stream()))       # the blocks without a certificate go on
+        if last:
+            check(L.nrx_ldpc_resume_decode_merge_sel_f64(n_tb, G, cfgp, nl, qm, upto - done, r, ptr(tb_out), ptr(cb_ok), ptr(sel), ptr(n_sel),
+                                                         ptr(state), 0, stream()))
+        else:
+            check(L.nrx_ldpc_stage_decode_merge_f64(None, n_tb, G, cfgp, nl, qm, upto - done, r, ptr(tb_out), ptr(cb_ok), ptr(sel), ptr(n_sel),
+                                                    ptr(state), ptr(lam), stream()))
+            check(L.nrx_ldpc_certify_f64(ptr(state), n_tb, G, cfgp, nl, qm, r, ptr(sel), ptr(n_sel), ptr(cb_ok), ptr(lam), upto, int(n_iter),
+                                         int(max_sweeps), int(flags), ptr(exit_iter), stream()))
+        done = upto
+    return tb_out, cb_ok, exit_iter
+
+
 def ldpc_fused_supported(cfg, nl, qm, G, rows):
     """Host-side mirror of nrx_ldpc_recover_decode_merge_f64's capability test (so that a caller can choose the demapper's
     output layout before it demaps)."""
