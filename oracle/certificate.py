@@ -49,7 +49,7 @@ def _lfp(cols, ncol, lam):
             if (np.isfinite(new) != f).any():
                 change = np.inf
             elif both.any():
-                change = max(change, np.abs(new - U[i])[both].max())
+                change = max(change, np.abs(new[both] - U[i][both]).max())
             U[i] = new
         fin = [u[np.isfinite(u)] for u in U]
         if max((x.max() if len(x) else 0.0) for x in fin) > 1e9:

@@ -1,0 +1,141 @@
+"""GPU: the certified early exit (nrx_ldpc_stage_decode_merge_f64 + nrx_ldpc_certify_f64) through the C ABI.
+
+The reference runs a fixed number of iterations (ldpc.py:1545); a block the certificate stops early must carry exactly the bits
+the fixed schedule ends on.  Checked bit for bit against the fixed schedule of the same library (itself bit-identical to the
+oracle, tests/test_gpu_ldpc.py), over >= 1e5 code blocks across the waterfall at the metric configuration, with filler bits,
+exact zeros and saturated LLRs, for both on-chip instantiations (13 / 15 rows); against the oracle's own certificate on a
+slot; and a deliberately broken certificate must be caught."""
+import numpy as np
+import pytest
+
+from oracle import coding as oc
+from oracle import certificate as cert
+
+pytestmark = pytest.mark.gpu
+
+
+def _metric_link(**kw):
+    import neoradium_amd as nr
+    import bench
+    return bench.build_link(nr, decoder="f64", num_iter=50, **kw)
+
+
+def test_certified_blocks_equal_the_fixed_schedule_over_the_waterfall(dev):
+    """>= 1e5 code blocks, 29 ... 35 dB (code-block error rate ~0.6 ... 0): transport-block bits and CRC verdicts of the certified
+    schedule identical to the fixed 50-iteration schedule for EVERY block, certified or not."""
+    import torch
+    fixed = _metric_link()
+    certd = _metric_link(certifiedExit=(8, 14, 24))
+    C, pay = fixed.cfg.C, fixed.cfg.cb_len - 24
+    total = certified = 0
+    hist = {}
+    for k, snr in enumerate((29.0, 30.0, 31.0, 31.5, 32.0, 33.0, 35.0)):
+        for b in range(2):
+            n = 100
+            slot0 = 7000 * k + 300 * b
+            _, d0 = fixed.run(slot0, n, snr, seed=11, details="verdicts")
+            _, d1 = certd.run(slot0, n, snr, seed=11, details="verdicts")
+            ex = certd.last_exit_iter
+            assert torch.equal(d0[0][1]['cb_ok'], d1[0][1]['cb_ok']), f"CRC verdicts differ at {snr} dB"
+            same = (d0[0][1]['tb_out'].reshape(-1, pay) == d1[0][1]['tb_out'].reshape(-1, pay)).all(1)
+            bad = (~same).nonzero().reshape(-1)
+            assert bad.numel() == 0, f"{bad.numel()} blocks differ at {snr} dB (exit iterations {ex[bad][:8].tolist()})"
+            total += ex.numel()
+            certified += int((ex > 0).sum())
+            for v, c in zip(*np.unique(ex.cpu().numpy(), return_counts=True)):
+                hist[int(v)] = hist.get(int(v), 0) + int(c)
+    assert total >= 100000
+    assert certified > 0.5 * total and set(hist) >= {0, 8, 14}, hist
+
+
+def test_a_broken_certificate_is_caught(dev):
+    """Without its conditions (flags 7: no sign / closure conditions, CRC filter off) everything 'certifies' at the first check
+    and blocks that had not converged differ from the fixed schedule: the comparison above would fail."""
+    fixed = _metric_link()
+    broken = _metric_link(certifiedExit=(8, 16), certFlags=7)
+    pay = fixed.cfg.cb_len - 24
+    _, d0 = fixed.run(50, 16, 30.5, seed=2, details="verdicts")
+    _, d1 = broken.run(50, 16, 30.5, seed=2, details="verdicts")
+    assert (broken.last_exit_iter == 8).all()
+    diff = (d0[0][1]['tb_out'].reshape(-1, pay) != d1[0][1]['tb_out'].reshape(-1, pay)).any(1)
+    assert int(diff.sum()) > 0
+
+
+@pytest.mark.parametrize("tbs,qm,nl,e_bits", [(25000, 6, 4, 13000), (25000, 2, 1, 12300), (33000, 4, 2, 13000)])
+def test_fillers_zeros_saturation_and_both_instantiations(dev, tbs, qm, nl, e_bits):
+    """Synthetic LLRs straight into the entries: F > 0 (the filler positions' posteriors sit at 1e10), exact zeros, one clean / one
+    marginal / one hopeless transport block, E_r reaching 15 or only 13 rows; then the same with a saturated LLR (1e10) outside
+    the filler positions in every block: the certificate must refuse those blocks, the bits stay those of the fixed schedule."""
+    import torch
+    from neoradium_amd import ops, _lib
+    cfg = _lib.ldpc_config(1, tbs + 24)
+    assert cfg.Zc == 384 and cfg.C > 1 and cfg.F > 0
+    n_tb = 6
+    rng = np.random.default_rng(tbs + qm)
+    e_small = (e_bits // (nl * qm)) * (nl * qm)
+    G = cfg.C * e_small
+    lens = _lib.ldpc_cb_lens(G, cfg.C, nl, qm)
+    tb = torch.from_numpy(rng.integers(0, 2, (n_tb, tbs)).astype(np.uint8)).to(dev)
+    coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+    bits = ops.ldpc_rate_match(coded, cfg, G, nl, qm).cpu().numpy().astype(np.float64)
+    sig = np.array([0.45, 0.5, 0.74, 0.76, 0.78, 1.1])[:, None]
+    llr = (2 / sig ** 2) * ((1 - 2 * bits) + sig * rng.standard_normal(bits.shape))
+    llr[rng.random(llr.shape) < 0.001] = 0.0
+    rows = ops.ldpc_active_rows(cfg, max(lens))
+    assert rows <= 15 and ops.ldpc_fused_supported(cfg, nl, qm, G, rows)
+
+    def deint(a):
+        out = np.empty_like(a)
+        off = 0
+        for E in lens:
+            out[:, off:off + E] = a[:, off:off + E].reshape(n_tb, E // qm, qm).transpose(0, 2, 1).reshape(n_tb, E)
+            off += E
+        return torch.from_numpy(out).to(dev)
+
+    n_iter = 30
+    for saturate in (False, True):
+        x = llr.copy()
+        if saturate:
+            off = 0
+            for E in lens:                      # one received LLR per code block at the clip, with the right sign
+                x[:, off + 5] = 1e10 * (1 - 2 * bits[:, off + 5])
+                off += E
+        xd = deint(x)
+        tb_ref, ok_ref = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, n_iter, rows=rows)
+        tb_c, ok_c, ex = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (5, 9, 14), n_iter, rows=rows)
+        assert torch.equal(ok_c, ok_ref) and torch.equal(tb_c, tb_ref), saturate
+        exn = ex.cpu().numpy().reshape(n_tb, cfg.C)
+        okn = ok_ref.cpu().numpy().astype(bool)
+        if saturate:
+            assert (exn == 0).all(), "a block with a saturated LLR outside the fillers was certified"
+        else:
+            # (a marginal block may pass its CRC only after the last check: it runs to the end)
+            assert (exn[okn] > 0).mean() > 0.5 and (exn[~okn] == 0).all(), (exn, okn)
+            assert 0 < okn.sum() < okn.size
+
+
+def test_gpu_certificate_against_the_oracle_on_a_slot(dev):
+    """One slot at the metric configuration (72 blocks of Zc 384): the blocks the kernel certifies after 8 iterations carry, at 8,
+    the bits the ORACLE's full 50-iteration run ends on, and the oracle's own certificate (another search for the slacks, same
+    theorem) certifies nearly the same set."""
+    import torch
+    from neoradium_amd import ops
+    link = _metric_link()
+    cw = link.cw[0]
+    cfg = cw['cfg']
+    _, det = link.run(4242, 1, 31.5, seed=4, details=True)
+    llr = det[0][1]['llr']                                       # (1, G) in the reference's order
+    rr = ops.ldpc_rate_recover(llr, cfg, cw['nl'], cw['qm']).cpu().numpy()
+    rows = cw['rows']
+    res = cert.decode_certified(rr, 1, cfg.iLS, cfg.Zc, 50, rows, [8], (), sweeps=12)
+    certd = _metric_link(certifiedExit=(8,))
+    _, d1 = certd.run(4242, 1, 31.5, seed=4, details="verdicts")
+    ex = certd.last_exit_iter.cpu().numpy()
+    gpu8 = ex == 8
+    assert gpu8.sum() > 10
+    assert np.array_equal(res['bits_at'][8][gpu8], res['bits'][gpu8]), "a GPU-certified block's bits at 8 are not the oracle's final bits"
+    pay = cfg.cb_len - 24
+    got = d1[0][1]['tb_out'].reshape(-1, pay).cpu().numpy()
+    assert np.array_equal(got, res['bits'][:, :pay]), "decoded payload differs from the oracle's 50-iteration run"
+    agree = (gpu8 == res['cert'][8]).mean()
+    assert agree >= 0.9, (int(gpu8.sum()), int(res['cert'][8].sum()))
