@@ -234,6 +234,74 @@ def decoder_isa(kernel_key):
     return None
 
 
+def library_identity(stub=False):
+    """SHA-256 of the libnrx.so that is loaded, and whether neoradium_amd/libnrx.stamp (source hash + library hash, written by the
+    link) says it is the file these sources produced."""
+    import hashlib
+    from neoradium_amd import _lib, build
+    try:
+        sha = hashlib.sha256(open(_lib._LIB_PATH, 'rb').read()).hexdigest()
+        src, so = build.read_stamp()
+        return {"sha256": sha, "stamp_library_sha256": so, "stamp_source_hash": src, "source_hash": build.source_hash(),
+                "stamp_ok": bool(build.stamp_ok())}
+    except Exception as e:       # (never fails the measurement)
+        return {"error": str(e)}
+
+
+def side_configs(nr, ops, sync):
+    """The other BASELINE.json configurations in the driver-timed record (N = 1 only, a few seconds in all): cfg2 and cfg3 slots/s over
+    3 steps each, cfg5 (HARQ-IR at the metric configuration) transmissions/s over 4 rounds; same protocol (warm-up, then timed steps
+    between synchronisations, inputs generated on the device)."""
+    import torch
+    out = {}
+
+    def steps(link, B, snr, k=3):
+        link.run(0, B, snr, seed=1)
+        sync()
+        t0 = time.perf_counter()
+        c = torch.zeros(4, dtype=torch.int64, device=link.dev)
+        for i in range(k):
+            link.run((i + 1) * B, B, snr, seed=1, counters=c)
+        sync()
+        dt = time.perf_counter() - t0
+        c = c.cpu().numpy()
+        return {"value": B * k / dt, "unit": "slots/s", "steps": k, "ms_per_step": 1e3 * dt / k, "slots_per_step": B, "snr_db": snr,
+                "block_errors": int(c[0]), "blocks": int(c[1])}
+
+    nr.random.setSeed(123)
+    car = nr.Carrier(numRbs=106, spacing=30)
+    p = nr.PDSCH(car.curBwp, numLayers=2, nID=car.cellId, modulation='64QAM')
+    p.setDMRS(configType=1, additionalPos=1)
+    ch = nr.CdlChannel(car.curBwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                       txAntenna=nr.AntennaPanel([1, 1], polarization="x"), rxAntenna=nr.AntennaPanel([1, 1], polarization="x"))
+    l2 = nr.PdschLink(p, ch, 666 / 1024, baseGraphNo=1, numIter=50, freqDomain=False, chanEst="LS", decoder="f64")
+    out["cfg2"] = dict(steps(l2, 1024, 20.0), workload="106 PRB @30 kHz, 64-QAM, 2 layers, 2x2 MMSE, CDL-C 300 ns, BG1 R=666/1024, 50 iterations, "
+                                                        "batch 1024 slots, float64")
+    del l2
+    nr.random.setSeed(123)
+    car = nr.Carrier(numRbs=273, spacing=30)
+    p = nr.PDSCH(car.curBwp, numLayers=4, nID=car.cellId, modulation='256QAM')
+    p.setDMRS(configType=1, additionalPos=1)
+    ch = nr.CdlChannel(car.curBwp, 'D', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                       txAntenna=nr.AntennaPanel([1, 2], polarization="x"), rxAntenna=nr.AntennaPanel([1, 2], polarization="x"))
+    l3 = nr.PdschLink(p, ch, 0.75, baseGraphNo=1, numIter=50, freqDomain=True, chanEst="Perfect", decoder="f64")
+    out["cfg3"] = dict(steps(l3, 48, 58.0), workload="273 PRB @30 kHz, 256-QAM, 4 layers, 4x4 MMSE, CDL-D 300 ns, BG1 R=0.75 (113 CB), perfect CSI "
+                                                      "(frequency-domain channel), 50 iterations, batch 48 slots, float64")
+    del l3
+    l5 = build_link(nr, decoder="f64")
+    _, st = l5.run_harq(64, 1, 27.0, seed=1)
+    sync()
+    t0 = time.perf_counter()
+    stats, st = l5.run_harq(64, 4, 27.0, seed=1, state=st)
+    sync()
+    dt = time.perf_counter() - t0
+    out["cfg5"] = {"value": 64 * 4 / dt, "unit": "transmissions/s", "rounds": 4, "harq_processes": 64, "snr_db": 27.0, "ms_per_round": 1e3 * dt / 4,
+                   "bler_pct": stats['bler'], "meanTries": stats['meanTries'],
+                   "workload": "HARQ-IR (rv 0,2,3,1, soft-LLR combining resident in HBM) at the metric configuration, 64 processes, float64"}
+    del l5, st
+    return out
+
+
 def launch_ranks(n):
     """--gpus N without a launcher: start N ranks as children (torch.distributed.run) and pass their exit code on.
     Runs before this process has made any GPU call; the parent never touches the GPU."""
@@ -261,6 +329,8 @@ def main():
     ap.add_argument('--no-fast', action='store_true', help="skip the extra float32 fast-mode measurement")
     ap.add_argument('--no-allrows', action='store_true', help="skip the extra all-46-rows measurement")
     ap.add_argument('--no-twopass', action='store_true', help="skip the opt-in two-pass schedule block")
+    ap.add_argument('--no-cert', action='store_true', help="skip the certified-early-exit block")
+    ap.add_argument('--no-configs', action='store_true', help="skip the side configurations (cfg2, cfg3, cfg5)")
     ap.add_argument('--stub', action='store_true', help=argparse.SUPPRESS)      # test hook, see StubLink
     args = ap.parse_args()
 
@@ -323,7 +393,17 @@ def main():
         # whatever the mix (tools/ubench/issue_probe.hip, profiles/r3_issue_probe.txt: sustained v_fma_f64 77.5 TFLOP/s = 4.0
         # cycles, and the same 4.0 for VOP3 / mixed streams); the instruction count of an iteration is read from the ISA of
         # the library that is loaded (neoradium_amd/libnrx.isa.json, checked by SHA-256)
-        N_SIMD, CLOCK, CYC_PER_VALU = 256 * 4, 2.4e9, 4.0
+        N_SIMD, CYC_PER_VALU = 256 * 4, 4.0
+        # the shader clock is read on the device in this run (s_memtime against the 100 MHz s_memrealtime under a float64 load on
+        # every CU, right behind the timed region); 2.4 GHz is the nominal figure it is checked against
+        CLOCK, clock_src = 2.4e9, "nominal"
+        if not args.stub:
+            try:
+                hz = ops.shader_clock_hz(dev)
+                if 1.0e9 < hz < 3.0e9:
+                    CLOCK, clock_src = hz, "nrx_debug_clock_probe (s_memtime / s_memrealtime) in this run"
+            except Exception:
+                pass
         if f64:
             key = f"chip64_kernelILi1ELi50ELi{rows_run}ELb1ELi2ELi0E" if rows_run <= 15 else None      # <BG1, Zc 384, rows, FUSED, NS 2, MODE 0>
         else:
@@ -340,7 +420,12 @@ def main():
                           "valu_instr_per_wave_edge_visit": isa['valu'] / BG1_ROW_START[rows_run],
                           "vgpr": isa['vgpr'], "scratch_bytes": isa['scratch_bytes'], "kernel_symbol": isa['kernel_symbol'],
                           "isa_source": isa['source'], "library_sha256": isa['library_sha256'],
-                          "cycles_per_valu_instr": CYC_PER_VALU, "clock_hz": CLOCK,
+                          "cycles_per_valu_instr": CYC_PER_VALU, "clock_hz": CLOCK, "clock_source": clock_src,
+                          # utilisation of the issue slots rewards instruction bloat: the irreducible arithmetic of an edge-visit is ~7
+                          # VALU instructions (subtract, three min/max, add, two LDS address selects), so the fraction of an
+                          # IDEAL-instruction bound is 7 / (instructions per edge-visit) x the issue fraction
+                          "ideal_valu_instr_per_edge_visit": 7.0,
+                          "ideal_instruction_frac": 7.0 / (isa['valu'] / BG1_ROW_START[rows_run]) * (ach_rate / peak_rate),
                           "bound_edge_visits_per_s": peak_rate / (isa['valu'] / BG1_ROW_START[rows_run]) * 64}
         traffic = None
         try:                                              # HBM bytes per launch from the committed PMC passes
@@ -371,12 +456,13 @@ def main():
                           "unit": valu_issue["unit"], "frac": valu_issue["frac"]} if valu_issue else
                          {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0}),
             "env": {k: v for k, v in os.environ.items() if k.startswith('NRX_')},
+            "library": library_identity(args.stub),
         }
         out["roofline"].update({
             "traffic": traffic, "avg_launch_ms": dec_ms, "launch_share_of_step": dec_ms / (dt / K * 1e3), "edge_visits_per_s": ev_s,
             "hbm": {"achieved": achieved, "peak": 8000.0, "unit": "GB/s", "hbm_frac": achieved / 8000.0, "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "the decoder re-uses its LDS/VGPR-resident working set numIter times and touches HBM at entry / exit only"},
-            "note": "bound = VALU issue: one wave64 VALU instruction per SIMD per 4 cycles x 1024 SIMDs x 2.4 GHz; achieved = VALU "
+            "note": "bound = VALU issue: one wave64 VALU instruction per SIMD per 4 cycles x 1024 SIMDs x the shader clock read in this run; achieved = VALU "
                     "instructions of the iteration loop (ISA of the loaded library) x waves x iterations / HIP-event launch time"})
         if valu_issue:
             out["roofline"]["valu_issue"] = valu_issue
@@ -423,6 +509,41 @@ def main():
                                "note": "opt-in (off by default, not the reference's schedule): shown as the labelled fast line",
                                "points": pts}
             del tp
+        if not args.stub and world == 1 and not args.no_cert and f64:
+            # OPT-IN schedule with a PROOF, reported beside `value`, never instead of it: at 8 and 16 iterations a block stops only if
+            # its CRC passes AND the stability certificate holds on its frozen decoder state (nrx_ldpc_certify_f64): every
+            # later iteration of the same float64 recursion then provably leaves its hard decisions unchanged, i.e. its bits ARE the
+            # reference schedule's.  Checked here on one batch per SNR point block by block against the fixed schedule's bits.
+            ce = build_link(nr, decoder='f64', certifiedExit=(8, 16))
+            kt, wt = min(K, 8), max(min(W, 2), 2)
+            pts = []
+            pay = cfg.cb_len - 24
+            for snr_t in sorted({float(args.snr), 33.0, 35.0}):
+                tdt, tc, _ = timed_steps(ce, ops, B, kt, wt, snr_t, slot_base, None, sync, timer_enabled=False)
+                cs = torch.zeros(4, dtype=torch.int64, device=dev)
+                for k in range(kt):
+                    link.run(slot_base + (wt + k) * B, B, snr_t, seed=123, counters=cs)
+                # one batch block by block: bits of the fixed schedule against the certified schedule
+                _, d0 = link.run(slot_base, B, snr_t, seed=123, details="verdicts")
+                _, d1 = ce.run(slot_base, B, snr_t, seed=123, details="verdicts")
+                ex = ce.last_exit_iter
+                diff = (d0[0][1]['tb_out'].reshape(-1, pay) != d1[0][1]['tb_out'].reshape(-1, pay)).any(1)
+                hist = {int(v): int(n) for v, n in zip(*np.unique(ex.cpu().numpy(), return_counts=True))}
+                hist = {("ran_all_%d" % link.numIter if k == 0 else str(k)): v for k, v in hist.items()}
+                tc, cs = tc.cpu().numpy(), cs.cpu().numpy()
+                pts.append({"snr_db": snr_t, "value": B * kt / tdt, "unit": "slots/s", "steps": kt, "ms_per_step": tdt / kt * 1e3,
+                            "block_errors": int(tc[0]), "blocks": int(tc[1]),
+                            "counters_identical_to_reference_schedule": bool((tc == cs).all()),
+                            "exit_iteration_histogram": hist, "blocks_certified": int((ex > 0).sum()),
+                            "blocks_checked_against_full_run": int(ex.numel()),
+                            "mismatches": int(diff.sum()), "verdict_mismatches": int((d0[0][1]['cb_ok'] != d1[0][1]['cb_ok']).sum())})
+            main_pt = next(q for q in pts if q["snr_db"] == float(args.snr))
+            out["certified_early_exit"] = dict(main_pt, checks_at=list(ce.certStages), num_iter=link.numIter, exact_by_construction=True,
+                                               certificate="nrx_ldpc_certify_f64 on the parked decoder state (DESIGN 4.1j; tests/test_gpu_cert.py, "
+                                                           "tests/test_certificate_cpu.py)",
+                                               note="opt-in (off by default; the reference has no early stop, ldpc.py:1545): `value` above stays the fixed schedule",
+                                               points=pts)
+            del ce
         if not args.stub and world == 1 and not args.no_allrows:
             # the same steps with all 46 rows of the base graph (what the reference runs): identical counters, slower
             al = build_link(nr, decoder=args.decoder, skipPuncturedRows=False)
@@ -434,6 +555,11 @@ def main():
             out["ldpc_rows"]["all_rows"] = {"value": B * ka / adt, "unit": "slots/s", "steps": ka,
                                             "counters_identical": bool((ac.cpu().numpy() == cs.cpu().numpy()).all())}
             del al
+        if not args.stub and world == 1 and not args.no_configs and f64:
+            try:
+                out["configs"] = side_configs(nr, ops, sync)
+            except Exception as e:      # (a side configuration never fails the headline measurement)
+                out["configs"] = {"error": repr(e)}
         if not args.stub and not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 at N = 1 only (contract)
             base, parity = cpu_baseline(link, args.snr)
             out["cpu_baseline"] = base

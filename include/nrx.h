@@ -209,6 +209,9 @@ int32_t nrx_ldpc_certify_f64(const void* state, int32_t n_tb, int32_t llr_len, c
                              int32_t iter_now, int32_t n_iter_total, int32_t max_sweeps, int32_t flags, uint8_t* exit_iter,
                              void* stream);
 
+/* Developer hook (no reference counterpart): the shader clock under a float64 load on every CU -- out2_dev[0] / out2_dev[1] = s_memtime
+ * ticks / s_memrealtime (100 MHz) ticks around `spin` x 4 dependent v_fma_f64 per lane; bench.py prices its VALU roofline with it. */
+int32_t nrx_debug_clock_probe(unsigned long long* out2_dev, double* sink_dev, int32_t spin, void* stream);
 /* Developer hook (no reference counterpart): out16[k] = code blocks nrx_ldpc_certify_f64 certified in relaxation sweep k (k < 15),
  * out16[15] = blocks it refused, since the last reset. */
 int32_t nrx_debug_cert_sweeps(unsigned long long* out16, int32_t reset);

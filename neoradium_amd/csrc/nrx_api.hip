@@ -86,3 +86,32 @@ extern "C" int32_t nrx_gold_sequence(uint32_t c_init, int64_t n, uint8_t* out_ho
   }
   return NRX_OK;
 }
+
+// Developer hook for bench.py's roofline: the shader clock under a float64 load on every CU, read on the device -- s_memtime (shader
+// clock counter) against s_memrealtime (constant 100 MHz) around a spin of dependent v_fma_f64 (three waves per SIMD, like the
+// decoder).  out2[0] += s_memtime ticks, out2[1] += s_memrealtime ticks of wave 0 of workgroup 0; clock = 1e8 * out2[0] / out2[1].
+namespace {
+__global__ void __launch_bounds__(768, 1) clock_probe_kernel(unsigned long long* out2, int spin, double* sink) {
+  unsigned long long t0, r0, t1, r1;
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0000001, c = 1e-12;
+  for (int i = 0; i < spin; ++i) {
+    a = __builtin_fma(a, b, c);
+    a = __builtin_fma(a, b, c);
+    a = __builtin_fma(a, b, c);
+    a = __builtin_fma(a, b, c);
+  }
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+  if (a == 12345.678) sink[0] = a;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out2[0] = t1 - t0;
+    out2[1] = r1 - r0;
+  }
+}
+}  // namespace
+extern "C" int32_t nrx_debug_clock_probe(unsigned long long* out2_dev, double* sink_dev, int32_t spin, void* stream) {
+  NRX_REQUIRE(out2_dev && sink_dev && spin > 0, NRX_E_ARG, "nrx_debug_clock_probe: bad argument");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(256), dim3(768), 0, (hipStream_t)stream, out2_dev, spin, sink_dev);
+  NRX_CHECK_LAUNCH("nrx_debug_clock_probe");
+  return NRX_OK;
+}

@@ -306,6 +306,15 @@ def ldpc_recover_decode_merge_two_pass(llr, cfg, nl, qm, first_iter, n_iter, row
     return tb_out, cb_ok
 
 
+def shader_clock_hz(dev, spin=200000):
+    """The shader clock under a float64 load on every CU (nrx_debug_clock_probe: s_memtime against the 100 MHz s_memrealtime), Hz."""
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float64, device=dev)
+    check(lib().nrx_debug_clock_probe(ptr(out), ptr(sink), int(spin), stream()))
+    t, r = [int(x) for x in out.cpu()]
+    return 1e8 * t / max(r, 1)
+
+
 def ldpc_cert_bounds(cfg, rows):
     """nrx_ldpc_cert_bounds (host): (gamma, gamma1, dmax) of the first ``rows`` rows -- the a-priori magnitude bounds the
     early-termination certificate prices its error budget with."""

@@ -66,3 +66,37 @@ def test_counter_all_reduce_through_rccl_world_1(dev):
     assert np.array_equal(np.array(out['table']), ref) and np.array_equal(np.array(out['again']), ref)
     assert np.array_equal(np.array(out['neg']), -ref)
     assert ref[:, 1].min() > 0 and ref[0, 0] > ref[-1, 0]            # blocks were simulated; the low-SNR point fails more often
+
+
+def test_bench_two_ranks_on_one_gpu_with_the_real_engine(dev):
+    """`bench.py --gpus 2` with the REAL PdschLink: two ranks (children started before anything touches the GPU) share the one GPU of
+    a test box, the collectives go through gloo (NRX_BENCH_BACKEND: two RCCL ranks cannot share a device).  One JSON line, n_gpus 2,
+    every rank's slot range counted, and the counters equal those of ONE process running both ranks' timed slot ranges -- the
+    device generator is keyed by the absolute slot number, so sharding must not change a single block."""
+    import torch
+    import neoradium_amd as nr
+    import bench
+    K, W, B = 2, 1, 32
+    env = dict(os.environ, NRX_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', str(K), '--warmup', str(W), '--batch', str(B),
+                        '--no-cpu', '--no-fast', '--no-allrows', '--no-twopass', '--no-cert', '--no-configs'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == K and out['warmup'] == W and out['scaling'] == 'weak'
+    assert out['bler']['blocks'] == 2 * K * B * 72
+    assert out['value'] > 0 and out['roofline']['frac'] > 0
+    # one process, both ranks' timed slot ranges: rank r owns [r (K+W) B, (r+1)(K+W) B), its first W*B slots are warm-up
+    link = bench.build_link(nr, decoder="f64")
+    c = torch.zeros(4, dtype=torch.int64, device=link.dev)
+    for rank in range(2):
+        base = rank * (K + W) * B
+        for k in range(K):
+            link.run(base + (W + k) * B, B, out['config']['snr_db'], seed=123, counters=c)
+    c = c.cpu().numpy()
+    got = out['bler']
+    assert [got['block_errors'], got['blocks'], got['bit_errors'], got['bits']] == [int(v) for v in c]
