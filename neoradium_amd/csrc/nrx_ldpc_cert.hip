@@ -3,6 +3,8 @@
 // stage of nrx_ldpc_dec3.hip parked, and the entry points.  DESIGN 4.1j has the statement and the proof; oracle/certificate.py is
 // the CPU restatement the tests check this against.
 #include <stddef.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "nrx_ldpc_graph.h"
 #include "nrx_common.h"
 
@@ -26,6 +28,9 @@ using namespace nrx_ldpc;
 // w is looked for by Gauss-Seidel relaxation (a row raises its slacks to what (M) asks, doubled, and updates W at once); a sweep
 // in which nothing was raised and nothing failed has verified the final w on a state that did not move: certified.
 // A row's messages take two values (pm1 to every edge but the old argmin, pm2 to that one), so it keeps two slacks.
+// (Tried and not kept: two wave groups per code block -- 768 threads, group g the rows L = g mod 2, LDS atomics -- to put twelve waves
+//  on a CU instead of six: at 168 registers per lane the row body spilled, and a step that is Jacobi inside needed four sweeps where
+//  Gauss-Seidel needs two: 36.8 against 28.8 ms per 256-slot step of the whole chain.)
 struct CertParams {
   double gamma, gamma1;      // a-priori magnitude bounds per unit of the LLR maxima (nrx_ldpc_cert_bounds)
   int32_t dmax, n_iter_total, max_sweeps, flags, iter_now;
@@ -295,6 +300,7 @@ ldpc_certify_kernel(const double* __restrict__ state, int n_cb, const int32_t* _
     if (z == 0) atomicAdd(&g_cert_hist[certified ? (last_sweep < 15 ? last_sweep : 14) : 15], 1ull);
   }
 }
+
 
 }  // namespace nrx_cert
 

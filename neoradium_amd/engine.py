@@ -246,6 +246,7 @@ class PdschLink:
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
         self._sep_rr = bool(int(os.environ.get('NRX_SEPARATE_RATE_RECOVERY', '0')))    # developer switch: demap, then rate recovery
+        self._poison = bool(int(os.environ.get('NRX_DEBUG_POISON', '0')))             # test hook: the rate-recovering demapper's buffer starts as NaN
         self._sep_power = bool(int(os.environ.get('NRX_SEPARATE_POWER', '0')))     # developer switch: noise level in its own pass
         # gain instants on the device (no host -> device copy per batch: such a copy from pageable memory waits for the
         # stream to drain, i.e. for the previous batch's decoder, and the GPU then idles while the host prepares the next one)
@@ -494,7 +495,8 @@ class PdschLink:
             if not fuse and harq is None and self.useMax and details is not True and not self._sep_rr:
                 n_cols = min(ccfg.N // ccfg.Zc, ccfg.K // ccfg.Zc - 2 + ops.ldpc_rows_read(ccfg, cw['rows'], self.decoder == "f32"))
                 rr = ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
-                                   llr_dtype=ldt, rate_recovered=(ccfg, cw['nl'], n_cols))
+                                   llr_dtype=ldt, rate_recovered=(ccfg, cw['nl'], n_cols) if not self._poison else
+                                   (ccfg, cw['nl'], n_cols, torch.full((n * ccfg.C, ccfg.N), float('nan'), dtype=ldt, device=dev)))
             llr = None if rr is not None else \
                 ops.qam_demap(eq, nv, cw['qm'], scr=cw['scr'], re_index=cw['re_index'], scales=sc, nv_floor=1e-10,
                               exact=not self.useMax, llr_dtype=ldt, code_blocks=(ccfg.C, cw['nl']) if fuse else None)

@@ -5,6 +5,7 @@ can take the whole node down), allocates outputs with torch, and enqueues one li
 stream.  Leading batch dimension = Monte-Carlo slots / transport blocks.
 """
 import ctypes as C
+import os
 import numpy as np
 import torch
 
@@ -521,6 +522,11 @@ def ldpc_rows_read(cfg, rows, f32):
     nrx_ldpc_decode_rows_*), all rows for every other graph -- a superset is always safe."""
     total = 46 if cfg.bg == 1 else 42
     rows = total if not rows else int(rows)
+    # the library's developer switches change which kernel runs (NRX_LDPC_ALLROWS / NRX_LDPC_NOSPEC: the float32 decoder reads every
+    # row; the others fall back to kernels with their own row handling): with any of them set, every column counts as read
+    if any(os.environ.get(k) is not None for k in ('NRX_LDPC_ALLROWS', 'NRX_LDPC_NOSPEC', 'NRX_LDPC_NOCHIP64', 'NRX_LDPC_NOCHIP384',
+                                                    'NRX_LDPC_NOHYBRID')):
+        return total
     if cfg.bg == 1 and cfg.Zc == 384:
         for r in ((13, 15, 16, 22, 31) if f32 else (13, 15, 31)):
             if rows <= r:

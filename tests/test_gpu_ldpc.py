@@ -571,3 +571,28 @@ def test_hybrid_decoder_for_more_than_15_rows(dev, rows):
     assert torch.equal(got, ref)
     o = oc.decode(llr[:2], 1, 1, 384, num_iter=11, rows=rows)
     assert np.array_equal(o, got[:2].cpu().numpy())
+
+
+@pytest.mark.parametrize("extra_env", [{}, {"NRX_LDPC_ALLROWS": "1"}, {"NRX_LDPC_NOSPEC": "1"}])
+def test_rate_recovering_demapper_leaves_nothing_the_decoder_reads_uninitialised(dev, extra_env):
+    """nrx_qam_demap_rr_* initialises only the columns the decoder will read (ops.ldpc_rows_read).  With the buffer poisoned with NaN
+    first (NRX_DEBUG_POISON) the float32 chain must count exactly the errors of the route through nrx_ldpc_rate_recover, which
+    zero-fills everything -- also under the developer switches that make the float32 decoder read every row (a child process: the
+    library reads them once)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import neoradium_amd as nr, bench\n"
+        "link = bench.build_link(nr, decoder='f32', num_iter=10)\n"
+        "print(json.dumps(link.run(10, 6, 31.0, seed=7).cpu().tolist()))\n" % root)
+    res = []
+    for env_add in (dict(extra_env, NRX_DEBUG_POISON="1"), dict(extra_env, NRX_SEPARATE_RATE_RECOVERY="1")):
+        env = dict(os.environ, **env_add)
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().split("\n")[-1]))
+    assert res[0] == res[1] and res[0][1] == 6 * 72 and 0 < res[0][0] < res[0][1], res

@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r4
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r4/test_gpu_all.log 2>&1
-tail -15 gpurun_out/r4/test_gpu_all.log
+timeout -k 10 900 python -m pytest tests/test_gpu_ldpc.py -x -q -k "uninitialised" 2>&1 | tail -8
+timeout -k 10 600 python -m pytest tests/test_gpu_cert.py -x -q 2>&1 | tail -3
