@@ -8,7 +8,8 @@ step   = one pass of the whole per-slot hot path (Tx -> OFDM -> CDL channel -> A
 config = BASELINE.json metric: 273 PRB @30 kHz (nFFT 4096), 64-QAM, 4 layers, 4x4 CDL-C 300 ns, LDPC BG1 R=666/1024,
          TBS 606504 (72 code blocks of Zc=384), time-domain channel, DMRS-LS + MMSE.
 value  = slots/s over all ranks (each rank simulates its own slot range; one RCCL all-reduce of the 4 counters), with
-         the float64 chain (the reference's arithmetic: CRC verdicts and hard bits identical to the NumPy path).  The
+         the float64 chain (the reference's arithmetic stage by stage: every stage bit-exact on identical inputs; end to end the
+         FFT / summation order differs in the last bits, which moves ~0.1-0.3 % of the CRC verdicts at the waterfall).  The
          float32 LLR/decoder chain is reported beside it as `fast_mode`, measured with the same steps/warmup.
 
 `--gpus N` without a launcher (no WORLD_SIZE in the environment) starts N ranks itself, before anything touches the GPU:
@@ -322,7 +323,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help="slots per step per GPU (15 GB of device buffers at 256)")
     ap.add_argument('--snr', type=float, default=31.0)
     ap.add_argument('--decoder', default='f64', choices=['f32', 'f64'],
-                    help="f64 (default): the reference's arithmetic end to end; f32: float32 LLRs + decoder (fast mode)")
+                    help="f64 (default): the reference's float64 arithmetic end to end (the wideband precoder applied through the channel filter's gains: "
+                         "same operations up to reassociation, NRX_SEPARATE_PRECODER=1 restores the reference's order); f32: float32 LLRs + decoder (fast mode)")
     ap.add_argument('--waveform', default='f64', choices=['f32', 'f64'],
                     help="f32: complex64 waveform chain (with --decoder f32 = the fast_mode.f32_waveform figure as the main line; never the default)")
     ap.add_argument('--no-cpu', action='store_true', help="skip the CPU-oracle baseline leg")

@@ -246,6 +246,9 @@ class PdschLink:
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
         self._sep_rr = bool(int(os.environ.get('NRX_SEPARATE_RATE_RECOVERY', '0')))    # developer switch: demap, then rate recovery
+        # developer switch: the reference's operation order for the wideband precoder (precode the grid, then modulate the ports and
+        # filter with the plain gains) instead of folding it into the filter's gains (same arithmetic up to reassociation of the precoder)
+        self._sep_prec = bool(int(os.environ.get('NRX_SEPARATE_PRECODER', '0')))
         self._poison = bool(int(os.environ.get('NRX_DEBUG_POISON', '0')))             # test hook: the rate-recovering demapper's buffer starts as NaN
         self._sep_power = bool(int(os.environ.get('NRX_SEPARATE_POWER', '0')))     # developer switch: noise level in its own pass
         # gain instants on the device (no host -> device copy per batch: such a copy from pageable memory waits for the
@@ -387,7 +390,7 @@ class PdschLink:
         # A wideband precoder is the same Nt x Nl matrix on every subcarrier, so it commutes with the modulator: the Nl LAYER
         # grids are modulated (one read of each row) and the precoder goes into the path gains of the channel filter.
         # Per-PRG precoders depend on the subcarrier and are applied to the grid.
-        gfold = None if (self.freqDomain or self.prg) else ops.fold_precoder(gains1, F)
+        gfold = None if (self.freqDomain or self.prg or self._sep_prec) else ops.fold_precoder(gains1, F)
         return gains1, off, H, F, gfold
 
     def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details, harq=None):
@@ -438,6 +441,8 @@ class PdschLink:
         gains1, off, H, F, gfold = ch
         if self.prg:
             grid = ops.precode_prg(grid, F, self.prg_k2g)                       # (n, Nt, L, K); F is applied from here on
+        elif self._sep_prec and not self.freqDomain:
+            grid = ops.precode(grid, F)                                         # (NRX_SEPARATE_PRECODER: pdsch.py / grid.py order)
 
         if self.freqDomain:
             rx = ops.apply_channel_fd(grid if self.prg else ops.precode(grid, F), H)
@@ -451,12 +456,12 @@ class PdschLink:
             lens = [int(v) for v in self.sym_lens[sis]]
             mult = self.nfft / (12.0 * self.bwp.numRbs)
             # the filter leaves the power sums of its output (getRePower) where its kernel supports that ...
-            got = None if self._sep_power else ops.apply_td_paths(tx, gains1 if self.prg else gfold, self.taps, self.tap_off, lens,
+            got = None if self._sep_power else ops.apply_td_paths(tx, gains1 if gfold is None else gfold, self.taps, self.tap_off, lens,
                                                                   hist=self.td_hist, power=(self.nfft, snr_lin, mult, float(self.nfft)))
             if got is not None:
                 ry, sigma, nv = got
             else:           # ... else a second pass over the waveform
-                ry = ops.apply_td_paths(tx, gains1 if self.prg else gfold, self.taps, self.tap_off, lens, hist=self.td_hist)
+                ry = ops.apply_td_paths(tx, gains1 if gfold is None else gfold, self.taps, self.tap_off, lens, hist=self.td_hist)
                 _, sigma, nv = ops.noise_level(ry, snr_lin=snr_lin, mult=mult, nv_mult=float(self.nfft),
                                                gather=self._cp_gather(sis, ry.shape[-1]))
             if noise is not None:

@@ -67,7 +67,13 @@ def ldpc_encode(cbs, cfg, puncture=True, rows=None):
     out = torch.empty((cbs.shape[0], width), dtype=torch.uint8, device=_dev(cbs))
     check(lib().nrx_ldpc_encode(ptr(cbs), cbs.shape[0], C.byref(cfg), 1 if puncture else 0, int(rows or 0), ptr(out), stream()))
     if rows:
-        out._nrx_rows = int(rows)          # the columns of the other rows are unwritten: ldpc_rate_match refuses to read them
+        # the parity columns of the other rows are not computed: they are ZEROED (a view, a clone or a slice of the result must
+        # never expose uninitialised memory), and ldpc_rate_match refuses a transmission that would read them
+        kb = 22 if cfg.bg == 1 else 10
+        first = (kb + int(rows) - (2 if puncture else 0)) * cfg.Zc
+        if first < width:
+            out[:, first:].zero_()
+        out._nrx_rows = int(rows)
     return out
 
 

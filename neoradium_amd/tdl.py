@@ -96,6 +96,7 @@ class TdlChannel(ChannelModel):
             self.rangen = random.getGenerator(self.seed)
         # 'Xiao': the generator as it stands before slot 0's draws -- what staticCoefficientsAt() reproduces any slot's draws from
         self._slot0_state = self._rangenState() if self._static_per_slot else None
+        self._legacy_run = None
         super().restart(restartRanGen, applyToBwp)
 
     def _rangenState(self):
@@ -109,19 +110,35 @@ class TdlChannel(ChannelModel):
         batched engine (PdschLink) prepare any range of slots at once, on any rank."""
         if not self._static_per_slot:
             raise ValueError("staticCoefficientsAt: only the per-slot statistical model (sosType='Xiao') has per-slot coefficients")
+        if self.seed is None:
+            # without its own seed the channel draws from the package-wide generator it shares with the bits and the noise: the
+            # number of draws between two slots is then not this channel's alone and a slot's coefficients cannot be reproduced
+            raise ValueError("staticCoefficientsAt (sosType='Xiao' through PdschLink): the channel needs its own seed (seed=...)")
         nr, nt = self.nrNt
         per_slot = self.sosNumSins * self.numPaths * (1 + nr * nt)       # doubles drawn per slot
         kind, st = self._slot0_state
         if kind == 'pcg':
-            bg = np.random.PCG64()
+            src = getattr(self.rangen, 'generator', self.rangen).bit_generator
+            bg = type(src)()                                              # the same kind of bit generator as the channel's own
+            if not hasattr(bg, 'advance'):
+                raise ValueError(f"staticCoefficientsAt: the channel's bit generator ({type(src).__name__}) cannot jump ahead")
             bg.state = st
             bg.advance(int(slot) * per_slot)                              # Generator.random(): one 64-bit output per double
             g = np.random.Generator(bg)
         else:
+            # legacy RandomState cannot jump: a running copy is kept and moved forward (slots are asked for in ascending order by
+            # the engine; going back restarts from the slot-0 state)
+            cache = getattr(self, '_legacy_run', None)
+            if cache is None or cache[0] > int(slot):
+                g0 = np.random.RandomState()
+                g0.set_state(st)
+                cache = [0, g0]
+            while cache[0] < int(slot):
+                cache[1].random_sample(per_slot)
+                cache[0] += 1
+            self._legacy_run = cache
             g = np.random.RandomState()
-            g.set_state(st)
-            for _ in range(int(slot)):
-                g.random_sample(per_slot)
+            g.set_state(cache[1].get_state())
         return self.staticCoefficients(gen=g)
 
     @property

@@ -219,3 +219,25 @@ def test_headline_path_at_273_prb_against_separate_stages_and_oracle(dev):
         assert np.array_equal(v['cb_ok'][i].cpu().numpy().astype(bool), ref['crc'])
         nb = len(ref['tb_out'])
         assert np.array_equal(v['tb_out'][i].cpu().numpy()[:nb], ref['tb_out'].astype(np.uint8))
+
+
+def test_folded_precoder_against_the_reference_operation_order(dev):
+    """The default time-domain link folds the wideband precoder into the channel filter's gains (sum_t g F computed before filtering):
+    the reference precodes the grid first (pdsch.py / grid.py order).  NRX_SEPARATE_PRECODER=1 restores that order; the two differ
+    by reassociation only: LLRs within 1e-9 of their scale, CRC verdicts equal away from the waterfall."""
+    import os
+    import bench
+    import neoradium_amd as nr
+    folded = bench.build_link(nr, decoder="f64", num_iter=10)
+    os.environ['NRX_SEPARATE_PRECODER'] = '1'
+    try:
+        separate = bench.build_link(nr, decoder="f64", num_iter=10)
+    finally:
+        del os.environ['NRX_SEPARATE_PRECODER']
+    assert separate._sep_prec and not folded._sep_prec
+    _, d0 = folded.run(77, 2, 36.0, seed=9, details=True)
+    _, d1 = separate.run(77, 2, 36.0, seed=9, details=True)
+    a, b = d0[0][1]['llr'], d1[0][1]['llr']
+    scale = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 1e-9 * scale
+    assert (d0[0][1]['cb_ok'] == d1[0][1]['cb_ok']).all()
