@@ -106,9 +106,10 @@ ldpc_certify_kernel(const double* __restrict__ state, int n_cb, const int32_t* _
     const double beta = cp.gamma * lam_all;
     const double E_ = 2.0 * cp.n_iter_total * cp.dmax * 0x1p-53 * beta * 1.0625;
     const double rmin = (cp.gamma1 > 1.0 ? cp.gamma1 : 1.0) * lam_pe * (1 + 1e-9) + E_;
-    const double mcap_ = 0.75 * (1.0e5 - rmin) * (1 - 1e-9) - E_;
+    const double mcap_ = 0.75 * (1.0e5 - rmin) * (1 - 1e-9) - E_;                       // core rows: their smallest |t| stays below gamma1 * lam_pe
+    const double mcapx_ = 0.75 * (1.0e5 - (lam_pe * (1 + 1e-9) + E_)) * (1 - 1e-9) - E_;   // rows with their own degree-1 column: below that column's |LLR| + E
     const double E = uniform(E_), zeta = uniform(4.0 * E_), G = uniform(4.0 * E_);
-    const double mcap = uniform(mcap_);
+    const double mcap = uniform(mcap_), mcapx = uniform(mcapx_);
     const bool bounds_ok = beta < 2.5e8 && lam_all < 1e9 && mcap > 0.0 && beta == beta && mcap == mcap;     // (NaN / inf refuse)
     // ---- the frozen state
     const double* st = state + (size_t)cb * SL::NF * ZC + z;
@@ -246,7 +247,7 @@ ldpc_certify_kernel(const double* __restrict__ state, int n_cb, const int32_t* _
         // ---- (S): even parity of the hard decisions, the second smallest floor positive (at most one edge may sit at or under
         // zero), every posterior clear of the slack it may lose, no message above mcap
         const double am1 = __builtin_fabs(pm1) * 0x1p-7, am2 = __builtin_fabs(pm2) * 0x1p-7;      // |messages| (exact)
-        const bool bad = (__builtin_popcount(srw) & 1) != 0 || !(a2 > 0.0) || pmin < G || am1 > mcap || am2 > mcap;
+        const bool bad = (__builtin_popcount(srw) & 1) != 0 || !(a2 > 0.0) || pmin < G || am1 > (EXT ? mcapx : mcap) || am2 > (EXT ? mcapx : mcap);
         if ((cp.flags & 1) == 0) dead |= bad;
         // ---- (M): the normalised messages nu = s m.  Their signs as bit words (bit D-1-j = edge j): old extrinsic sign ^ row parity of
         // the message ^ sign of the posterior.  pm1-messages go to every edge but the old argmin, the pm2-message to that one.

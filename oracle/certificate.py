@@ -105,17 +105,18 @@ def growth_bounds(bgn, rows, filler_cols=()):
 def margins(gb, lam_all, lam_pe, num_iter=50):
     """The error budget of the proof.  E bounds |r_c - (L_c + sum_j m_{j,c})| over the whole run: two roundings per
     (row, column) visit, each at most 2^-53 of a magnitude below beta = gamma * max|LLR|.  zeta = the slack of a floor under its
-    frozen message, delta = what a future extrinsic value of a core column can lose against the frozen one, G = the sign margin
-    asked of every edge, mcap = the largest frozen message for which the +1e5 quirk (ldpc.py:1563) cannot push a later message
-    under its floor: 0.75 * (1e5 - the largest minimum a row can ever have) with that minimum <= gamma1 * lam_pe for the core rows
-    and <= lam_pe for the rows that own a degree-1 column."""
+    frozen message, delta = what a future extrinsic value of a core column can lose against the frozen one (kept for reference: the
+    relaxation works with per-message slacks), G = the sign margin asked of every posterior, mcap / mcapx = the largest frozen message
+    of a core row / of a row that owns a degree-1 column for which the +1e5 quirk (ldpc.py:1563) cannot push a later message under
+    its floor: 0.75 * (1e5 - the largest minimum such a row can ever have), that minimum being <= gamma1 * lam_pe resp. <= lam_pe + E."""
     beta = gb['gamma'] * lam_all
     E = 2.0 * num_iter * gb['dmax'] * U53 * beta * 1.0625
     zeta = 4.0 * E
     delta = (gb['dmax'] - 1) * zeta + 2.0 * E
     rmin = max(gb['gamma1'], 1.0) * lam_pe * (1 + 1e-9) + E
-    mcap = 0.75 * (1.0e5 - rmin) * (1 - 1e-9) - E
-    return dict(beta=beta, E=E, zeta=zeta, delta=delta, G=2.0 * delta, mcap=mcap)
+    mcap = 0.75 * (1.0e5 - rmin) * (1 - 1e-9) - E                                   # core rows
+    mcapx = 0.75 * (1.0e5 - (lam_pe * (1 + 1e-9) + E)) * (1 - 1e-9) - E              # rows that own a degree-1 column
+    return dict(beta=beta, E=E, zeta=zeta, delta=delta, G=4.0 * E, mcap=mcap, mcapx=mcapx)
 
 
 def certify(r, msg, cols, bg, zc, ncore, gb, lam_all, lam_pe, num_iter=50, flags=0, sweeps=6, stats=None):
@@ -151,7 +152,7 @@ def certify(r, msg, cols, bg, zc, ncore, gb, lam_all, lam_pe, num_iter=50, flags
         sg = np.where(sr, -1.0, 1.0)
         ext = cl[-1] >= ncore
         rows.append(dict(cl=cl, sh=sh, tau=(rs - ms) * sg, nu=ms * sg, ext=ext, absr=np.abs(rs)))
-        fail_q |= bool((np.abs(ms) > mcap).any())
+        fail_q |= bool((np.abs(ms) > (mg['mcapx'] if ext else mcap)).any())
         par_bad |= bool(((sr.sum(0) & 1) == 1).any())
     w = [np.full(rw['tau'].shape, zeta) for rw in rows]
     for rw, wi in zip(rows, w):
