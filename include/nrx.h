@@ -204,6 +204,15 @@ int32_t nrx_ldpc_cert_bounds(const nrx_ldpc_cfg* cfg, int32_t n_rows, double* ou
 int32_t nrx_ldpc_stage_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
                                         int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,
                                         const int32_t* sel, const int32_t* n_sel, void* state, double* lam, void* stream);
+/* The same stage with the certificate evaluated INSIDE the kernel's tail, on the state the workgroup still holds (posterior columns in
+ * LDS, check-node state in registers; only the slack sums and the rows' slacks go through `scratch`, 2 * 56 * 384 floats per workgroup of the
+ * launch, which takes as many workgroups as fit): a block whose CRC passes and whose state holds the certificate gets
+ * exit_iter[cb] = min(iter_now, 255) and does NOT park; every other block that ran parks.  No nrx_ldpc_certify_f64 launch is needed. */
+int32_t nrx_ldpc_stage_certify_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
+                                                int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,
+                                                const int32_t* sel, const int32_t* n_sel, void* state, double* lam, uint8_t* exit_iter,
+                                                void* scratch, size_t scratch_bytes, int32_t iter_now, int32_t n_iter_total,
+                                                int32_t max_sweeps, int32_t flags, void* stream);
 int32_t nrx_ldpc_certify_f64(const void* state, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm,
                              int32_t n_rows, const int32_t* sel, const int32_t* n_sel, const uint8_t* cb_ok, const double* lam,
                              int32_t iter_now, int32_t n_iter_total, int32_t max_sweeps, int32_t flags, uint8_t* exit_iter,

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include "nrx_ldpc_graph.h"
+#include "nrx_ldpc_certcore.h"
 #include "nrx_common.h"
 
 #ifndef NRX_DEC3_HYB_RC
@@ -271,6 +272,12 @@ struct FuseArgs {
   // received position that is not a filler, and over the core-parity + extension columns alone (written by the stage that fills
   // from the LLRs; nrx_ldpc_certify_f64 prices its error budget and the +1e5 quirk with them)
   double* lam;
+  // MODE bit 2, optional (cert_w != NULL): the stability certificate is evaluated in the kernel's tail on the state the workgroup
+  // still holds (nrx_ldpc_certcore.h); a block that holds it gets exit_iter[cb] = cp.iter_now and does NOT park.  cert_w = scratch for
+  // the slack sums and the rows' slacks, (CORE + 2 ROWS) * Zc floats per code-block slot of the launch (grid * NS slots)
+  float* cert_w;
+  uint8_t* exit_iter;
+  nrx_certcore::Params cp;
 };
 // The kernel reads FuseArgs through the kernarg segment pointer at the two places that need it (initial fill, tail)
 // instead of through its parameter: as a parameter its ten scalars and two pointers stay live across the whole layer
@@ -793,7 +800,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       }
       if constexpr ((MODE & 1) != 0) {
         __syncthreads();
-        if (live && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u)) {      // CRC failed (bit 2: or not): park the state for the continuation launch
+        // MODE bit 2: EVERY block parks its state; then, where asked for (cert_w != NULL), the stability certificate is evaluated on the
+        // spot -- posterior columns still in LDS, the check-node state read back from what this lane just parked -- and a block
+        // that holds it gets its exit iteration: the caller's work list of the next stage leaves it out.
+        if (live && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u)) {      // park the state for the continuation launch
           using SL = StateLay<BG, RA>;
           double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
           static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
@@ -814,6 +824,28 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
             st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgn[decltype(i)::value]);
           });
+        }
+        if constexpr ((MODE & 4) != 0) {
+          if (fa->cert_w != nullptr) {             // (kernel-uniform)
+            using SL = StateLay<BG, RA>;
+            nrx_certcore::Params cp;
+            cp.gamma = fa->cp.gamma; cp.gamma1 = fa->cp.gamma1; cp.dmax = fa->cp.dmax; cp.n_iter_total = fa->cp.n_iter_total;
+            cp.max_sweeps = fa->cp.max_sweeps; cp.flags = fa->cp.flags; cp.iter_now = fa->cp.iter_now;
+            const bool crc = red[NS * (ZC / 64) + slot] != 0u;
+            const double* lam = fa->lam;
+            const double la = __hip_atomic_load(lam + 2 * (size_t)cbm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double lp = __hip_atomic_load(lam + 2 * (size_t)cbm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float* Wg = fa->cert_w + ((size_t)blockIdx.x * NS + slot) * (size_t)((B::CORE + 2 * B::ROWS) * ZC);
+            const double* stc = fa->state + (size_t)cbm * SL::NF * ZC + zt;
+            const double c0c = stc[(size_t)SL::C0 * ZC];
+            __syncthreads();                       // (the CRC flags have been read: the padding words are free again)
+            const bool want = live && (crc || (cp.flags & 4) != 0);
+            const nrx_certcore::lds_cd Pc = (nrx_certcore::lds_cd)(Praw + ZS + slot * BUF);
+            // (with filler bits the row pass also has to recognise their posteriors: 7 more instructions per edge)
+            const bool settled = fa->g.F > 0 ? nrx_certcore::certify_on_chip<BG, ZI, RA, true, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64))
+                                             : nrx_certcore::certify_on_chip<BG, ZI, RA, false, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64));
+            if (settled && zt == 0) fa->exit_iter[cb] = (uint8_t)(cp.iter_now < 255 ? cp.iter_now : 255);
+          }
         }
       }
     }
@@ -931,7 +963,8 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
                                          int32_t nl, int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out,
                                          uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream,
                                          int mode = 0, double* state = nullptr, size_t* state_bytes_per_cb = nullptr,
-                                         double* lam = nullptr, int* rows_run = nullptr) {
+                                         double* lam = nullptr, int* rows_run = nullptr, float* cert_w = nullptr, size_t cert_w_bytes = 0,
+                                         uint8_t* exit_iter = nullptr, const nrx_certcore::Params* cp = nullptr) {
   using namespace nrx_dec3;
   NRX_REQUIRE(llr && cfg && tb_out && cb_ok, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: NULL buffer");
   NRX_REQUIRE(nl >= 1 && qm >= 1 && llr_len > 0 && n_tb >= 0 && n_iter >= 0, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: bad argument");
@@ -945,6 +978,9 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   fa.state = state;
   fa.ws = nullptr;
   fa.lam = lam;
+  fa.cert_w = nullptr;
+  fa.exit_iter = exit_iter;
+  fa.cp = nrx_certcore::Params{};
   FuseGeom& fg = fa.g;
   fg.C = cfg->C; fg.f = f; fg.qm = qm; fg.F = cfg->F; fg.llr_len = llr_len; fg.cb_len = cfg->cb_len;
   fg.e_small = (gb / cfg->C) * f;
@@ -973,7 +1009,15 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   if (rc) return rc;
   const int n_cb = n_tb * cfg->C;
   const int n_wg = (n_cb + 1) / 2;
-  const int grid = n_wg < 1024 ? n_wg : 1024;
+  int grid = n_wg < 1024 ? n_wg : 1024;
+  if (cert_w) {            // the in-kernel certificate: its slack sums need 26 * 384 floats per code-block slot of the launch
+    NRX_REQUIRE(cp && exit_iter && lam && (mode & 4), NRX_E_ARG, "nrx_ldpc_stage_certify_decode_merge: missing certificate argument");
+    const size_t per_wg = 2 * sizeof(float) * (26 + 2 * 15) * 384;      // slack sums of 26 columns + two slacks per row and lane
+    NRX_REQUIRE(cert_w_bytes >= per_wg, NRX_E_ARG, "nrx_ldpc_stage_certify_decode_merge: scratch of %zu bytes (one workgroup needs %zu)", cert_w_bytes, per_wg);
+    if ((size_t)grid > cert_w_bytes / per_wg) grid = (int)(cert_w_bytes / per_wg);
+    fa.cert_w = cert_w;
+    fa.cp = *cp;
+  }
   constexpr int ZI384 = zindex_c(384);
   hipStream_t st = (hipStream_t)stream;
 #define NRX_FUSED_LAUNCH(RA_, MODE_) \
@@ -1040,6 +1084,34 @@ int32_t nrx_ldpc_fused_rows_run(const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm,
   uint8_t dummy = 0;
   const double d0 = 0;
   return recover_decode_merge_impl(&d0, 1, llr_len, cfg, nl, qm, 1, n_rows, &dummy, &dummy, nullptr, nullptr, nullptr, 0, nullptr, &per, nullptr, rows_run);
+}
+
+// A stage with the certificate evaluated in the kernel's tail (nrx_ldpc_certcore.h): nrx_ldpc_stage_decode_merge_f64, and a block
+// whose CRC passes and whose state holds the stability certificate gets exit_iter[cb] = min(iter_now, 255) and does not park.
+extern "C" int32_t nrx_ldpc_stage_certify_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
+                                                           int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,
+                                                           const int32_t* sel, const int32_t* n_sel, void* state, double* lam,
+                                                           uint8_t* exit_iter, void* scratch, size_t scratch_bytes, int32_t iter_now,
+                                                           int32_t n_iter_total, int32_t max_sweeps, int32_t flags, void* stream) {
+  NRX_REQUIRE(state && lam && exit_iter && scratch, NRX_E_ARG, "nrx_ldpc_stage_certify_decode_merge: NULL state / maxima / exit_iter / scratch");
+  NRX_REQUIRE((sel == nullptr) == (n_sel == nullptr), NRX_E_ARG, "nrx_ldpc_stage_certify_decode_merge: selection list without its count");
+  NRX_REQUIRE(iter_now >= 1 && n_iter_total >= iter_now && max_sweeps >= 1, NRX_E_ARG, "nrx_ldpc_stage_certify_decode_merge: bad iteration counts");
+  int rows_run = 0;
+  const int32_t rr = nrx_ldpc_fused_rows_run(cfg, nl, qm, llr_len, n_rows, &rows_run);
+  if (rr) return rr;
+  double b3[3];
+  const int32_t rb = nrx_ldpc_cert_bounds(cfg, rows_run, b3);
+  if (rb) return rb;
+  nrx_certcore::Params cp;
+  cp.gamma = b3[0]; cp.gamma1 = b3[1]; cp.dmax = (int32_t)b3[2]; cp.n_iter_total = n_iter_total; cp.max_sweeps = max_sweeps; cp.flags = flags;
+  cp.iter_now = iter_now;
+  if (sel == nullptr) {
+    NRX_REQUIRE(llr, NRX_E_ARG, "nrx_ldpc_stage_certify_decode_merge: NULL llr");
+    return recover_decode_merge_impl(llr, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, nullptr, nullptr, stream, 5, (double*)state,
+                                     nullptr, lam, nullptr, (float*)scratch, scratch_bytes, exit_iter, &cp);
+  }
+  return recover_decode_merge_impl((const double*)state, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, sel, n_sel, stream, 7,
+                                   (double*)state, nullptr, lam, nullptr, (float*)scratch, scratch_bytes, exit_iter, &cp);
 }
 
 // One STAGE of the certified schedule on the fused entry: n_iter iterations of every block (sel == NULL: from the LLRs, which

@@ -106,7 +106,7 @@ def gain_times(tables, slots):
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
                  decoder="f64", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
-                 skipPuncturedRows=True, waveform="f64", certifiedExit=None, certFlags=0, certSweeps=8):
+                 skipPuncturedRows=True, waveform="f64", certifiedExit=None, certFlags=0, certSweeps=8, certInKernel=True):
         if waveform not in ("f32", "f64"):
             raise ValueError("waveform must be 'f64' (the reference's complex128 waveforms, default) or 'f32' (time-domain link only: "
                              "Tx grid, OFDM, channel filter and received grid in complex64 -- not the parity path)")
@@ -148,6 +148,7 @@ class PdschLink:
             self.certStages = None
         self.certFlags = int(certFlags)
         self.certSweeps = int(certSweeps)      # relaxation sweeps the certificate may take before it refuses
+        self.certInKernel = bool(certInKernel) # the certificate in the stage kernel's tail (default) or as its own launch on the parked states
         self.last_exit_iter = None          # (n_cb,) uint8 of the last batch that ran the certified schedule
         if firstPassIter is None:
             self.firstPassIter, self.passStages = None, ()
@@ -509,7 +510,7 @@ class PdschLink:
                 if not fuse:
                     raise ValueError("certifiedExit needs the fused float64 decoder entry (BG1, Zc 384, first transmission, <= 15 rows, max-log LLRs)")
                 got = ops.ldpc_recover_decode_merge_certified(llr, ccfg, cw['nl'], cw['qm'], self.certStages, self.numIter, rows=cw['rows'],
-                                                              flags=self.certFlags, max_sweeps=self.certSweeps)
+                                                              flags=self.certFlags, max_sweeps=self.certSweeps, in_kernel=self.certInKernel)
                 fused = None if got is None else got[:2]
                 self.last_exit_iter = None if got is None else got[2]
             elif fuse and self.firstPassIter is not None:     # two passes, both on the fused entry, the failing blocks' list on the device

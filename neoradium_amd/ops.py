@@ -331,15 +331,18 @@ def ldpc_cert_bounds(cfg, rows):
 
 
 _cert_bufs = {}
+_cert_scratch = {}
 
 
-def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0, max_sweeps=8, flags=0):
+def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0, max_sweeps=8, flags=0, in_kernel=True):
     """The CERTIFIED early exit on the fused entry (opt-in; the reference has no early stop, ldpc.py:1545).  ``stages`` = ascending
     iteration counts at which the blocks still running are checked: a block whose CRC24B passes AND whose frozen decoder state holds
     the stability certificate (nrx_ldpc_certify_f64: every later iteration provably leaves its hard decisions unchanged) stops there;
     every other block continues from its parked state, the last ones to ``n_iter``.  Work lists stay on the device.
     -> (tb_out, cb_ok, exit_iter uint8 (n_cb,): the iteration a block was certified at, 0 = ran all n_iter), or None when the
-    configuration has no fused instantiation.  ``flags`` != 0 breaks the certificate on purpose (tests only)."""
+    configuration has no fused instantiation.  ``flags`` != 0 breaks the certificate on purpose (tests only).  ``in_kernel`` (default):
+    the certificate is evaluated in the stage kernel's tail (nrx_ldpc_stage_certify_decode_merge_f64: a certified block never parks);
+    False: stage, then the stand-alone nrx_ldpc_certify_f64 on the parked states -- the same conditions, another search order."""
     if llr.dtype != torch.float64 or llr.dim() != 2 or not (cfg.bg == 1 and cfg.Zc == 384 and cfg.C > 1):
         return None
     llr = llr.contiguous()
@@ -368,6 +371,30 @@ def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0
         raise ValueError("stages must hold at least one iteration count below n_iter")
     L = lib()
     cfgp, r = C.byref(cfg), int(rows or 0)
+    if in_kernel:
+        n_wg = min((n_cb + 1) // 2, 1024)
+        need = n_wg * 2 * (26 + 2 * 15) * 384 * 4
+        scr = _cert_scratch.get(key)
+        if scr is None or scr.numel() < need:
+            scr = _cert_scratch[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        sw = min(int(max_sweeps), 4)
+        check(L.nrx_ldpc_stage_certify_decode_merge_f64(ptr(llr), n_tb, G, cfgp, nl, qm, marks[0], r, ptr(tb_out), ptr(cb_ok), None, None, ptr(state),
+                                                        ptr(lam), ptr(exit_iter), ptr(scr), scr.numel(), marks[0], int(n_iter), sw, int(flags), stream()))
+        done = marks[0]
+        sels = (sel_a, sel_b)
+        for k, upto in enumerate(marks[1:] + [int(n_iter)]):
+            last = k == len(marks) - 1
+            sel, n_sel = sels[k & 1], cnt[(k & 1):(k & 1) + 1]
+            check(L.nrx_select_failed(ptr(exit_iter), n_cb, ptr(sel), ptr(n_sel), stream()))
+            if last:
+                check(L.nrx_ldpc_resume_decode_merge_sel_f64(n_tb, G, cfgp, nl, qm, upto - done, r, ptr(tb_out), ptr(cb_ok), ptr(sel), ptr(n_sel),
+                                                             ptr(state), 0, stream()))
+            else:
+                check(L.nrx_ldpc_stage_certify_decode_merge_f64(None, n_tb, G, cfgp, nl, qm, upto - done, r, ptr(tb_out), ptr(cb_ok), ptr(sel),
+                                                                ptr(n_sel), ptr(state), ptr(lam), ptr(exit_iter), ptr(scr), scr.numel(), upto,
+                                                                int(n_iter), sw, int(flags), stream()))
+            done = upto
+        return tb_out, cb_ok, exit_iter
     check(L.nrx_ldpc_stage_decode_merge_f64(ptr(llr), n_tb, G, cfgp, nl, qm, marks[0], r, ptr(tb_out), ptr(cb_ok), None, None,
                                             ptr(state), ptr(lam), stream()))
     check(L.nrx_ldpc_certify_f64(ptr(state), n_tb, G, cfgp, nl, qm, r, None, None, ptr(cb_ok), ptr(lam), marks[0], int(n_iter),

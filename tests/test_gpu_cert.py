@@ -20,12 +20,14 @@ def _metric_link(**kw):
     return bench.build_link(nr, decoder="f64", num_iter=50, **kw)
 
 
-def test_certified_blocks_equal_the_fixed_schedule_over_the_waterfall(dev):
+@pytest.mark.parametrize("in_kernel", [True, False])
+def test_certified_blocks_equal_the_fixed_schedule_over_the_waterfall(dev, in_kernel):
     """>= 1e5 code blocks, 29 ... 35 dB (code-block error rate ~0.6 ... 0): transport-block bits and CRC verdicts of the certified
-    schedule identical to the fixed 50-iteration schedule for EVERY block, certified or not."""
+    schedule identical to the fixed 50-iteration schedule for EVERY block, certified or not -- with the certificate evaluated in the
+    stage kernel's tail (the default) and as its own launch on the parked states."""
     import torch
     fixed = _metric_link()
-    certd = _metric_link(certifiedExit=(8, 14, 24))
+    certd = _metric_link(certifiedExit=(8, 14, 24), certInKernel=in_kernel)
     C, pay = fixed.cfg.C, fixed.cfg.cb_len - 24
     total = certified = 0
     hist = {}
@@ -52,13 +54,14 @@ def test_a_broken_certificate_is_caught(dev):
     """Without its conditions (flags 7: no sign / closure conditions, CRC filter off) everything 'certifies' at the first check
     and blocks that had not converged differ from the fixed schedule: the comparison above would fail."""
     fixed = _metric_link()
-    broken = _metric_link(certifiedExit=(8, 16), certFlags=7)
     pay = fixed.cfg.cb_len - 24
     _, d0 = fixed.run(50, 16, 30.5, seed=2, details="verdicts")
-    _, d1 = broken.run(50, 16, 30.5, seed=2, details="verdicts")
-    assert (broken.last_exit_iter == 8).all()
-    diff = (d0[0][1]['tb_out'].reshape(-1, pay) != d1[0][1]['tb_out'].reshape(-1, pay)).any(1)
-    assert int(diff.sum()) > 0
+    for in_kernel in (True, False):
+        broken = _metric_link(certifiedExit=(8, 16), certFlags=7, certInKernel=in_kernel)
+        _, d1 = broken.run(50, 16, 30.5, seed=2, details="verdicts")
+        assert (broken.last_exit_iter == 8).all()
+        diff = (d0[0][1]['tb_out'].reshape(-1, pay) != d1[0][1]['tb_out'].reshape(-1, pay)).any(1)
+        assert int(diff.sum()) > 0, in_kernel
 
 
 @pytest.mark.parametrize("tbs,qm,nl,e_bits", [(25000, 6, 4, 13000), (25000, 2, 1, 12300), (33000, 4, 2, 13000)])
@@ -102,16 +105,17 @@ def test_fillers_zeros_saturation_and_both_instantiations(dev, tbs, qm, nl, e_bi
                 off += E
         xd = deint(x)
         tb_ref, ok_ref = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, n_iter, rows=rows)
-        tb_c, ok_c, ex = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (5, 9, 14), n_iter, rows=rows)
-        assert torch.equal(ok_c, ok_ref) and torch.equal(tb_c, tb_ref), saturate
-        exn = ex.cpu().numpy().reshape(n_tb, cfg.C)
-        okn = ok_ref.cpu().numpy().astype(bool)
-        if saturate:
-            assert (exn == 0).all(), "a block with a saturated LLR outside the fillers was certified"
-        else:
-            # (a marginal block may pass its CRC only after the last check: it runs to the end)
-            assert (exn[okn] > 0).mean() > 0.5 and (exn[~okn] == 0).all(), (exn, okn)
-            assert 0 < okn.sum() < okn.size
+        for in_kernel in (True, False):
+            tb_c, ok_c, ex = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (5, 9, 14), n_iter, rows=rows, in_kernel=in_kernel)
+            assert torch.equal(ok_c, ok_ref) and torch.equal(tb_c, tb_ref), (saturate, in_kernel)
+            exn = ex.cpu().numpy().reshape(n_tb, cfg.C)
+            okn = ok_ref.cpu().numpy().astype(bool)
+            if saturate:
+                assert (exn == 0).all(), "a block with a saturated LLR outside the fillers was certified"
+            else:
+                # (a marginal block may pass its CRC only after the last check: it runs to the end)
+                assert (exn[okn] > 0).mean() > 0.5 and (exn[~okn] == 0).all(), (exn, okn, in_kernel)
+                assert 0 < okn.sum() < okn.size
 
 
 def test_gpu_certificate_against_the_oracle_on_a_slot(dev):

@@ -29,10 +29,11 @@ def main():
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--sweeps', type=int, default=8)
+    ap.add_argument('--standalone', action='store_true', help='the certificate as its own launch on the parked states')
     ap.add_argument('--json', default='')
     a = ap.parse_args()
     fixed = bench.build_link(nr, decoder="f64", num_iter=a.iters)
-    cert = bench.build_link(nr, decoder="f64", num_iter=a.iters, certifiedExit=tuple(a.stages), certFlags=a.flags, certSweeps=a.sweeps)
+    cert = bench.build_link(nr, decoder="f64", num_iter=a.iters, certifiedExit=tuple(a.stages), certFlags=a.flags, certSweeps=a.sweeps, certInKernel=not a.standalone)
     C = fixed.cfg.C
     pay = fixed.cfg.cb_len - 24
     out = {}
