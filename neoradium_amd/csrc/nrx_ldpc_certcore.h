@@ -32,6 +32,18 @@ __device__ __forceinline__ double sel_fnma_x(double x, uint32_t oidx, double u, 
       : [y] "=&v"(y) : [x] "v"(x), [j] "n"(J), [oidx] "v"(oidx), [u] "v"(u), [p1] "v"(p1), [p2] "v"(p2) : "vcc");
   return y;
 }
+// x - (oidx == J ? k2 : k1); the lanes of the old argmin also copy the result into tlo (EXEC instead of five selects)
+template <int J>
+__device__ __forceinline__ double sel_sub_x(double x, uint32_t oidx, double k1, double k2, double& tlo) {
+  double y;
+  asm("v_add_f64 %[y], %[x], -%[k1]\n\t"
+      "v_cmpx_eq_u32_e32 vcc, %[j], %[oidx]\n\t"
+      "v_add_f64 %[y], %[x], -%[k2]\n\t"
+      "v_mov_b64 %[tlo], %[y]\n\t"
+      "s_mov_b64 exec, -1"
+      : [y] "=&v"(y), [tlo] "+v"(tlo) : [x] "v"(x), [j] "n"(J), [oidx] "v"(oidx), [k1] "v"(k1), [k2] "v"(k2) : "vcc");
+  return y;
+}
 __device__ __forceinline__ double flip_by(double x, double s) {
   u32x2 v = __builtin_bit_cast(u32x2, x);
   v.y ^= hi32(s) & 0x80000000u;
@@ -181,7 +193,7 @@ __device__ __forceinline__ bool certify_on_chip(const Params& cp, double lam_all
           double tl;
           if constexpr (col < B::CORE) {
             const double x = tau - (double)W[j];
-            tl = x - ((uint32_t)j == oidx ? k2 : k1);
+            tl = sel_sub_x<j>(x, oidx, k1, k2, tlo);      // x - (j == oidx ? k2 : k1), and tlo <- that where j == oidx
             double pr = __builtin_fabs(rj) - (double)W[j];
             if constexpr (HASF) {
               const bool hg = __builtin_fabs(rj) >= 5.0e8;
@@ -190,7 +202,6 @@ __device__ __forceinline__ bool certify_on_chip(const Params& cp, double lam_all
               pr = hg ? 1.0e300 : pr;
             }
             pmin = fmin2(pmin, pr);
-            tlo = (uint32_t)j == oidx ? tl : tlo;
           } else {
             tl = tau - 2.0 * E;
             if constexpr (HASF) hgw <<= 1;

@@ -803,15 +803,23 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         // MODE bit 2: EVERY block parks its state; then, where asked for (cert_w != NULL), the stability certificate is evaluated on the
         // spot -- posterior columns still in LDS, the check-node state read back from what this lane just parked -- and a block
         // that holds it gets its exit iteration: the caller's work list of the next stage leaves it out.
-        if (live && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u)) {      // park the state for the continuation launch
+        // (the check-node state first: it is all the certificate reads back; the posterior columns follow behind the certificate, and
+        //  only for the blocks that have to go on)
+        const bool parks = live && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u);
+        const bool cert_here = (MODE & 4) != 0 && fa->cert_w != nullptr;      // (kernel-uniform)
+        auto park_columns = [&]() __attribute__((always_inline)) {
           using SL = StateLay<BG, RA>;
           double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
           static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value + 1;
             st[(size_t)(SL::COL + c - 1) * ZC] = Ps[c * ZS + zt];
           });
-          st[(size_t)SL::C0 * ZC] = c0;
           st[(size_t)SL::F1 * ZC] = f1;
+        };
+        if (parks) {      // park the state for the continuation launch
+          using SL = StateLay<BG, RA>;
+          double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
+          st[(size_t)SL::C0 * ZC] = c0;
           static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
             constexpr int L = decltype(lc)::value;
             st[(size_t)(SL::M1 + L) * ZC] = m1[L];
@@ -824,6 +832,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
             st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgn[decltype(i)::value]);
           });
+          if (!cert_here) park_columns();
         }
         if constexpr ((MODE & 4) != 0) {
           if (fa->cert_w != nullptr) {             // (kernel-uniform)
@@ -845,6 +854,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             const bool settled = fa->g.F > 0 ? nrx_certcore::certify_on_chip<BG, ZI, RA, true, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64))
                                              : nrx_certcore::certify_on_chip<BG, ZI, RA, false, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64));
             if (settled && zt == 0) fa->exit_iter[cb] = (uint8_t)(cp.iter_now < 255 ? cp.iter_now : 255);
+            if (parks && !settled) park_columns();
           }
         }
       }
