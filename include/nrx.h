@@ -218,6 +218,15 @@ int32_t nrx_ldpc_certify_f64(const void* state, int32_t n_tb, int32_t llr_len, c
                              int32_t iter_now, int32_t n_iter_total, int32_t max_sweeps, int32_t flags, uint8_t* exit_iter,
                              void* stream);
 
+/* The certified early exit for ANY configuration (both base graphs, every lifting size, any row count): ldpc.py:1495-1581 decode of
+ * rate-recovered LLRs (n_cb, N) -> hard decisions of the K information bits, with the certificate evaluated after the iterations
+ * checks[0 .. n_checks) (host array, ascending, <= 8): a block that holds it stops there, exit_iter[cb] = that iteration (0 = it ran
+ * all n_iter).  Plain kernel with its state in `ws` (n_cb * nrx_ldpc_decode_certified_ws_bytes bytes) -- the tuned form for the metric
+ * configuration is nrx_ldpc_stage_certify_decode_merge_f64. */
+int64_t nrx_ldpc_decode_certified_ws_bytes(const nrx_ldpc_cfg* cfg, int32_t n_rows);
+int32_t nrx_ldpc_decode_certified_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
+                                      const int32_t* checks, int32_t n_checks, uint8_t* hard_out, uint8_t* exit_iter, void* ws,
+                                      size_t ws_bytes, int32_t max_sweeps, int32_t flags, void* stream);
 /* Developer hook (no reference counterpart): the shader clock under a float64 load on every CU -- out2_dev[0] / out2_dev[1] = s_memtime
  * ticks / s_memrealtime (100 MHz) ticks around `spin` x 4 dependent v_fma_f64 per lane; bench.py prices its VALU roofline with it. */
 int32_t nrx_debug_clock_probe(unsigned long long* out2_dev, double* sink_dev, int32_t spin, void* stream);

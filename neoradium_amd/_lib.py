@@ -56,6 +56,8 @@ SIGNATURES = {
     'nrx_ldpc_stage_decode_merge_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     'nrx_ldpc_stage_certify_decode_merge_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp]),
     'nrx_ldpc_certify_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    'nrx_ldpc_decode_certified_ws_bytes': (i64, [_cfgp, i32]),
+    'nrx_ldpc_decode_certified_f64': (i32, [vp, i32, _cfgp, i32, i32, vp, i32, vp, vp, vp, u64, i32, i32, vp]),
     'nrx_debug_cert_sweeps': (i32, [vp, i32]),
     'nrx_debug_clock_probe': (i32, [vp, vp, i32, vp]),
     'nrx_count_errors': (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),

@@ -449,6 +449,281 @@ extern "C" int32_t nrx_ldpc_certify_f64(const void* state, int32_t n_tb, int32_t
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The GENERIC form: ldpc.py:1495-1581 for any base graph, lifting size and row count, with the certificate evaluated after the
+// iterations the caller names; a block that holds it stops there (its hard decisions are the final ones).  One code
+// block per workgroup, lane z = check row z of every layer, ALL state in the caller's workspace (posteriors, stored messages, slack
+// sums, slacks): plain code, no tuning -- the throughput path for the metric configuration is the stage kernel of nrx_ldpc_dec3.hip;
+// this entry makes the certified schedule available (and testable) for every code the library decodes.
+namespace nrx_cert {
+struct GraphTab {
+  int16_t row_start[48];
+  int16_t col[320];
+  int16_t shift[8][320];
+};
+template <int BG> constexpr GraphTab make_graph_tab() {
+  GraphTab t{};
+  using Gt = G<BG>;
+  for (int r = 0; r <= Gt::ROWS; ++r) t.row_start[r] = (int16_t)Gt::row_start(r);
+  for (int e = 0; e < Gt::EDGES; ++e) {
+    t.col[e] = (int16_t)Gt::col(e);
+    for (int i = 0; i < 8; ++i) t.shift[i][e] = (int16_t)Gt::shift(i, e);
+  }
+  return t;
+}
+__constant__ GraphTab kGraph1 = make_graph_tab<1>();
+__constant__ GraphTab kGraph2 = make_graph_tab<2>();
+
+struct GenArgs {
+  int n_cb, Zc, ils, n_rows, N, K, F, kb, core, n_iter, n_checks;
+  int checks[8];
+  double gamma, gamma1;
+  int dmax, max_sweeps, flags;
+  size_t ws_doubles;       // per code block
+};
+
+template <int BG>
+__global__ void __launch_bounds__(ZMAX, 1)
+cert_generic_kernel(const double* __restrict__ llr, GenArgs a, double* __restrict__ ws, uint8_t* __restrict__ hard, uint8_t* __restrict__ exit_iter) {
+  const GraphTab& gt = BG == 1 ? kGraph1 : kGraph2;
+  const int Zc = a.Zc, z = (int)threadIdx.x;
+  const bool on = z < Zc;
+  const int ncol = a.core + a.n_rows - 4;                       // columns the rows that run touch
+  __shared__ double redm[2 * (ZMAX / 64)];
+  __shared__ int flag[4];
+  constexpr int DMAX = 19;
+  for (int cb = blockIdx.x; cb < a.n_cb; cb += gridDim.x) {
+    double* R = ws + (size_t)cb * a.ws_doubles;                 // [ncol][Zc]
+    double* W = R + (size_t)ncol * Zc;                          // [ncol][Zc]
+    double* M1 = W + (size_t)ncol * Zc;                         // [rows][Zc]: 0.75 * min1 of the row's last visit
+    double* M2 = M1 + (size_t)a.n_rows * Zc;                    // 0.75 * min2 (the message to the argmin)
+    double* S1 = M2 + (size_t)a.n_rows * Zc;                    // slack of the pm1-messages
+    double* S2 = S1 + (size_t)a.n_rows * Zc;                    // slack of the pm2-message
+    unsigned long long* WD = (unsigned long long*)(S2 + (size_t)a.n_rows * Zc);   // bits 0..18: sign of the message to edge j, 24..28: argmin
+    const double* in = llr + (size_t)cb * a.N;
+    // ---- load (ldpc.py:1536-1538): two punctured columns of zeros in front, clip to +-1e10; the block's LLR maxima on the way
+    double la = 0.0, lp = 0.0;
+    if (on) {
+      for (int c = 0; c < ncol; ++c) {
+        double v = 0.0;
+        const int p = (c - 2) * Zc + z;
+        if (c >= 2 && p < a.N) {
+          v = in[p];
+          v = v < -1e10 ? -1e10 : (v > 1e10 ? 1e10 : v);
+          v += 0.0;
+          const bool filler = p >= a.K - a.F - 2 * Zc && p < a.K - 2 * Zc;
+          const double av = filler ? 0.0 : __builtin_fabs(v);
+          la = av > la ? av : la;
+          if (c >= a.kb) lp = av > lp ? av : lp;
+        }
+        R[(size_t)c * Zc + z] = v;
+      }
+      for (int L = 0; L < a.n_rows; ++L) {
+        M1[(size_t)L * Zc + z] = 0.0;
+        M2[(size_t)L * Zc + z] = 0.0;
+        WD[(size_t)L * Zc + z] = 0ull;
+      }
+    }
+    for (int k = 1; k < 64; k <<= 1) {
+      la = __builtin_fmax(la, __shfl_xor(la, k, 64));
+      lp = __builtin_fmax(lp, __shfl_xor(lp, k, 64));
+    }
+    if ((z & 63) == 0) { redm[2 * (z >> 6)] = la; redm[2 * (z >> 6) + 1] = lp; }
+    __syncthreads();
+    la = 0.0; lp = 0.0;
+    for (int w = 0; w < (int)blockDim.x / 64; ++w) { la = __builtin_fmax(la, redm[2 * w]); lp = __builtin_fmax(lp, redm[2 * w + 1]); }
+    const double beta = a.gamma * la;
+    const double E = 2.0 * a.n_iter * a.dmax * 0x1p-53 * beta * 1.0625;
+    const double zeta = 4.0 * E, G = 4.0 * E;
+    const double mcap = 0.75 * (1.0e5 - ((a.gamma1 > 1.0 ? a.gamma1 : 1.0) * lp * (1 + 1e-9) + E)) * (1 - 1e-9) - E;
+    const double mcapx = 0.75 * (1.0e5 - (lp * (1 + 1e-9) + E)) * (1 - 1e-9) - E;
+    const bool bounds_ok = beta < 2.5e8 && la < 1e9 && mcap > 0.0 && beta == beta && mcap == mcap;
+    int next_check = 0, certified_at = 0;
+    for (int it = 1; it <= a.n_iter && certified_at == 0; ++it) {
+      // ---- one iteration (ldpc.py:1546-1576)
+      for (int L = 0; L < a.n_rows; ++L) {
+        __syncthreads();
+        if (on) {
+          const int e0 = gt.row_start[L], D = gt.row_start[L + 1] - e0;
+          const unsigned long long wd = WD[(size_t)L * Zc + z];
+          const int oidx = (int)((wd >> 24) & 31ull);
+          const double pm1 = M1[(size_t)L * Zc + z], pm2 = M2[(size_t)L * Zc + z];
+          double t[DMAX];
+          int el[DMAX];
+          int nneg = 0, am = 0;
+          double m1 = 0.0;
+          for (int j = 0; j < D; ++j) {
+            const int c = gt.col[e0 + j];
+            int x = z + gt.shift[a.ils][e0 + j] % Zc;
+            x -= x >= Zc ? Zc : 0;
+            el[j] = c * Zc + x;
+            const double mag = j == oidx ? pm2 : pm1;
+            const double m = ((wd >> j) & 1ull) ? -mag : mag;
+            t[j] = R[el[j]] - m;
+            nneg += t[j] < 0.0 ? 1 : 0;
+            const double aj = __builtin_fabs(t[j]);
+            if (j == 0 || aj < m1) { m1 = aj; am = j; }          // first index of the minimum (np.argmin)
+          }
+          double m2 = __builtin_fabs(t[am] + 100000.0);          // QUIRK ldpc.py:1563
+          for (int j = 0; j < D; ++j)
+            if (j != am) { const double aj = __builtin_fabs(t[j]); m2 = aj < m2 ? aj : m2; }
+          const bool par = (nneg & 1) != 0;
+          unsigned long long nw = (unsigned long long)am << 24;
+          for (int j = 0; j < D; ++j) {
+            const double mag = j == am ? m2 : m1;
+            const bool ng = (t[j] < 0.0) != par;
+            const double nm = (ng ? -mag : mag) * 0.75;            // (mag * sgn) * 0.75, ldpc.py:1570-1573
+            R[el[j]] = t[j] + nm;
+            nw |= (unsigned long long)((__double_as_longlong(nm) >> 63) & 1ll) << j;
+          }
+          M1[(size_t)L * Zc + z] = m1 * 0.75;
+          M2[(size_t)L * Zc + z] = m2 * 0.75;
+          WD[(size_t)L * Zc + z] = nw;
+        }
+      }
+      __syncthreads();
+      if (next_check >= a.n_checks || a.checks[next_check] != it) continue;
+      ++next_check;
+      // ---- the certificate on the frozen state (same conditions and relaxation as ldpc_certify_kernel)
+      if (on) {
+        for (int c = 0; c < ncol; ++c) W[(size_t)c * Zc + z] = 0.0;
+      }
+      __syncthreads();
+      bool dead = !bounds_ok;
+      bool certified = false;
+      for (int sweep = -1; sweep < a.max_sweeps && !certified; ++sweep) {
+        bool raised = false;
+        for (int L = 0; L < a.n_rows; ++L) {
+          if (on) {
+            const int e0 = gt.row_start[L], D = gt.row_start[L + 1] - e0;
+            const bool ext = gt.col[e0 + D - 1] >= a.core;
+            const int DC = ext ? D - 1 : D;
+            const unsigned long long wd = WD[(size_t)L * Zc + z];
+            const int oidx = (int)((wd >> 24) & 31ull);
+            double d1 = 0.0, d2 = 0.0;
+            int el[DMAX];
+            for (int j = 0; j < D; ++j) {
+              const int c = gt.col[e0 + j];
+              int x = z + gt.shift[a.ils][e0 + j] % Zc;
+              x -= x >= Zc ? Zc : 0;
+              el[j] = c * Zc + x;
+            }
+            if (sweep < 0) {
+              S1[(size_t)L * Zc + z] = zeta;
+              S2[(size_t)L * Zc + z] = zeta;
+              d1 = d2 = zeta;
+            } else {
+              const double pm1 = M1[(size_t)L * Zc + z], pm2 = M2[(size_t)L * Zc + z];
+              const double ow1 = S1[(size_t)L * Zc + z], ow2 = S2[(size_t)L * Zc + z];
+              double a1 = 1e300, a2 = 1e300, tlo = 1e300, nu1 = -1e300, nu2 = 0.0;
+              bool any1 = false, has2 = false, bad = false;
+              int parity = 0, nonpos = 0;
+              for (int j = 0; j < D; ++j) {
+                const double r = R[el[j]];
+                const double mag = j == oidx ? pm2 : pm1;
+                const double m = ((wd >> j) & 1ull) ? -mag : mag;
+                const double tj = r - m;
+                const bool sr = __builtin_signbit(r);
+                const bool hg = __builtin_fabs(r) >= 5.0e8;
+                const bool core = j < DC;
+                const double Wj = core ? W[el[j]] : 0.0;
+                const double loss = core ? (Wj - (j == oidx ? ow2 : ow1)) + 2.0 * E : 2.0 * E;
+                const double tl = hg ? 1e300 : (sr ? -tj : tj) - loss;
+                const double nu = sr ? -m : m;
+                parity ^= sr ? 1 : 0;
+                nonpos += tl <= 0.0 ? 1 : 0;
+                bad |= mag > (ext ? mcapx : mcap);
+                if (core && !hg) {
+                  bad |= __builtin_fabs(r) < Wj + G;
+                  if (j == oidx) { nu2 = nu; has2 = true; tlo = tl; }
+                  else { any1 = true; nu1 = nu > nu1 ? nu : nu1; }
+                }
+                if (tl < a1) { a2 = a1; a1 = tl; } else if (tl < a2) a2 = tl;
+              }
+              bad |= parity != 0 || nonpos > 1;
+              if ((a.flags & 1) == 0) dead |= bad;
+              const double need1 = any1 ? nu1 - 0.75 * a1 + E : -1e300;
+              const double need2 = has2 ? nu2 - 0.75 * (tlo == a1 ? a2 : a1) + E : -1e300;
+              if ((a.flags & 2) == 0) {
+                if (need1 > ow1) { const double nwv = (2.0 * need1 + zeta) * (1.0 + 0x1p-20); d1 = nwv - ow1; S1[(size_t)L * Zc + z] = nwv; raised = true; }
+                if (need2 > ow2) { const double nwv = (2.0 * need2 + zeta) * (1.0 + 0x1p-20); d2 = nwv - ow2; S2[(size_t)L * Zc + z] = nwv; raised = true; }
+              }
+            }
+            if (d1 != 0.0 || d2 != 0.0)
+              for (int j = 0; j < DC; ++j) W[el[j]] += j == oidx ? d2 : d1;
+          }
+          __syncthreads();
+        }
+        if (sweep < 0) continue;
+        if (z == 0) { flag[0] = 0; flag[1] = 0; }
+        __syncthreads();
+        if (dead) atomicOr(&flag[0], 1);
+        if (raised) atomicOr(&flag[1], 1);
+        __syncthreads();
+        const bool any_dead = flag[0] != 0, any_raised = flag[1] != 0;
+        __syncthreads();
+        if (any_dead) break;
+        if (!any_raised) certified = true;
+      }
+      if (certified) certified_at = it;
+    }
+    // ---- hard decisions of the information columns (ldpc.py:1578-1581)
+    __syncthreads();
+    if (on) {
+      for (int c = 0; c < a.kb; ++c) hard[(size_t)cb * a.K + c * Zc + z] = R[(size_t)c * Zc + z] < 0.0 ? 1 : 0;
+    }
+    if (z == 0) exit_iter[cb] = (uint8_t)(certified_at < 255 ? certified_at : 255);
+    __syncthreads();
+  }
+}
+}  // namespace nrx_cert
+
+extern "C" int64_t nrx_ldpc_decode_certified_ws_bytes(const nrx_ldpc_cfg* cfg, int32_t n_rows) {
+  if (!cfg || (cfg->bg != 1 && cfg->bg != 2)) return -1;
+  const int total = cfg->bg == 1 ? 46 : 42, core = cfg->bg == 1 ? 26 : 14;
+  const int rows = n_rows <= 0 || n_rows > total ? total : (n_rows < 4 ? 4 : n_rows);
+  return (int64_t)sizeof(double) * ((size_t)2 * (core + rows - 4) + (size_t)5 * rows) * cfg->Zc;
+}
+
+// ldpc.py:1495-1581 decode (hard decisions of the K information bits) with the certified early exit for ANY configuration:
+// llr (n_cb, N) rate-recovered LLRs, checks[0 .. n_checks) ascending iteration counts (host array, <= 8) after which the certificate is
+// evaluated; hard_out (n_cb, K); exit_iter[cb] = the iteration the block was certified at (0: it ran all n_iter).  ws: n_cb *
+// nrx_ldpc_decode_certified_ws_bytes(cfg, n_rows) bytes.
+extern "C" int32_t nrx_ldpc_decode_certified_f64(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
+                                                 const int32_t* checks, int32_t n_checks, uint8_t* hard_out, uint8_t* exit_iter, void* ws,
+                                                 size_t ws_bytes, int32_t max_sweeps, int32_t flags, void* stream) {
+  using namespace nrx_cert;
+  NRX_REQUIRE(llr && cfg && hard_out && exit_iter && ws && (checks || n_checks == 0), NRX_E_ARG, "nrx_ldpc_decode_certified: NULL buffer");
+  NRX_REQUIRE(cfg->bg == 1 || cfg->bg == 2, NRX_E_ARG, "nrx_ldpc_decode_certified: base graph %d", cfg->bg);
+  NRX_REQUIRE(n_cb >= 0 && n_iter >= 0 && n_checks >= 0 && n_checks <= 8 && max_sweeps >= 1, NRX_E_ARG, "nrx_ldpc_decode_certified: bad argument");
+  NRX_REQUIRE(cfg->Zc >= 2 && cfg->Zc <= ZMAX && cfg->iLS >= 0 && cfg->iLS < 8, NRX_E_ARG, "nrx_ldpc_decode_certified: bad lifting size");
+  const int total = cfg->bg == 1 ? 46 : 42;
+  const int rows = n_rows <= 0 || n_rows > total ? total : (n_rows < 4 ? 4 : n_rows);
+  const int64_t per = nrx_ldpc_decode_certified_ws_bytes(cfg, rows);
+  NRX_REQUIRE(per > 0 && ws_bytes >= (size_t)per * (size_t)n_cb, NRX_E_ARG, "nrx_ldpc_decode_certified: workspace of %zu bytes, %lld needed", ws_bytes,
+              (long long)per * n_cb);
+  if (n_cb == 0) return NRX_OK;
+  double b3[3];
+  const int32_t rb = nrx_ldpc_cert_bounds(cfg, rows, b3);
+  if (rb) return rb;
+  GenArgs a{};
+  a.n_cb = n_cb; a.Zc = cfg->Zc; a.ils = cfg->iLS; a.n_rows = rows; a.N = cfg->N; a.K = cfg->K; a.F = cfg->F;
+  a.kb = cfg->bg == 1 ? 22 : 10; a.core = cfg->bg == 1 ? 26 : 14; a.n_iter = n_iter; a.n_checks = n_checks;
+  for (int i = 0; i < n_checks; ++i) {
+    NRX_REQUIRE(checks[i] >= 1 && (i == 0 || checks[i] > checks[i - 1]), NRX_E_ARG, "nrx_ldpc_decode_certified: checks must ascend from 1");
+    a.checks[i] = checks[i];
+  }
+  a.gamma = b3[0]; a.gamma1 = b3[1]; a.dmax = (int)b3[2]; a.max_sweeps = max_sweeps; a.flags = flags;
+  a.ws_doubles = (size_t)per / sizeof(double);
+  const int threads = ((cfg->Zc + 63) / 64) * 64;
+  const int grid = n_cb < 4096 ? n_cb : 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (cfg->bg == 1) hipLaunchKernelGGL(cert_generic_kernel<1>, dim3(grid), dim3(threads), 0, st, llr, a, (double*)ws, hard_out, exit_iter);
+  else hipLaunchKernelGGL(cert_generic_kernel<2>, dim3(grid), dim3(threads), 0, st, llr, a, (double*)ws, hard_out, exit_iter);
+  NRX_CHECK_LAUNCH("nrx_ldpc_decode_certified_f64");
+  return NRX_OK;
+}
+
 // developer hook: histogram of the sweep a block was certified in ([15] = refused); reset != 0 clears it
 extern "C" int32_t nrx_debug_cert_sweeps(unsigned long long* out16, int32_t reset) {
   if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(nrx_cert::g_cert_hist), sizeof(unsigned long long) * 16) != hipSuccess) return NRX_E_HIP;

@@ -195,14 +195,25 @@ class LdpcDecoder(LdpcBase):
             harq.decBuffer = circ
         return N(out)
 
-    def decode(self, rxCodeBlock, numIter=5, onlyInfoBits=True, outputBelief=False):
+    def decode(self, rxCodeBlock, numIter=5, onlyInfoBits=True, outputBelief=False, certifiedExit=None):
         """Layered normalised min-sum (ldpc.py:1495-1581).  float64 input -> the bit-exact float64 kernel;
-        float32 input -> the single-precision throughput kernel."""
+        float32 input -> the single-precision throughput kernel.
+
+        ``certifiedExit`` (not in the reference, which always runs ``numIter`` iterations; float64 hard decisions of the information
+        bits only): ascending iteration counts after which a code block may stop -- only where the stability certificate proves
+        that its hard decisions are already those of the full run, so the returned bits are the reference's.
+        ``self.lastExitIter`` then holds the iteration every block stopped at (0 = it ran all ``numIter``)."""
         rx = np.asarray(rxCodeBlock)
         if rx.dtype != np.float32:
             rx = np.float64(rx)
         if self._cfg is None or rx.shape[1] != self._cfg.N:
             raise ValueError("decode: call recoverRate first (or the block length does not match the configuration)")
+        if certifiedExit is not None:
+            if outputBelief or not onlyInfoBits or rx.dtype != np.float64:
+                raise ValueError("certifiedExit gives float64 hard decisions of the information bits (onlyInfoBits=True, outputBelief=False)")
+            hard, ex = ops.ldpc_decode_certified(D(rx), self._cfg, numIter, [int(v) for v in np.atleast_1d(certifiedExit)])
+            self.lastExitIter = N(ex)
+            return N(hard).astype(np.int8)
         out = N(ops.ldpc_decode(D(rx), self._cfg, numIter, only_info=onlyInfoBits, belief=outputBelief))
         return out if outputBelief else out.astype(np.int8)
 

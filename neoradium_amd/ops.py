@@ -330,6 +330,26 @@ def ldpc_cert_bounds(cfg, rows):
     return float(out[0]), float(out[1]), int(out[2])
 
 
+def ldpc_decode_certified(llr, cfg, n_iter, checks, rows=None, max_sweeps=8, flags=0):
+    """ldpc.py:1495-1581 decode with the certified early exit for ANY configuration (nrx_ldpc_decode_certified_f64): (n_cb, N) float64
+    rate-recovered LLRs -> (hard (n_cb, K) uint8, exit_iter (n_cb,) uint8: the iteration a block was certified at, 0 = it ran all
+    ``n_iter``).  ``checks``: ascending iteration counts (<= 8) after which the certificate is evaluated."""
+    if llr.dtype != torch.float64 or llr.dim() != 2 or llr.shape[1] != cfg.N:
+        raise ValueError(f"LLRs must be a float64 (n_cb, N={cfg.N}) tensor")
+    llr = llr.contiguous()
+    n_cb = llr.shape[0]
+    dev = _dev(llr)
+    r = int(rows or 0)
+    per = int(lib().nrx_ldpc_decode_certified_ws_bytes(C.byref(cfg), r))
+    ws = torch.empty(max(n_cb * per, 8), dtype=torch.uint8, device=dev)
+    hard = torch.empty((n_cb, cfg.K), dtype=torch.uint8, device=dev)
+    ex = torch.zeros(n_cb, dtype=torch.uint8, device=dev)
+    ck = (C.c_int32 * max(len(checks), 1))(*[int(c) for c in checks])
+    check(lib().nrx_ldpc_decode_certified_f64(ptr(llr), n_cb, C.byref(cfg), int(n_iter), r, ck, len(checks), ptr(hard), ptr(ex), ptr(ws),
+                                              ws.numel(), int(max_sweeps), int(flags), stream()))
+    return hard, ex
+
+
 _cert_bufs = {}
 _cert_scratch = {}
 

@@ -143,3 +143,75 @@ def test_gpu_certificate_against_the_oracle_on_a_slot(dev):
     assert np.array_equal(got, res['bits'][:, :pay]), "decoded payload differs from the oracle's 50-iteration run"
     agree = (gpu8 == res['cert'][8]).mean()
     assert agree >= 0.9, (int(gpu8.sum()), int(res['cert'][8].sum()))
+
+
+# (bg, A, G, nl, qm, sigma): both base graphs, lifting sizes 22 ... 384, with and without fillers, truncated and full row sets
+GENERIC_CASES = [
+    (1, 10000, 22808, 1, 2, 0.80),      # C=2, Zc=240, F=244
+    (2, 2408, 7800, 1, 2, 1.05),        # C=1, Zc=256 (BASELINE cfg1's graph)
+    (1, 30216, 63648, 2, 4, 0.78),      # C=4, Zc=352
+    (2, 3817, 12000, 1, 6, 1.00),       # BG2, two blocks
+    (1, 800, 2400, 2, 4, 0.95),         # Zc=40
+    (2, 100, 600, 1, 2, 1.20),          # Zc=22 (less than a wavefront)
+    (1, 25344 * 2, 3 * 13104 * 2, 4, 6, 0.62),   # Zc=384, C=7
+]
+
+
+@pytest.mark.parametrize("bg,A,G,nl,qm,sigma", GENERIC_CASES)
+def test_generic_certified_decoder_any_code(dev, bg, A, G, nl, qm, sigma):
+    """nrx_ldpc_decode_certified_f64 (any base graph / lifting size / row count): hard decisions identical to the fixed schedule of
+    nrx_ldpc_decode_rows_f64 for every block, certified or not; the certified blocks' exit iterations are those of the oracle's
+    certificate for most blocks, and every block the kernel certifies carries, at its exit, the oracle's final bits."""
+    import torch
+    from neoradium_amd import ops, _lib
+    rng = np.random.default_rng(A + qm)
+    n_tb = 4
+    cfg = _lib.ldpc_config(bg, A + 24)
+    tb = torch.from_numpy(rng.integers(0, 2, (n_tb, A)).astype(np.uint8)).to(dev)
+    coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+    bits = ops.ldpc_rate_match(coded, cfg, G, nl, qm).cpu().numpy().astype(np.float64)
+    sig = (sigma * np.array([0.8, 0.95, 1.0, 1.25]))[:, None]
+    llr = (2 / sig ** 2) * ((1 - 2 * bits) + sig * rng.standard_normal(bits.shape))
+    llr[rng.random(llr.shape) < 0.002] = 0.0
+    rr = ops.ldpc_rate_recover(torch.from_numpy(llr).to(dev), cfg, nl, qm)
+    lens = _lib.ldpc_cb_lens(G, cfg.C, nl, qm)
+    total = 46 if bg == 1 else 42
+    rows = min(total, ops.ldpc_active_rows(cfg, max(lens)))
+    n_iter, checks = 24, [4, 7, 10, 14, 18]
+    ref = ops.ldpc_decode(rr, cfg, n_iter, rows=rows)
+    hard, ex = ops.ldpc_decode_certified(rr, cfg, n_iter, checks, rows=rows)
+    assert torch.equal(hard, ref), f"{int((hard != ref).any(1).sum())} blocks differ from the fixed schedule"
+    exn = ex.cpu().numpy()
+    assert (exn > 0).any() and set(np.unique(exn)) <= set([0] + checks)
+    # against the oracle's certificate on the same LLRs
+    p = oc.LdpcParams(bg, A + 24)
+    fcols = cert.filler_columns(bg, p.Zc, p.F)
+    res = cert.decode_certified(rr.cpu().numpy(), bg, p.iLS, p.Zc, n_iter, rows, checks, fcols, sweeps=12)
+    assert np.array_equal(hard.cpu().numpy(), res['bits'][:, :cfg.K])
+    first = np.zeros(len(exn), dtype=int)
+    for k in reversed(checks):
+        first[res['cert'][k]] = k
+    assert (first == exn).mean() >= 0.75, (first, exn)
+    for b in np.nonzero(exn)[0]:
+        assert np.array_equal(res['bits_at'][int(exn[b])][b], res['bits'][b])
+    # and a broken certificate (no conditions) stops blocks that have not converged: caught by the comparison above
+    hard_b, ex_b = ops.ldpc_decode_certified(rr, cfg, n_iter, [1], rows=rows, flags=3)
+    assert (ex_b == 1).all() and not torch.equal(hard_b, ref)
+
+
+def test_class_surface_decode_with_certified_exit(dev):
+    """LdpcDecoder.decode(..., certifiedExit=...): the reference's call with one opt-in keyword -- same bits as without it."""
+    import neoradium_amd as nr
+    rng = np.random.default_rng(12)
+    enc = nr.LdpcEncoder(baseGraphNo=2, modulation='QPSK', txLayers=1, targetRate=0.4)
+    tb = rng.integers(0, 2, 3000).astype(np.int8)
+    G = 9000
+    tx = enc.getRateMatchedCodeBlocks(tb, G)
+    llr = 4.0 * ((1 - 2.0 * np.asarray(tx)) + 0.8 * rng.standard_normal(len(tx)))
+    dec = enc.getDecoder()
+    rr = dec.recoverRate(llr, len(tb))
+    ref = dec.decode(rr, numIter=20)
+    got = dec.decode(rr, numIter=20, certifiedExit=(5, 9, 14))
+    assert np.array_equal(ref, got) and dec.lastExitIter.shape == (rr.shape[0],) and (dec.lastExitIter > 0).any()
+    with pytest.raises(ValueError):
+        dec.decode(rr, numIter=20, certifiedExit=(5,), outputBelief=True)
