@@ -61,6 +61,8 @@ def main():
         link, snrs = build(nr, which, 'f32')
         link64, _ = build(nr, which, 'f64')
         linkw, _ = build(nr, which, 'f32', waveform='f32')       # float32 decoder AND complex64 waveform chain (opt-in fast mode)
+        # round 4: the float64 chain with the CERTIFIED early exit (metric configuration: the fused entry's instantiations)
+        linkc = build(nr, which, 'f64', certifiedExit=(8, 16))[0] if which == 'metric' else None
         if a.snrs:
             snrs = [float(v) for v in a.snrs.split(',')]
         st = olink.static_from_link(link, slots=range(0, 20 * len(snrs) + a.slots))
@@ -83,6 +85,15 @@ def main():
             fused_ok = torch.cat([x['cb_ok'] for _, x in dv]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
             _, dw = linkw.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
             wave_ok = torch.cat([x['cb_ok'] for _, x in dw]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
+            cert = {}
+            if linkc is not None:
+                _, dc = linkc.run(slots0, n, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
+                cert_ok = torch.cat([x['cb_ok'] for _, x in dc]).cpu().numpy().astype(bool).reshape(gpu64_ok.shape)
+                same_bits = all(torch.equal(x['tb_out'], y['tb_out']) for (_, x), (_, y) in zip(dc, dv))
+                cert = dict(gpu_f64_certified_block_errors=int((~cert_ok).sum()),
+                            certified_crc_vectors_differ_from_f64_throughput_path_in=int((cert_ok != fused_ok).sum()),
+                            certified_bits_identical_to_f64_throughput_path=bool(same_bits),
+                            blocks_stopped_early=int((linkc.last_exit_iter > 0).sum()))
             F = d['F'].cpu().numpy()
             t0 = time.time()
             jobs = [(st, slots0 + i, snr, tb[i].astype(np.int8), zc[i], F[i]) for i in range(n)]
@@ -98,7 +109,7 @@ def main():
                              f32_waveform_crc_vectors_differ_in=int((cpu_ok != wave_ok).sum()),
                              f32_crc_vectors_differ_in=int((cpu_ok != gpu_ok).sum()),
                              f64_crc_vectors_differ_in=int((cpu_ok != gpu64_ok).sum()),
-                             f64_throughput_path_differs_from_f64_in=int((fused_ok != gpu64_ok).sum())))
+                             f64_throughput_path_differs_from_f64_in=int((fused_ok != gpu64_ok).sum()), **cert))
             print(which, rows[-1], flush=True)
         res[which] = dict(tbs=link.tbs, code_blocks=link.cfg.C, slots_per_point=a.slots, points=rows,
                           cpu_oracle_s_per_slot=t_cpu / (len(snrs) * a.slots))
