@@ -251,7 +251,7 @@ def library_identity(stub=False):
 
 def side_configs(nr, ops, sync):
     """The other BASELINE.json configurations in the driver-timed record (N = 1 only, a few seconds in all): cfg2 and cfg3 slots/s over
-    3 steps each, cfg5 (HARQ-IR at the metric configuration) transmissions/s over 4 rounds; same protocol (warm-up, then timed steps
+    3 steps each, cfg4 (polar SCL blind-decode candidates/s), cfg5 (HARQ-IR at the metric configuration) transmissions/s over 4 rounds; same protocol (warm-up, then timed steps
     between synchronisations, inputs generated on the device)."""
     import torch
     out = {}
@@ -289,6 +289,33 @@ def side_configs(nr, ops, sync):
     out["cfg3"] = dict(steps(l3, 48, 58.0), workload="273 PRB @30 kHz, 256-QAM, 4 layers, 4x4 MMSE, CDL-D 300 ns, BG1 R=0.75 (113 CB), perfect CSI "
                                                       "(frequency-domain channel), 50 iterations, batch 48 slots, float64")
     del l3
+    # cfg4: polar-coded control path -- batched DCI blind-decode candidates (A = 64 payload bits, E = 864 = aggregation level 8, CRC-aided
+    # SCL list 8): rate recovery + decode, 3 launches of 32 768 candidates
+    try:
+        from neoradium_amd.polar import PolarEncoder, PolarDecoder
+        from neoradium_amd._dev import device as _device
+        dev = _device()
+        A, E, n = 64, 864, 32768
+        enc, dec = PolarEncoder(A, E, 'dci'), PolarDecoder(A, E, 'dci', sclListSize=8)
+        g = torch.Generator(device=dev).manual_seed(7)
+        tb = torch.randint(0, 2, (n, A), dtype=torch.uint8, device=dev, generator=g)
+        cbs = torch.cat([tb, ops.crc(tb, '24C')], 1).contiguous()
+        rm = enc.rateMatchDevice(enc.encodeDevice(cbs))
+        sig = 10 ** (4.0 / 20)
+        llr = 2 * (1 - 2 * rm.double() + sig * torch.randn(rm.shape, dtype=torch.float64, device=dev, generator=g)) / sig ** 2
+        msg, ok = dec.decodeDevice(dec.recoverRateDevice(llr))
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            msg, ok = dec.decodeDevice(dec.recoverRateDevice(llr))
+        sync()
+        dt = time.perf_counter() - t0
+        good = (msg[:, :A] == tb).all(1)
+        out["cfg4"] = {"value": 3 * n / dt, "unit": "candidates/s", "launches": 3, "candidates_per_launch": n, "ms_per_launch": 1e3 * dt / 3,
+                       "bler": float(1 - good.double().mean()),
+                       "workload": "polar control path: DCI blind-decode candidates, A=64, E=864 (AL 8), CRC-aided SCL list 8, -4 dB, float64"}
+    except Exception as e:
+        out["cfg4"] = {"error": repr(e)}
     l5 = build_link(nr, decoder="f64")
     _, st = l5.run_harq(64, 1, 27.0, seed=1)
     sync()
