@@ -5,7 +5,8 @@
 
 --json writes, for every matching kernel, the register metadata and the loop's instruction counts by issue class (VALU / SALU /
 LDS / waits) together with the SHA-256 of the inspected file: bench.py prices the decoder's VALU-issue bound from
-profiles/r3_decoder_isa.json and checks that hash against the library it actually loaded.
+neoradium_amd/libnrx.isa.json (written by the build next to the library; a copy per round under profiles/) and checks that hash
+against the library it actually loaded.
 
 Prints register / scratch metadata, the opcode histogram of the innermost long backward-branch loop, and the number of
 back-to-back VOP2 v_cndmask_b32 pairs in it (each costs the issuing wave ~19 cycles on gfx950)."""
