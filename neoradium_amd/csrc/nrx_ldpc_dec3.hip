@@ -800,9 +800,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       }
       if constexpr ((MODE & 1) != 0) {
         __syncthreads();
-        // MODE bit 2: EVERY block parks its state; then, where asked for (cert_w != NULL), the stability certificate is evaluated on the
-        // spot -- posterior columns still in LDS, the check-node state read back from what this lane just parked -- and a block
-        // that holds it gets its exit iteration: the caller's work list of the next stage leaves it out.
+        // MODE bit 2: every block parks (whatever its CRC says); where asked for (cert_w != NULL) the stability certificate is evaluated
+        // on the spot in between -- posterior columns still in LDS, the check-node state read back from what this lane just parked --
+        // and a block that holds it gets its exit iteration (the caller's work list of the next stage leaves it out) and keeps its
+        // columns to itself.
         // (the check-node state first: it is all the certificate reads back; the posterior columns follow behind the certificate, and
         //  only for the blocks that have to go on)
         const bool parks = live && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u);
