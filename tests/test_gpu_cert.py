@@ -215,3 +215,30 @@ def test_class_surface_decode_with_certified_exit(dev):
     assert np.array_equal(ref, got) and dec.lastExitIter.shape == (rr.shape[0],) and (dec.lastExitIter > 0).any()
     with pytest.raises(ValueError):
         dec.decode(rr, numIter=20, certifiedExit=(5,), outputBelief=True)
+
+
+def test_certified_exit_at_baseline_cfg2(dev):
+    """BASELINE configs[1] (106 PRB @30 kHz, 64-QAM, 2 layers, 2x2 MMSE, CDL-C, BG1: 16 code blocks of Zc 384 per slot) through the engine:
+    the certified schedule's bits and verdicts equal the fixed schedule's across its waterfall."""
+    import torch
+    import neoradium_amd as nr
+
+    def link(**kw):
+        nr.random.setSeed(123)
+        car = nr.Carrier(numRbs=106, spacing=30)
+        p = nr.PDSCH(car.curBwp, numLayers=2, nID=car.cellId, modulation='64QAM')
+        p.setDMRS(configType=1, additionalPos=1)
+        ch = nr.CdlChannel(car.curBwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                           txAntenna=nr.AntennaPanel([1, 1], polarization="x"), rxAntenna=nr.AntennaPanel([1, 1], polarization="x"))
+        return nr.PdschLink(p, ch, 666 / 1024, baseGraphNo=1, numIter=50, freqDomain=False, chanEst="LS", decoder="f64", **kw)
+
+    fixed, certd = link(), link(certifiedExit=(8, 16))
+    pay = fixed.cfg.cb_len - 24
+    stopped = total = 0
+    for snr in (16.0, 18.0, 20.0, 23.0):
+        _, d0 = fixed.run(40, 192, snr, seed=6, details="verdicts")
+        _, d1 = certd.run(40, 192, snr, seed=6, details="verdicts")
+        assert torch.equal(d0[0][1]['cb_ok'], d1[0][1]['cb_ok']) and torch.equal(d0[0][1]['tb_out'], d1[0][1]['tb_out']), snr
+        stopped += int((certd.last_exit_iter > 0).sum())
+        total += certd.last_exit_iter.numel()
+    assert stopped > 0.3 * total, (stopped, total)
