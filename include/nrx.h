@@ -524,6 +524,20 @@ int32_t nrx_apply_td_paths_pow_f32(const void* x, int32_t n_items, int32_t n_tx,
                                    const int32_t* tap_off, int32_t flen, int32_t hist, const int32_t* set_lens,
                                    void* y, int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part,
                                    void* stream);
+/* channelmodel.py:403-448 applyToSignal by OVERLAP-SAVE (nrx_chan_os.hip): the same operator as nrx_apply_td_paths_f64 -- y[r][n] =
+ * sum_t sum_p gains1[set(n)][r][t][p] * (taps_p * x_t)[n - off_p] -- as 1024-point circular convolutions per gain set, the Nr x Nt
+ * spectra of a set held in registers (nothing but x and y touches HBM).
+ * nrx_td_path_spectra_f64: spec (n_paths,1024) complex128 = the 1024-point spectrum of every row of the coefficient matrix
+ * (channelmodel.py:292-318: taps (n_paths,flen) at column tap_off[p]) in the transform's own position order, scaled by 1/1024 --
+ * a constant of the channel, computed once per link.
+ * nrx_apply_td_os_f64: x (n_items,n_tx,ns), gains1 (n_items,n_sets,n_rx,n_tx,n_paths), hist >= max(tap_off)+flen-1 -> y
+ * (n_items,n_rx,ns); pow_acc != NULL also leaves the power sums of nrx_apply_td_paths_pow_f64 (one triple per wave: *n_part per
+ * item).  Same values as the path form up to rounding (|diff| ~ 1e-15 of the largest sample).  NRX_E_UNSUPPORTED unless
+ * n_rx == n_tx in {1,2,4} and hist <= 640: call nrx_apply_td_paths_* then. */
+int32_t nrx_td_path_spectra_f64(const double* taps, const int32_t* tap_off, int32_t n_paths, int32_t flen, void* spec, void* stream);
+int32_t nrx_apply_td_os_f64(const void* x, int32_t n_items, int32_t n_tx, int64_t ns, const void* gains1, int32_t n_sets,
+                            int32_t n_rx, int32_t n_paths, const void* spec, int32_t hist, const int32_t* set_lens, void* y,
+                            int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part, void* stream);
 int32_t nrx_noise_level_finish_f64(const double* acc, int32_t n_part, int64_t count, int32_t n_batch, void* var_out,
                                    const double* snr_lin, int32_t snr_stride, double mult, void* sigma_out, void* nv_out,
                                    double nv_mult, void* stream);

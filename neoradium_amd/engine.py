@@ -237,6 +237,11 @@ class PdschLink:
         taps, offs = ops.path_taps(coeff, channel.filterLen)
         self.taps, self.tap_off = D(taps), D(offs)
         self.td_hist = int(np.max(offs)) + int(np.asarray(taps).shape[1]) - 1
+        # overlap-save form of the channel filter (nrx_apply_td_os_f64): the path spectra are a constant of the channel.
+        # NRX_TD_PATHS=1 keeps the path-form kernel (what the reference literally does, channelmodel.py:431-447).
+        self.td_spec = None
+        if not freqDomain and waveform == "f64" and not bool(int(os.environ.get('NRX_TD_PATHS', '0'))):
+            self.td_spec = ops.td_path_spectra(self.taps, self.tap_off)
         self.max_delay = tb_['max_delay']
         self.fs = bwp.sampleRate
         self.window = windowing
@@ -457,8 +462,13 @@ class PdschLink:
             lens = [int(v) for v in self.sym_lens[sis]]
             mult = self.nfft / (12.0 * self.bwp.numRbs)
             # the filter leaves the power sums of its output (getRePower) where its kernel supports that ...
-            got = None if self._sep_power else ops.apply_td_paths(tx, gains1 if gfold is None else gfold, self.taps, self.tap_off, lens,
-                                                                  hist=self.td_hist, power=(self.nfft, snr_lin, mult, float(self.nfft)))
+            gmix = gains1 if gfold is None else gfold
+            got = None
+            if self.td_spec is not None and not self._sep_power:       # overlap-save; None where it has no instantiation
+                got = ops.apply_td_os(tx, gmix, self.td_spec, self.td_hist, lens, power=(self.nfft, snr_lin, mult, float(self.nfft)))
+            if got is None and not self._sep_power:
+                got = ops.apply_td_paths(tx, gmix, self.taps, self.tap_off, lens, hist=self.td_hist,
+                                         power=(self.nfft, snr_lin, mult, float(self.nfft)))
             if got is not None:
                 ry, sigma, nv = got
             else:           # ... else a second pass over the waveform

@@ -1254,6 +1254,59 @@ def apply_td_paths(x, gains1, taps, tap_off, set_lens, hist=None, power=None):
     return y
 
 
+def td_path_spectra(taps, tap_off):
+    """nrx_td_path_spectra_f64: (P, flen) taps at columns tap_off -> (P, 1024) complex128 path spectra for apply_td_os (a constant
+    of the channel; computed once per link)."""
+    if not (isinstance(taps, torch.Tensor) and taps.is_cuda):
+        raise ValueError("td_path_spectra: taps must be a GPU tensor")
+    dev = _dev(taps)
+    taps = taps.to(torch.float64).contiguous()
+    P, flen = taps.shape
+    tap_off = _i32(tap_off, dev)
+    spec = torch.empty((P, 1024), dtype=torch.complex128, device=dev)
+    check(lib().nrx_td_path_spectra_f64(ptr(taps), ptr(tap_off), P, flen, ptr(spec), stream()))
+    return spec
+
+
+def apply_td_os(x, gains1, spec, hist, set_lens, power=None):
+    """ChannelModel.applyToSignal by overlap-save (nrx_apply_td_os_f64): x (n,Nt,ns) complex128, gains1 (n,nc+1,Nr,Nt,P), spec from
+    td_path_spectra, hist = max(tap_off) + flen - 1 -> y (n,Nr,ns), or (y, sigma, nv) with power = (nfft, snr_lin, mult, nv_mult)
+    like apply_td_paths.  None when the geometry has no instantiation (Nr != Nt, more than 4 antennas, paths longer than 640
+    samples): the caller takes the path form."""
+    if x.dtype != torch.complex128:
+        return None
+    x = x.contiguous()
+    gains1 = gains1.to(torch.complex128).contiguous()
+    n, nt, ns = x.shape
+    if gains1.shape[0] != n or gains1.shape[3] != nt or gains1.shape[1] != len(set_lens):
+        raise ValueError("The number of transmit antennas in the signal does not match the channel.")
+    nr, P = gains1.shape[2], gains1.shape[4]
+    if spec.shape[0] != P:
+        raise ValueError("path spectra / path count mismatch")
+    dev = _dev(x)
+    y = torch.empty((n, nr, ns), dtype=torch.complex128, device=dev)
+    acc, cap, nfft = None, 0, 0
+    if power is not None:
+        nfft = int(power[0])
+        cap = 3 * n * len(set_lens) * 2 * nr
+        acc = torch.empty(max(cap, 1), dtype=torch.float64, device=dev)
+    n_part = C.c_int32(0)
+    rc = lib().nrx_apply_td_os_f64(ptr(x), n, nt, ns, ptr(gains1), len(set_lens), nr, P, ptr(spec), int(hist), _host_i32(set_lens), ptr(y),
+                                   nfft, ptr(acc), cap, C.byref(n_part), stream())
+    if rc == -3:                 # NRX_E_UNSUPPORTED
+        return None
+    check(rc)
+    if power is None:
+        return y
+    _, snr_lin, mult, nv_mult = power
+    snr = torch.as_tensor(snr_lin, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+    sigma = torch.empty(n, dtype=torch.float64, device=dev)
+    nv = torch.empty(n, dtype=torch.float64, device=dev)
+    check(lib().nrx_noise_level_finish_f64(ptr(acc), n_part.value, nr * (len(set_lens) - 1) * nfft, n, None, ptr(snr),
+                                           0 if snr.numel() == 1 else 1, float(mult), ptr(sigma), ptr(nv), float(nv_mult), stream()))
+    return y, sigma, nv
+
+
 def _apply_td_paths_f32(x, gains1, taps, tap_off, set_lens, hist, power):
     """apply_td_paths on a complex64 waveform with packed float32 arithmetic (nrx_apply_td_paths_pow_f32); sigma / nv stay
     float64.  NotImplemented when the geometry has no float32 instantiation."""

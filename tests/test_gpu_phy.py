@@ -296,6 +296,52 @@ def test_tdl_chain(dev):
     assert rel(gs.cpu().numpy(), np.einsum('bcrtp,tl->bcrlp', ref_g, F[0])) < 1e-13
 
 
+@pytest.mark.parametrize("nx,max_delay_ns,nfft,mu", [(4, 900, 1024, 1), (4, 19000, 1024, 1), (2, 5000, 512, 2), (1, 300, 256, 3), (4, 2600, 4096, 1)])
+def test_overlap_save_filter_equals_the_path_form(dev, nx, max_delay_ns, nfft, mu):
+    """nrx_apply_td_os_f64 (1024-point overlap-save, the Nr x Nt spectra of a gain set in registers) against the oracle's
+    channelmodel.py:403-448 restatement and against the path-form kernel: waveform and noise level.  Cases: short and long paths
+    (hist 43 ... 600: one to many blocks per gain set, a tail set shorter than a block), symbols shorter than a block, Nr = Nt in
+    {1, 2, 4}, non-zero input right up to the end of the buffer."""
+    from neoradium_amd import ops
+    rng = np.random.default_rng(nx * 1000 + nfft)
+    n, N = 3, 7
+    fs = 30.72e6 * nfft / 1024
+    cps = np.append(op.cp_lens_slot(mu, 0, nfft), op.cp_lens_slot(mu, 1, nfft)[0])
+    slot_len = int((cps[:-1] + nfft).sum())
+    g = crandn(rng, n, 15, nx, nx, N + 1)
+    delays = np.sort(rng.uniform(0, max_delay_ns, N + 1))
+    delays[0] = 0
+    coeff, _ = op.coeff_matrix(delays, fs, op.build_firs())
+    taps, offs = ops.path_taps(coeff)
+    hist = int(offs.max()) + taps.shape[1] - 1
+    ns = slot_len + coeff.shape[1] + 5
+    x = crandn(rng, n, nx, ns)
+    lens = list(cps + nfft)
+    spec = ops.td_path_spectra(T(taps, dev), offs)
+    # the path spectra: FFT_1024 of every row of the coefficient matrix / 1024, in decimation-in-frequency position order
+    c = np.zeros((N + 1, 1024))
+    c[:, :coeff.shape[1]] = coeff
+    pos = np.array([int(format(k, '010b')[::-1], 2) for k in range(1024)])
+    assert rel(spec.cpu().numpy()[:, pos], np.fft.fft(c, axis=1) / 1024) < 1e-13
+    snr = np.array([3.0, 40.0, 17.0])
+    y_os, sg, nv = ops.apply_td_os(T(x, dev), T(g, dev), spec, hist, lens, power=(nfft, snr, nfft / (12.0 * 25), float(nfft)))
+    y_pf = ops.apply_td_paths(T(x, dev), T(g, dev), T(taps, dev), offs, lens).cpu().numpy()
+    y_os = y_os.cpu().numpy()
+    for b in range(n):
+        ref_y = op.apply_td(x[b], g[b], coeff, cps + nfft)
+        assert rel(y_os[b], ref_y) < 1e-12 and rel(y_pf[b], ref_y) < 1e-12
+    assert np.abs(y_os - y_pf).max() < 1e-12 * np.abs(y_pf).max()       # sample by sample, tail beyond the slot included
+    assert np.array_equal(ops.apply_td_os(T(x, dev), T(g, dev), spec, hist, lens).cpu().numpy(), y_os)
+    starts = np.concatenate([[0], np.cumsum((cps + nfft)[:-1])])
+    o = np.int64(np.round(cps[:-1] * 0.5))
+    idx = (starts[:-1, None] + o[:, None] + np.arange(nfft)[None]).reshape(-1)
+    var_ref = np.array([np.var(y_pf[b][:, idx]) for b in range(n)])
+    sg_ref = np.sqrt(var_ref * nfft / (12.0 * 25) / snr)
+    assert rel(sg.cpu().numpy(), sg_ref) < 1e-12 and rel(nv.cpu().numpy(), sg_ref ** 2 * nfft) < 1e-12
+    # no instantiation: Nr != Nt -> None (the caller takes the path form)
+    assert nx == 1 or ops.apply_td_os(T(x, dev), T(g[:, :, :1], dev), spec, hist, lens) is None
+
+
 @pytest.mark.parametrize("P,l_cdm,ds,ctype", [(1, 1, [2], 1), (2, 1, [2, 11], 1), (4, 1, [2, 7, 11], 1), (4, 2, [2, 3, 10, 11], 1),
                                              (3, 1, [3, 9], 2)])
 def test_chest_ls(dev, P, l_cdm, ds, ctype):
