@@ -540,7 +540,7 @@ def main():
             del tp
         if not args.stub and world == 1 and not args.no_cert and f64:
             # OPT-IN schedule with a PROOF, reported beside `value`, never instead of it: at 8 and 16 iterations a block stops only if
-            # its CRC passes AND the stability certificate holds on its frozen decoder state (nrx_ldpc_certify_f64, DESIGN 4.1j): every
+            # its CRC passes AND the stability certificate holds on its frozen decoder state (nrx_ldpc_certify_f64, DESIGN 4.3): every
             # later iteration of the same float64 recursion then provably leaves its hard decisions unchanged, i.e. its bits ARE the
             # reference schedule's.  Checked here on one batch per SNR point block by block against the fixed schedule's bits.
             ce = build_link(nr, decoder='f64', certifiedExit=(8, 16))
@@ -568,7 +568,7 @@ def main():
                             "mismatches": int(diff.sum()), "verdict_mismatches": int((d0[0][1]['cb_ok'] != d1[0][1]['cb_ok']).sum())})
             main_pt = next(q for q in pts if q["snr_db"] == float(args.snr))
             out["certified_early_exit"] = dict(main_pt, checks_at=list(ce.certStages), num_iter=link.numIter, exact_by_construction=True,
-                                               certificate="nrx_ldpc_certify_f64 on the parked decoder state (DESIGN 4.1j; tests/test_gpu_cert.py, "
+                                               certificate="nrx_ldpc_certify_f64 on the parked decoder state (DESIGN 4.3; tests/test_gpu_cert.py, "
                                                            "tests/test_certificate_cpu.py)",
                                                note="opt-in (off by default; the reference has no early stop, ldpc.py:1545): `value` above stays the fixed schedule",
                                                points=pts)

@@ -187,7 +187,7 @@ int32_t nrx_ldpc_resume_decode_merge_sel_f64(int32_t n_tb, int32_t llr_len, cons
 /* ---- Certified early exit (opt-in schedule; never the headline measurement).  The reference runs a fixed number of iterations
  * (ldpc.py:1545-1576) and has no early stop.  These entries stop a code block early ONLY where a certificate evaluated on its
  * frozen decoder state proves that every later iteration of that same float64 recursion leaves every hard decision unchanged
- * (DESIGN.md 4.1j: statement and proof; oracle/certificate.py: the CPU restatement) -- the bits of a certified block ARE the
+ * (DESIGN.md 4.3: statement and proof; oracle/certificate.py: the CPU restatement) -- the bits of a certified block ARE the
  * bits ldpc.py:1578-1581 returns after numIter iterations.
  *
  * nrx_ldpc_cert_bounds (host only): a-priori magnitude bounds of ldpc.py:1546-1576 on the first n_rows rows, per unit of the
@@ -199,7 +199,10 @@ int32_t nrx_ldpc_resume_decode_merge_sel_f64(int32_t n_tb, int32_t llr_len, cons
  * lam[2 cb + 1]) or the continuation of the selected blocks from their parked state; EVERY block that ran parks its state.
  * nrx_ldpc_certify_f64: the certificate on the parked state of the selected blocks (all when sel == NULL) whose cb_ok is 1;
  * exit_iter[cb] = min(iter_now, 255) where it holds, untouched elsewhere.  n_iter_total = the reference's numIter (the horizon
- * of the error budget); flags: bit 0 / 1 skip the sign / closure conditions -- deliberately BROKEN certificates for the tests. */
+ * of the error budget); max_sweeps = relaxation sweeps before the certificate refuses (clamped to 16: the float32 slack sums'
+ * conservative inflation, nrx_ldpc_certcore.h, is priced for that many); flags -- deliberately BROKEN certificates for the tests:
+ * bit 0 skips the sign / posterior / magnitude conditions (S), (Q), bit 1 the closure condition (M), bit 2 also tries blocks whose
+ * CRC fails (all three honoured by the three kernels). */
 int32_t nrx_ldpc_cert_bounds(const nrx_ldpc_cfg* cfg, int32_t n_rows, double* out3);
 int32_t nrx_ldpc_stage_decode_merge_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
                                         int32_t qm, int32_t n_iter, int32_t n_rows, uint8_t* tb_out, uint8_t* cb_ok,

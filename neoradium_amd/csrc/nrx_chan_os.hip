@@ -170,12 +170,26 @@ td_path_spectra_kernel(const double* __restrict__ taps, const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------- the filter
+// LDS: NX transform buffers, then the twiddles of passes B (16 x 3) and C (2 x 3): only pass A's live in registers (the prefetched
+// input block needs the others' 24 VGPRs).  During the H set-up the transform buffers hold the set's gains.
+constexpr int OS_TWL = 64;
+#ifndef NRX_OS_ABLATE
+#define NRX_OS_ABLATE 0       // developer timing ablations (wrong results): 1 = one path in the H set-up, 2 = no prefetch of the next block
+#endif
+#ifndef NRX_OS_TW_LDS
+#define NRX_OS_TW_LDS 1       // twiddles of passes B and C from LDS (1) or in registers (0)
+#endif
+#ifndef NRX_OS_G_LDS
+#define NRX_OS_G_LDS 1        // the set's gains through LDS (1) or by scalar loads (0)
+#endif
+
 template <int NX>       // Nr = Nt = NX in {1, 2, 4}; 128 * NX threads
 __global__ void __launch_bounds__(128 * NX, 2)
-apply_td_os_kernel(const cd* __restrict__ x, int64_t ns, const cd* __restrict__ gains1, int n_paths, const cd* __restrict__ spec,
+apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gains1, int n_paths, const cd* __restrict__ spec,
                    const cd* __restrict__ tw, int hist, OsGeom g, cd* __restrict__ y, double* __restrict__ pow_acc, int pow_nfft) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* bufs = (cd*)smem;                     // [NX][OS_ELEMS]
+  cd* twl = bufs + NX * OS_ELEMS;           // [OS_TWL]
   constexpr int PP = 8 / NX;                // positions a thread owns in the pointwise phase
   constexpr int WAVES = 2 * NX;
   const int tid = threadIdx.x;
@@ -185,8 +199,39 @@ apply_td_os_kernel(const cd* __restrict__ x, int64_t ns, const cd* __restrict__ 
   const int s0 = g.start[set], n_end = g.start[set + 1];
   double sr = 0.0, si = 0.0, s2 = 0.0;
   if (s0 < n_end) {
-    const OsTw w = os_twiddles(tw, j);
-    // ---- H[r][t] at this thread's PP positions:  sum_p g[r][t][p] * C_p
+    const cd* xr = x + ((size_t)b * NX + f) * (size_t)ns;
+    cd* yr = y + ((size_t)b * NX + f) * (size_t)ns;
+    const int V = OSN - hist;
+    // input block of the outputs [n0, n0 + V): u[i] = x[n0 - hist + i], thread j takes i = j + 128 m
+    auto load8 = [&](int n0, cd (&u)[8]) __attribute__((always_inline)) {
+      const int i0 = n0 - hist + j;
+      if (n0 - hist >= 0 && n0 - hist + OSN <= ns) {            // (workgroup-uniform) all in range: eight plain loads
+#pragma unroll
+        for (int m = 0; m < 8; ++m) u[m] = xr[i0 + 128 * m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int idx = i0 + 128 * m;
+          u[m] = (idx >= 0 && idx < ns) ? xr[idx] : cd(0.0, 0.0);
+        }
+      }
+    };
+    cd pf[8];                               // the next block's input, in flight while this one is transformed
+    load8(s0, pf);
+    __builtin_amdgcn_sched_barrier(0);
+    const cd wa1 = tw[8 * j], wa2 = tw[16 * j], wa4 = tw[32 * j];
+    if (tid < 16) {
+      twl[3 * tid] = tw[64 * tid];
+      twl[3 * tid + 1] = tw[128 * tid];
+      twl[3 * tid + 2] = tw[256 * tid];
+    } else if (tid < 18) {
+      const int lc = tid - 16;
+      twl[48 + 3 * lc] = tw[512 * lc];
+      twl[48 + 3 * lc + 1] = tw[1024 * lc];
+      twl[48 + 3 * lc + 2] = tw[2048 * lc];
+    }
+    // ---- H[r][t] at this thread's PP positions:  sum_p g[r][t][p] * C_p.  The set's gains go through LDS (uniform reads), the
+    // spectra of path p + 1 are fetched while path p is accumulated.
     cd H[NX][NX][PP];
 #pragma unroll
     for (int r = 0; r < NX; ++r)
@@ -194,56 +239,88 @@ apply_td_os_kernel(const cd* __restrict__ x, int64_t ns, const cd* __restrict__ 
       for (int t = 0; t < NX; ++t)
 #pragma unroll
         for (int k = 0; k < PP; ++k) H[r][t][k] = cd(0.0, 0.0);
-    const cd* gb = gains1 + ((size_t)b * g.n_sets + set) * NX * NX * n_paths;      // [r][t][p], wave-uniform
-    for (int p = 0; p < n_paths; ++p) {
+    {
+      const cd* gb = gains1 + ((size_t)b * g.n_sets + set) * NX * NX * n_paths;      // [r][t][p]
+#if NRX_OS_G_LDS
+      cd* gl = bufs;
+      for (int i = tid; i < NX * NX * n_paths; i += 128 * NX) gl[i] = gb[i];
+#else
+      const cd* gl = gb;
+#endif
+      __syncthreads();
+      const cd* sp = spec + PP * tid;
       cd c[PP];
 #pragma unroll
-      for (int k = 0; k < PP; ++k) c[k] = spec[(size_t)p * OSN + PP * tid + k];
+      for (int k = 0; k < PP; ++k) c[k] = sp[k];
+#if NRX_OS_ABLATE == 1
+      const int np = 1;
+#else
+      const int np = n_paths;
+#endif
+      for (int p = 0; p < np; ++p) {
+        cd cn[PP];
+        const cd* spn = sp + (size_t)(p + 1 < np ? p + 1 : p) * OSN;
 #pragma unroll
-      for (int r = 0; r < NX; ++r)
+        for (int k = 0; k < PP; ++k) cn[k] = spn[k];
 #pragma unroll
-        for (int t = 0; t < NX; ++t) {
-          const cd gg = gb[(size_t)(r * NX + t) * n_paths + p];
+        for (int r = 0; r < NX; ++r)
 #pragma unroll
-          for (int k = 0; k < PP; ++k) {
-            H[r][t][k].re = fma(gg.re, c[k].re, fma(-gg.im, c[k].im, H[r][t][k].re));
-            H[r][t][k].im = fma(gg.re, c[k].im, fma(gg.im, c[k].re, H[r][t][k].im));
+          for (int t = 0; t < NX; ++t) {
+            const cd gg = gl[(r * NX + t) * n_paths + p];
+#pragma unroll
+            for (int k = 0; k < PP; ++k) {
+              H[r][t][k].re = fma(gg.re, c[k].re, fma(-gg.im, c[k].im, H[r][t][k].re));
+              H[r][t][k].im = fma(gg.re, c[k].im, fma(gg.im, c[k].re, H[r][t][k].im));
+            }
           }
-        }
+#pragma unroll
+        for (int k = 0; k < PP; ++k) c[k] = cn[k];
+      }
     }
     cd* buf = bufs + (size_t)f * OS_ELEMS;
     const int ia = osi(j), ib = os_base_b(j), ic = os_base_c(j);
     const int ip = osi(PP * tid);           // pointwise phase: positions PP*tid .. +PP-1 (inside one 16-block) of every transform
-    const cd* xr = x + ((size_t)b * NX + f) * ns;
-    cd* yr = y + ((size_t)b * NX + f) * ns;
-    const int V = OSN - hist;
+#if NRX_OS_TW_LDS
+    const cd* twb = twl + 3 * (j & 15);
+    const cd* twc = twl + 48 + 3 * (j & 1);
+#else
+    const cd twb[3] = {tw[64 * (j & 15)], tw[128 * (j & 15)], tw[256 * (j & 15)]};
+    const cd twc[3] = {tw[512 * (j & 1)], tw[1024 * (j & 1)], tw[2048 * (j & 1)]};
+#endif
     // power sums (Waveform.getRePower, waveform.py:107-117): the nfft samples of the symbol from round(cpLen / 2) on
     const bool want_pow = pow_acc && set < g.n_sets - 1;
     const int poff = (int)rint((double)(n_end - s0 - pow_nfft) * 0.5);
     for (int n0 = s0; n0 < n_end; n0 += V) {
       cd v[8];
-      // ---- forward pass A straight from global memory: u[i] = x[n0 - hist + i], i = j + 128 m
+      // ---- forward pass A on the prefetched input
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int64_t idx = (int64_t)n0 - hist + j + 128 * m;
-        v[m] = (idx >= 0 && idx < ns) ? xr[idx] : cd(0.0, 0.0);
-      }
-      dif3(v, w.a1, w.a2, w.a4);
-      __syncthreads();                      // (the previous block's inverse pass A has read its points)
+      for (int m = 0; m < 8; ++m) v[m] = pf[m];
+      dif3(v, wa1, wa2, wa4);
+      __syncthreads();                      // (the previous block's inverse pass A -- the first time: the H set-up -- has read the buffers)
 #pragma unroll
       for (int m = 0; m < 8; ++m) buf[ia + 136 * m] = v[m];
+#if NRX_OS_ABLATE != 2
+      if (n0 + V < n_end) load8(n0 + V, pf);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       __syncthreads();
+      {
+        const cd w1 = twb[0], w2 = twb[1], w4 = twb[2];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = buf[ib + 17 * m];
-      dif3(v, w.b1, w.b2, w.b4);
+        for (int m = 0; m < 8; ++m) v[m] = buf[ib + 17 * m];
+        dif3(v, w1, w2, w4);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) buf[ib + 17 * m] = v[m];
+        for (int m = 0; m < 8; ++m) buf[ib + 17 * m] = v[m];
+      }
       __syncthreads();
+      {
+        const cd w1 = twc[0], w2 = twc[1], w4 = twc[2];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = buf[ic + 2 * m];
-      dif3(v, w.c1, w.c2, w.c4);
+        for (int m = 0; m < 8; ++m) v[m] = buf[ic + 2 * m];
+        dif3(v, w1, w2, w4);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) buf[ic + 2 * m] = v[m];
+        for (int m = 0; m < 8; ++m) buf[ic + 2 * m] = v[m];
+      }
       __syncthreads();
       // ---- pointwise: stage 9 forward, Y_r = sum_t H[r][t] X_t, stage 9 inverse; in place (a thread touches its own positions only)
       {
@@ -278,21 +355,27 @@ apply_td_os_kernel(const cd* __restrict__ x, int64_t ns, const cd* __restrict__ 
       }
       __syncthreads();
       // ---- inverse passes C, B (LDS) and A (to global memory)
+      {
+        const cd w1 = twc[0], w2 = twc[1], w4 = twc[2];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = buf[ic + 2 * m];
-      dit3(v, w.c1, w.c2, w.c4);
+        for (int m = 0; m < 8; ++m) v[m] = buf[ic + 2 * m];
+        dit3(v, w1, w2, w4);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) buf[ic + 2 * m] = v[m];
+        for (int m = 0; m < 8; ++m) buf[ic + 2 * m] = v[m];
+      }
       __syncthreads();
+      {
+        const cd w1 = twb[0], w2 = twb[1], w4 = twb[2];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = buf[ib + 17 * m];
-      dit3(v, w.b1, w.b2, w.b4);
+        for (int m = 0; m < 8; ++m) v[m] = buf[ib + 17 * m];
+        dit3(v, w1, w2, w4);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) buf[ib + 17 * m] = v[m];
+        for (int m = 0; m < 8; ++m) buf[ib + 17 * m] = v[m];
+      }
       __syncthreads();
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = buf[ia + 136 * m];
-      dit3(v, w.a1, w.a2, w.a4);
+      dit3(v, wa1, wa2, wa4);
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int i = j + 128 * m;          // circular-convolution index: valid from hist on
@@ -307,6 +390,9 @@ apply_td_os_kernel(const cd* __restrict__ x, int64_t ns, const cd* __restrict__ 
           }
         }
       }
+#if NRX_OS_ABLATE == 2
+      if (n0 + V < n_end) load8(n0 + V, pf);
+#endif
     }
   }
   if (pow_acc) {        // one (sum re, sum im, sum |y|^2) triple per wave, in a fixed order: reproducible, no atomics
@@ -341,8 +427,8 @@ extern "C" int32_t nrx_apply_td_os_f64(const void* x, int32_t n_items, int32_t n
                                        int32_t n_rx, int32_t n_paths, const void* spec, int32_t hist, const int32_t* set_lens, void* y,
                                        int32_t nfft, double* pow_acc, int64_t pow_capacity, int32_t* n_part, void* stream) {
   NRX_REQUIRE(x && gains1 && spec && set_lens && y, NRX_E_ARG, "nrx_apply_td_os: NULL buffer");
-  NRX_REQUIRE(n_sets >= 1 && n_sets <= 16 && n_paths >= 1 && hist >= 0 && ns > 0 && n_items >= 0, NRX_E_ARG, "nrx_apply_td_os: bad sizes");
-  if (!(n_rx == n_tx && (n_rx == 1 || n_rx == 2 || n_rx == 4) && hist <= OSN - 384)) {
+  NRX_REQUIRE(n_sets >= 1 && n_sets <= 16 && n_paths >= 1 && hist >= 0 && ns > 0 && ns < (1ll << 30) && n_items >= 0, NRX_E_ARG, "nrx_apply_td_os: bad sizes");
+  if (!(n_rx == n_tx && (n_rx == 1 || n_rx == 2 || n_rx == 4) && hist <= OSN - 384 && n_paths <= 1024 / n_rx)) {
     ::nrx::set_error("nrx_apply_td_os: built for Nr = Nt in {1, 2, 4} and paths no longer than %d samples (Nr %d, Nt %d, hist %d)", OSN - 384,
                      n_rx, n_tx, hist);
     return NRX_E_UNSUPPORTED;
@@ -368,12 +454,12 @@ extern "C" int32_t nrx_apply_td_os_f64(const void* x, int32_t n_items, int32_t n
   if (n_items == 0) return NRX_OK;
   const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_apply_td_os: FFT twiddle table unavailable");
-  const size_t lds = sizeof(cd) * (size_t)n_rx * OS_ELEMS;
+  const size_t lds = sizeof(cd) * ((size_t)n_rx * OS_ELEMS + OS_TWL);      // (the set's Nr x Nt x n_paths gains fit the transform buffers)
   const dim3 grid(n_sets, n_items);
 #define NRX_OS_CASE(NX)                                                                                                         \
   case NX:                                                                                                                      \
     (void)hipFuncSetAttribute((const void*)apply_td_os_kernel<NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-    hipLaunchKernelGGL(apply_td_os_kernel<NX>, grid, dim3(128 * NX), lds, (hipStream_t)stream, (const cd*)x, ns, (const cd*)gains1, \
+    hipLaunchKernelGGL(apply_td_os_kernel<NX>, grid, dim3(128 * NX), lds, (hipStream_t)stream, (const cd*)x, (int)ns, (const cd*)gains1, \
                        n_paths, (const cd*)spec, tw, hist, g, (cd*)y, pow_acc, nfft);                                           \
     break;
   switch (n_rx) {

@@ -1,19 +1,20 @@
 // Stability certificate for early termination of the float64 layered min-sum decoder (ldpc.py:1495-1581 runs a fixed number of
 // iterations, ldpc.py:1545, and has no early stop): the a-priori magnitude bounds (host), the certificate kernel on the state a
-// stage of nrx_ldpc_dec3.hip parked, and the entry points.  DESIGN 4.1j has the statement and the proof; oracle/certificate.py is
+// stage of nrx_ldpc_dec3.hip parked, and the entry points.  DESIGN 4.3 has the statement and the proof; oracle/certificate.py is
 // the CPU restatement the tests check this against.
 #include <stddef.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "nrx_ldpc_graph.h"
 #include "nrx_common.h"
+#include "nrx_ldpc_certcore.h"      // WINFL: the float32 slack sums' conservative inflation
 
 int32_t nrx_ldpc_fused_rows_run(const nrx_ldpc_cfg* cfg, int32_t nl, int32_t qm, int32_t llr_len, int32_t n_rows, int* rows_run);   // nrx_ldpc_dec3.hip
 
 namespace nrx_cert {
 using namespace nrx_ldpc;
 
-// STABILITY CERTIFICATE for early termination (DESIGN 4.1j has the statement and the proof; oracle/certificate.py is its CPU
+// STABILITY CERTIFICATE for early termination (DESIGN 4.3 has the statement and the proof; oracle/certificate.py is its CPU
 // restatement).  The reference runs a fixed number of iterations (ldpc.py:1545) and has no early stop; this kernel decides, from
 // the FROZEN decoder state a stage parked, whether every later iteration of that same float64 recursion provably leaves every
 // hard decision where it is.  One code block per workgroup, in the decoder's own lane frame (lane z of layer L = check row
@@ -226,9 +227,10 @@ ldpc_certify_kernel(const double* __restrict__ state, int n_cb, const int32_t* _
           srw = __builtin_amdgcn_alignbit(srw, hi32(r[j]), 31);         // (srw << 1) | sign(r_j)
           double tl;
           if constexpr (col < B::CORE) {
-            const double x = tau - (double)W[j];
+            // float32 slack sums: W x WINFL bounds the true sum from above (nrx_ldpc_certcore.h)
+            const double x = __builtin_fma(-(double)W[j], nrx_certcore::WINFL, tau);
             tl = x - ((uint32_t)j == oidx ? k2 : k1);
-            double pr = __builtin_fabs(r[j]) - (double)W[j];
+            double pr = __builtin_fma(-(double)W[j], nrx_certcore::WINFL, __builtin_fabs(r[j]));
             if constexpr (HASF) {
               const bool hg = __builtin_fabs(r[j]) >= 5.0e8;
               hgw = (hgw << 1) | (hg ? 1u : 0u);
@@ -305,7 +307,7 @@ ldpc_certify_kernel(const double* __restrict__ state, int n_cb, const int32_t* _
 
 }  // namespace nrx_cert
 
-// ---- Certified early exit (DESIGN 4.1j).  A-priori magnitude bounds of the recursion on the first n_rows rows of the base graph,
+// ---- Certified early exit (DESIGN 4.3).  A-priori magnitude bounds of the recursion on the first n_rows rows of the base graph,
 // per unit of the LLR maxima (scale invariant, independent of the lifting size):  |t_{i,c}| <= |L_c| + sum_{j != i} |m_{j,c}|  and
 // |m_{i,c}| <= 0.75 min_{k != c} |t_{i,k}|  hold in every iteration whatever the signs (the +1e5 quirk, ldpc.py:1563, only lowers a
 // second minimum), so every magnitude stays below the least fixed point of  V_{i,c} = lam_c + sum_{j != i} U_{j,c},
@@ -431,7 +433,7 @@ extern "C" int32_t nrx_ldpc_certify_f64(const void* state, int32_t n_tb, int32_t
   cp.gamma1 = b3[1];
   cp.dmax = (int32_t)b3[2];
   cp.n_iter_total = n_iter_total;
-  cp.max_sweeps = max_sweeps;
+  cp.max_sweeps = max_sweeps < 16 ? max_sweeps : 16;      // (WINFL's update count assumes <= 16 sweeps)
   cp.flags = flags;
   cp.iter_now = iter_now;
   if (n_tb == 0) return NRX_OK;

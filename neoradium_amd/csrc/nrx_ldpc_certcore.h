@@ -9,6 +9,16 @@
 namespace nrx_certcore {
 using namespace nrx_ldpc;
 
+// The slack sums W_c (float32) are kept by round-to-nearest updates W <- fl(W + fl(w_new - w_old)): each update can leave W below the
+// true sum of the (exactly stored, float32) slacks by at most 2^-23 of the new sum (two roundings, both operands <= the sum; slacks
+// only grow, so the sum never shrinks).  An element of W is updated at most once per row and sweep: <= 46 rows x 16 sweeps (the
+// entries clamp max_sweeps to 16) = 736 updates, so  sum_j w_j <= W (1 + 736 x 2^-23)(1 + 2^-24 for the initial product zeta x degree)
+// < W (1 + 2^-13.4); the tuned kernels (15 rows, 4 sweeps by default) stay below W (1 + 2^-17).  Every USE of a sum therefore
+// takes W x WINFL, WINFL = 1 + 2^-13: the loss W - w + 2E of (S) and (M) and the posterior test rho >= W + G are evaluated on an
+// upper bound of the true sums -- what the proof ("Arithmetic of the certificate itself") needs.  The fused multiply-add
+// that forms tau - W x WINFL rounds once (relative 2^-53 of a quantity <= beta: inside E's 1.0625).
+constexpr double WINFL = 1.0 + 0x1p-13;
+
 struct Params {
   double gamma, gamma1;      // a-priori magnitude bounds per unit of the LLR maxima (nrx_ldpc_cert_bounds)
   int32_t dmax, n_iter_total, max_sweeps, flags, iter_now;
@@ -192,9 +202,10 @@ __device__ __forceinline__ bool certify_on_chip(const Params& cp, double lam_all
           srw = __builtin_amdgcn_alignbit(srw, hi32(rj), 31);
           double tl;
           if constexpr (col < B::CORE) {
-            const double x = tau - (double)W[j];
+            // the slack sums are float32, kept by round-to-nearest updates: W * WINFL is an upper bound of the true sum (see WINFL)
+            const double x = __builtin_fma(-(double)W[j], WINFL, tau);
             tl = sel_sub_x<j>(x, oidx, k1, k2, tlo);      // x - (j == oidx ? k2 : k1), and tlo <- that where j == oidx
-            double pr = __builtin_fabs(rj) - (double)W[j];
+            double pr = __builtin_fma(-(double)W[j], WINFL, __builtin_fabs(rj));
             if constexpr (HASF) {
               const bool hg = __builtin_fabs(rj) >= 5.0e8;
               hgw = (hgw << 1) | (hg ? 1u : 0u);

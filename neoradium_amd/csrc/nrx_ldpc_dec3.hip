@@ -1114,7 +1114,7 @@ extern "C" int32_t nrx_ldpc_stage_certify_decode_merge_f64(const double* llr, in
   const int32_t rb = nrx_ldpc_cert_bounds(cfg, rows_run, b3);
   if (rb) return rb;
   nrx_certcore::Params cp;
-  cp.gamma = b3[0]; cp.gamma1 = b3[1]; cp.dmax = (int32_t)b3[2]; cp.n_iter_total = n_iter_total; cp.max_sweeps = max_sweeps; cp.flags = flags;
+  cp.gamma = b3[0]; cp.gamma1 = b3[1]; cp.dmax = (int32_t)b3[2]; cp.n_iter_total = n_iter_total; cp.max_sweeps = max_sweeps < 16 ? max_sweeps : 16; cp.flags = flags;
   cp.iter_now = iter_now;
   if (sel == nullptr) {
     NRX_REQUIRE(llr, NRX_E_ARG, "nrx_ldpc_stage_certify_decode_merge: NULL llr");

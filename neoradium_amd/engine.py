@@ -106,7 +106,7 @@ def gain_times(tables, slots):
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
                  decoder="f64", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
-                 skipPuncturedRows=True, waveform="f64", certifiedExit=None, certFlags=0, certSweeps=8, certInKernel=True):
+                 skipPuncturedRows=True, waveform="f64", certifiedExit=None, certFlags=0, certSweeps=4, certInKernel=True):
         if waveform not in ("f32", "f64"):
             raise ValueError("waveform must be 'f64' (the reference's complex128 waveforms, default) or 'f32' (time-domain link only: "
                              "Tx grid, OFDM, channel filter and received grid in complex64 -- not the parity path)")
@@ -136,7 +136,7 @@ class PdschLink:
         # blocks stays on the device; elsewhere they are decoded again from scratch after one host read per batch.
         # Opt-in CERTIFIED early exit (off by default; the reference has no early stop, ldpc.py:1545): `certifiedExit` = an ascending
         # list of iteration counts.  At each of them a block stops only if its CRC passes AND the stability certificate holds on
-        # its frozen decoder state (ops.ldpc_recover_decode_merge_certified; DESIGN 4.1j): its bits are then provably those of the
+        # its frozen decoder state (ops.ldpc_recover_decode_merge_certified; DESIGN 4.3): its bits are then provably those of the
         # full `numIter` run.  Needs the fused float64 entry (else ValueError at the first batch).  `certFlags` != 0 breaks the
         # certificate on purpose (tests).
         if certifiedExit is not None:

@@ -354,13 +354,16 @@ _cert_bufs = {}
 _cert_scratch = {}
 
 
-def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0, max_sweeps=8, flags=0, in_kernel=True):
+def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0, max_sweeps=4, flags=0, in_kernel=True):
     """The CERTIFIED early exit on the fused entry (opt-in; the reference has no early stop, ldpc.py:1545).  ``stages`` = ascending
     iteration counts at which the blocks still running are checked: a block whose CRC24B passes AND whose frozen decoder state holds
     the stability certificate (nrx_ldpc_certify_f64: every later iteration provably leaves its hard decisions unchanged) stops there;
     every other block continues from its parked state, the last ones to ``n_iter``.  Work lists stay on the device.
     -> (tb_out, cb_ok, exit_iter uint8 (n_cb,): the iteration a block was certified at, 0 = ran all n_iter), or None when the
-    configuration has no fused instantiation.  ``flags`` != 0 breaks the certificate on purpose (tests only).  ``in_kernel`` (default):
+    configuration has no fused instantiation.  ``max_sweeps`` = relaxation sweeps the certificate may take before it refuses (both forms
+    honour it; 99.5 % of the certified blocks need 2; the library clamps it to 16).  ``flags`` != 0 breaks the certificate on purpose
+    (tests only: bit 0 drops the sign / posterior conditions (S), (Q), bit 1 the closure (M), bit 2 also tries blocks whose CRC fails).
+    ``in_kernel`` (default):
     the certificate is evaluated in the stage kernel's tail (nrx_ldpc_stage_certify_decode_merge_f64: a certified block never parks);
     False: stage, then the stand-alone nrx_ldpc_certify_f64 on the parked states -- the same conditions, another search order."""
     if llr.dtype != torch.float64 or llr.dim() != 2 or not (cfg.bg == 1 and cfg.Zc == 384 and cfg.C > 1):
@@ -397,7 +400,7 @@ def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0
         scr = _cert_scratch.get(key)
         if scr is None or scr.numel() < need:
             scr = _cert_scratch[key] = torch.empty(need, dtype=torch.uint8, device=dev)
-        sw = min(int(max_sweeps), 4)
+        sw = int(max_sweeps)
         check(L.nrx_ldpc_stage_certify_decode_merge_f64(ptr(llr), n_tb, G, cfgp, nl, qm, marks[0], r, ptr(tb_out), ptr(cb_ok), None, None, ptr(state),
                                                         ptr(lam), ptr(exit_iter), ptr(scr), scr.numel(), marks[0], int(n_iter), sw, int(flags), stream()))
         done = marks[0]

@@ -3,7 +3,7 @@
 The reference runs a fixed number of iterations (ldpc.py:1545); it has no early stop.  The certificate below is evaluated on
 the FROZEN state of the reference's own decoder (posteriors r, messages ll[row]; ldpc.py:1546-1576) after some iteration k
 and, when it holds, proves that every later iteration of that same float64 recursion leaves every hard decision unchanged
-(DESIGN.md 4.1j has the proof).  `decode_certified` is the oracle decoder (oracle/coding.py:decode) with that check evaluated
+(DESIGN.md 4.3 has the proof).  `decode_certified` is the oracle decoder (oracle/coding.py:decode) with that check evaluated
 after chosen iterations; the HIP kernels' certificate flags and certified bits are tested against it and against the full run.
 """
 import numpy as np
@@ -86,11 +86,19 @@ def growth_bounds(bgn, rows, filler_cols=()):
     got = _lfp(cols, ncol, lam)
     if got is not None:
         Vs, U = got
-        g = 0.0
+        # |r_c| <= lam_c + sum_j U_{j,c} on every column -- INCLUDING the columns that hold fillers: their non-filler elements carry
+        # real LLRs (|L| <= the maximum: lam = 1 for them), so a message of unbounded size into such a column means no bound at all
+        # (nrx_ldpc_cert_bounds does the same)
+        S = np.zeros(ncol)
+        unbounded = np.zeros(ncol, dtype=bool)
         for i, c in enumerate(cols):
-            fin = np.isfinite(lam[c])
-            g = max(g, (Vs[i] + U[i])[fin].max())
-        out['gamma'] = g * (1 + 1e-9)
+            fin = np.isfinite(U[i])
+            np.add.at(S, c[fin], U[i][fin])
+            unbounded[c[~fin]] = True
+        used = deg > 0
+        if not unbounded[used].any():
+            lam1 = np.where(np.arange(ncol) < 2, 0.0, 1.0)
+            out['gamma'] = float((lam1 + S)[used].max()) * (1 + 1e-9)
     lam = np.ones(ncol)
     lam[:2] = 0.0
     lam[2:kb] = np.inf
@@ -103,7 +111,7 @@ def growth_bounds(bgn, rows, filler_cols=()):
 
 
 def margins(gb, lam_all, lam_pe, num_iter=50):
-    """The error budget of the proof (DESIGN 4.1j).  E bounds |r_c - (L_c + sum_j m_{j,c})| over the whole run: two roundings per
+    """The error budget of the proof (DESIGN 4.3).  E bounds |r_c - (L_c + sum_j m_{j,c})| over the whole run: two roundings per
     (row, column) visit, each at most 2^-53 of a magnitude below beta = gamma * max|LLR|.  zeta = the slack of a floor under its
     frozen message, delta = what a future extrinsic value of a core column can lose against the frozen one (kept for reference: the
     relaxation works with per-message slacks), G = the sign margin asked of every posterior, mcap / mcapx = the largest frozen message

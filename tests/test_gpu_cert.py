@@ -1,4 +1,4 @@
-"""GPU: the certified early exit (nrx_ldpc_stage_decode_merge_f64 + nrx_ldpc_certify_f64, DESIGN 4.1j) through the C ABI.
+"""GPU: the certified early exit (nrx_ldpc_stage_decode_merge_f64 + nrx_ldpc_certify_f64, DESIGN 4.3) through the C ABI.
 
 The reference runs a fixed number of iterations (ldpc.py:1545); a block the certificate stops early must carry exactly the bits
 the fixed schedule ends on.  Checked bit for bit against the fixed schedule of the same library (itself bit-identical to the

@@ -1,4 +1,4 @@
-"""Prototype (CPU, NumPy) of the STABILITY CERTIFICATE for early termination of the layered min-sum decoder (DESIGN 4.1j).
+"""Prototype (CPU, NumPy) of the STABILITY CERTIFICATE for early termination of the layered min-sum decoder (DESIGN 4.3).
 
 Runs the oracle's float64 decoder (oracle/coding.py:decode = ldpc.py:1495-1581) on 64-QAM / AWGN LLRs and, after chosen
 iterations, evaluates the certificate on the frozen state.  Reports at which check a block certifies and verifies that every
