@@ -141,6 +141,15 @@ def test_noise_level_and_noise(dev):
         assert abs(a[i].mean()) < 0.02 and abs(np.var(a[i].real) - np.var(a[i].imag)) < 0.03 * sg[i].item() ** 2
     b = ops.awgn(big[2:], sg[2:], seed=99, batch_offset=2).cpu().numpy()
     assert np.array_equal(a[2:], b)
+    # ... and its shape: the components are N(0, sigma^2 / 2) (nrx_rng.h normal_pair: Box-Muller on the float32 transcendental
+    # unit) -- fourth moment, 3-sigma tail mass, no correlation between the components, uniform phase
+    for i in range(4):
+        c = np.concatenate([a[i].real, a[i].imag]) / (sg[i].item() / np.sqrt(2))
+        assert abs(np.mean(c ** 4) - 3.0) < 0.06 and abs(np.mean(np.abs(c) > 3.0) - 0.0026998) < 3e-4
+        assert abs(np.mean(a[i].real * a[i].imag)) < 0.01 * sg[i].item() ** 2
+        ph = np.histogram(np.angle(a[i]), bins=16, range=(-np.pi, np.pi))[0] / a[i].size
+        assert np.abs(ph - 1 / 16).max() < 0.004
+    assert np.abs(a[0]).max() > 3.0 and np.isfinite(a).all()
 
 
 @pytest.mark.parametrize("mu,nfft,K,slot", [(0, 2048, 300, 0), (1, 1024, 612, 1), (1, 4096, 3276, 0), (2, 512, 240, 2)])
