@@ -25,7 +25,7 @@ from .csirs import CsiRsConfig, CsiRsSet, CsiRs                # noqa: F401
 from .csifeedback import CsiReport                             # noqa: F401
 from .random import random                                     # noqa: F401
 from .snrhelper import SnrScheduler                            # noqa: F401
-from .engine import PdschLink, run_sweep                       # noqa: F401
+from .engine import PdschLink, run_sweep, run_harq_sharded     # noqa: F401
 
 try:                                                           # polar codec (control channel path)
     from .polar import PolarEncoder, PolarDecoder              # noqa: F401

@@ -251,6 +251,7 @@ class PdschLink:
         self.slot_len = [int(v[:-1].sum()) for v in self.sym_lens]
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
+        self._enc_buf = {}        # codeword -> ((batch size, rows), coded-bit buffer) reused from batch to batch (ops.ldpc_encode out=)
         self._sep_rr = bool(int(os.environ.get('NRX_SEPARATE_RATE_RECOVERY', '0')))    # developer switch: demap, then rate recovery
         # developer switch: the reference's operation order for the wideband precoder (precode the grid, then modulate the ports and
         # filter with the plain gains) instead of folding it into the filter's gains (same arithmetic up to reassociation of the precoder)
@@ -430,7 +431,12 @@ class PdschLink:
                 tb = (tb_bits[q] if self.numCW > 1 else tb_bits).to(dev).to(torch.uint8).contiguous()
             tbs_in.append(tb)
             # (first transmissions send nothing beyond the columns of the active rows: their parity is not computed)
-            coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'], rows=cw['rows'] if harq is None else None)
+            # (the coded-bit buffer of a (codeword, batch size, row count) is kept: its never-written parity columns are cleared once)
+            enc_rows = cw['rows'] if harq is None else None
+            ekey = (n, enc_rows)
+            held = self._enc_buf.get(q)
+            coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'], rows=enc_rows, out=held[1] if held and held[0] == ekey else None)
+            self._enc_buf[q] = (ekey, coded)
             bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[q][0])
             tx_bits.append(bits)
             if grid is None:    # one codeword: template + scramble + modulate + layer/RE map in one pass over the grid
@@ -579,7 +585,7 @@ class PdschLink:
 
     # ----------------------------------------------------------------------------------------------- HARQ
     def run_harq(self, n_proc, n_rounds, snr_db, seed=0, rvSequence=(0, 2, 3, 1), maxTries=4, harqType="IR", slot0=0,
-                 state=None, tb_bits=None, noise=None, trace=None):
+                 state=None, tb_bits=None, noise=None, trace=None, proc_offset=0, n_proc_total=None):
         """Batched HARQ (reference harq.py + Playground/HARQ/Harq.ipynb loop) for ``n_proc`` HARQ processes.
 
         Round k transmits slots slot0 + k*n_proc + p, p = 0..n_proc-1, one per process -- the reference's round-robin
@@ -598,9 +604,17 @@ class PdschLink:
         of every slot; ``trace`` (a list) receives one dict per round: rv / new flags / LLRs / CRC verdicts per codeword and a
         copy of the soft buffers after the round.
 
+        Sharding by process streams (``run_harq_sharded``): this call simulates the processes ``proc_offset .. proc_offset + n_proc - 1``
+        of ``n_proc_total`` -- process p of round k still transmits slot slot0 + k*n_proc_total + p, so every process sees the transport
+        blocks, channel and noise it sees in a single-process run of all n_proc_total of them, and the statistics simply add up.
+
         Returns (stats, state): stats with the fields of ``HarqEntity`` (txBlocks/rxBlocks/txBits/rxBits per try,
         numTimeouts, throughput and BLER in percent, meanTries); pass ``state`` back in to continue the run."""
         dev = self.dev
+        n_proc_total = int(n_proc if n_proc_total is None else n_proc_total)
+        proc_offset = int(proc_offset)
+        if proc_offset < 0 or proc_offset + n_proc > n_proc_total:
+            raise ValueError("run_harq: the processes [proc_offset, proc_offset + n_proc) must lie inside [0, n_proc_total)")
         if harqType not in ("IR", "CC"):
             raise ValueError("harqType must be 'IR' or 'CC'")
         rvs = torch.tensor(list(rvSequence) if harqType == "IR" else [0], dtype=torch.int32, device=dev)
@@ -625,7 +639,7 @@ class PdschLink:
         ones = torch.ones(n_proc, dtype=torch.int64, device=dev)
         spsf = self.bwp.slotsPerSubFrame
         for k in range(n_rounds):
-            s0 = state['next_slot']
+            s0 = state['next_slot'] + proc_offset          # this shard's first slot of the round
             slots = np.arange(s0, s0 + n_proc)
             new, rv = [], []
             for q, c in enumerate(self.cw):
@@ -684,14 +698,19 @@ class PdschLink:
                 trace.append(dict(slots=slots.copy(), rv=[r.clone() for r in rv], new=[n.clone() for n in new], ok=[o.clone() for o in oks],
                                   groups={g: [dict(llr=c['llr'], cb_ok=c['cb_ok'], tb_out=c['tb_out'], bits=c['bits']) for c in o['cw']] for g, o in outs.items()},
                                   circ=[c.clone() for c in state['circ']], tb=[t.clone() for t in state['tb']]))
-            state['next_slot'] = s0 + n_proc
-        tx, rx = state['tx'].cpu().numpy(), state['rx'].cpu().numpy()
-        txb, rxb = state['tx_bits'].cpu().numpy(), state['rx_bits'].cpu().numpy()
-        nto = int(state['timeouts'].item())
-        stats = dict(txBlocks=tx, rxBlocks=rx, txBits=txb, rxBits=rxb, numTimeouts=nto,
-                     throughput=100.0 * rxb.sum() / max(txb.sum(), 1), bler=100.0 * (tx.sum() - rx.sum()) / max(tx.sum(), 1),
-                     meanTries=float(((rx * np.arange(maxTries)).sum() + nto * maxTries) / max(rx.sum() + nto, 1)))
-        return stats, state
+            state['next_slot'] = s0 - proc_offset + n_proc_total
+        return harq_stats(state['tx'].cpu().numpy(), state['rx'].cpu().numpy(), state['tx_bits'].cpu().numpy(), state['rx_bits'].cpu().numpy(),
+                          int(state['timeouts'].item())), state
+
+
+def harq_stats(tx, rx, txb, rxb, nto):
+    """The statistics ``HarqEntity`` prints (harq.py:185-199, 337-395) from the per-try counters: transmitted / received blocks and bits
+    by number of earlier tries, time-outs."""
+    tx, rx, txb, rxb = (np.asarray(v, dtype=np.int64) for v in (tx, rx, txb, rxb))
+    max_tries = len(tx)
+    return dict(txBlocks=tx, rxBlocks=rx, txBits=txb, rxBits=rxb, numTimeouts=int(nto),
+                throughput=100.0 * rxb.sum() / max(txb.sum(), 1), bler=100.0 * (tx.sum() - rx.sum()) / max(tx.sum(), 1),
+                meanTries=float(((rx * np.arange(max_tries)).sum() + nto * max_tries) / max(rx.sum() + nto, 1)))
 
 
 # ------------------------------------------------------------------------------------------------------ sweeps
@@ -702,6 +721,31 @@ def shard_slots(slot0, n_slots, world, rank):
     lo = min(int(n_slots), rank * per)
     hi = min(int(n_slots), lo + per)
     return slot0 + lo, hi - lo
+
+
+def run_harq_sharded(link, n_proc, n_rounds, snr_db, state=None, **kw):
+    """``PdschLink.run_harq`` sharded by independent process streams over the ranks of the default process group (harq.py:626-631: the
+    HARQ processes of an entity take turns and share nothing).  Rank r simulates a contiguous share of the ``n_proc``
+    processes -- each with the slots, transport blocks, channel and noise it has in a single-process run -- and ONE all-reduce(SUM)
+    of the int64 per-try counters (txBlocks, rxBlocks, txBits, rxBits, time-outs: 4 maxTries + 1 numbers) gives every rank the
+    statistics of the whole entity.  Returns (stats, state) like run_harq; ``state`` is this rank's shard (pass it back in)."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    lo, cnt = shard_slots(0, n_proc, world, rank)
+    if cnt > 0:
+        _, state = link.run_harq(cnt, n_rounds, snr_db, state=state, proc_offset=lo, n_proc_total=n_proc, **kw)
+        vec = torch.cat([state['tx'], state['rx'], state['tx_bits'], state['rx_bits'], state['timeouts'].reshape(-1)]).to(torch.int64)
+    else:       # (more ranks than processes: an empty shard still joins the collective)
+        vec = torch.zeros(4 * int(kw.get('maxTries', 4)) + 1, dtype=torch.int64, device=link.dev)
+    vec = vec.clone()
+    if on:
+        if dist.get_backend() == 'gloo':        # (host-side collectives: the CPU tests, several ranks on one GPU)
+            vec = vec.cpu()
+        dist.all_reduce(vec)
+    v = vec.cpu().numpy()
+    m = (len(v) - 1) // 4
+    return harq_stats(v[:m], v[m:2 * m], v[2 * m:3 * m], v[3 * m:4 * m], int(v[4 * m])), state
 
 
 def run_sweep(link, snrs_db, n_slots, seed=0, batch=64, slot0=0):

@@ -56,24 +56,32 @@ def ldpc_segment(tb, cfg, add_tb_crc=True):
     return cbs
 
 
-def ldpc_encode(cbs, cfg, puncture=True, rows=None):
+def ldpc_encode(cbs, cfg, puncture=True, rows=None, out=None):
     """ldpc.py:1033-1090 encode: (n_cb, K) -> (n_cb, N) (or N+2Zc without puncturing).  ``rows``: only the parity of the
     first ``rows`` base-graph rows is produced (columns >= 22 + rows (BG1) / 10 + rows (BG2) of the output stay unwritten): for a
-    caller that rate-matches rv 0 into fewer bits than that (``ldpc_active_rows``)."""
+    caller that rate-matches rv 0 into fewer bits than that (``ldpc_active_rows``).  ``out``: a buffer of the result's shape that
+    an earlier call with the SAME ``rows`` returned (a batched caller's per-link buffer): its unwritten columns are zero already
+    and are not cleared again (219 MB per 256 slots at the metric configuration)."""
     cbs = _u8(cbs)
     if cbs.dim() != 2 or cbs.shape[1] != cfg.K:
         raise ValueError(f"code blocks must be (n_cb, K={cfg.K}), got {tuple(cbs.shape)}")
     width = cfg.N if puncture else cfg.N + 2 * cfg.Zc
-    out = torch.empty((cbs.shape[0], width), dtype=torch.uint8, device=_dev(cbs))
+    reuse = out is not None
+    if reuse:
+        if out.dtype != torch.uint8 or tuple(out.shape) != (cbs.shape[0], width) or not out.is_contiguous() or _dev(out) != _dev(cbs) \
+                or getattr(out, '_nrx_rows', None) != (int(rows) if rows else None):
+            raise ValueError("ldpc_encode: `out` must be the result of an earlier call of the same shape and row count")
+    else:
+        out = torch.empty((cbs.shape[0], width), dtype=torch.uint8, device=_dev(cbs))
     check(lib().nrx_ldpc_encode(ptr(cbs), cbs.shape[0], C.byref(cfg), 1 if puncture else 0, int(rows or 0), ptr(out), stream()))
-    if rows:
+    if rows and not reuse:
         # the parity columns of the other rows are not computed: they are ZEROED (a view, a clone or a slice of the result must
         # never expose uninitialised memory), and ldpc_rate_match refuses a transmission that would read them
         kb = 22 if cfg.bg == 1 else 10
         first = (kb + int(rows) - (2 if puncture else 0)) * cfg.Zc
         if first < width:
             out[:, first:].zero_()
-        out._nrx_rows = int(rows)
+    out._nrx_rows = int(rows) if rows else None
     return out
 
 
@@ -94,7 +102,7 @@ def ldpc_rate_match(coded, cfg, G, nl, qm, rv=0, nref=0):
     gout = ((G + f - 1) // f) * f
     dev = _dev(coded)
     part = getattr(coded, '_nrx_rows', None)
-    if part is not None:       # a rows-truncated encode holds the parity of its first rows only: rv 0 without wrap-around may read it
+    if part:       # a rows-truncated encode holds the parity of its first rows only: rv 0 without wrap-around may read it
         need = ldpc_active_rows(cfg, max(_lib.ldpc_cb_lens(int(G), cfg.C, nl, qm))) if (not torch.is_tensor(rv) and rv == 0 and nref == 0) \
             else (46 if cfg.bg == 1 else 42)
         if need > part:
@@ -395,7 +403,7 @@ def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0
     L = lib()
     cfgp, r = C.byref(cfg), int(rows or 0)
     if in_kernel:
-        n_wg = min((n_cb + 1) // 2, 1024)
+        n_wg = min((n_cb + 1) // 2, int(os.environ.get('NRX_CERT_WGS', '256')))      # (developer knob: workgroups of the stage launches = scratch slots)
         need = n_wg * 2 * (26 + 2 * 15) * 384 * 4
         scr = _cert_scratch.get(key)
         if scr is None or scr.numel() < need:

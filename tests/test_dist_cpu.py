@@ -101,6 +101,74 @@ def test_sharded_sweep_world2_equals_single_process():
         assert table == want
 
 
+class _StubHarqLink:
+    """Stands in for PdschLink.run_harq on the host: whether process p's transmission of round k decodes is a pure function of its
+    ABSOLUTE slot (slot0 + k * n_proc_total + p) -- what the device generator's keying gives the real engine -- and the per-try
+    bookkeeping is the engine's (harq.py:185-199)."""
+    dev = torch.device('cpu')
+
+    def run_harq(self, n_proc, n_rounds, snr_db, state=None, maxTries=4, slot0=0, proc_offset=0, n_proc_total=None, **kw):
+        n_proc_total = n_proc if n_proc_total is None else n_proc_total
+        if state is None:
+            state = dict(tries=np.zeros(n_proc, dtype=np.int64), tx=torch.zeros(maxTries, dtype=torch.int64), rx=torch.zeros(maxTries, dtype=torch.int64),
+                         tx_bits=torch.zeros(maxTries, dtype=torch.int64), rx_bits=torch.zeros(maxTries, dtype=torch.int64),
+                         timeouts=torch.zeros(1, dtype=torch.int64), next_slot=int(slot0))
+        for _ in range(n_rounds):
+            s0 = state['next_slot'] + proc_offset
+            slots = np.arange(s0, s0 + n_proc)
+            ok = ((slots * 2654435761 + 17 * state['tries']) % 11) < (2 + 2 * state['tries'])      # later tries decode more often
+            for t, o in zip(state['tries'], ok):
+                state['tx'][t] += 1
+                state['tx_bits'][t] += 1000
+                state['rx'][t] += int(o)
+                state['rx_bits'][t] += 1000 * int(o)
+            nxt = state['tries'] + 1
+            timeout = (~ok) & (nxt == maxTries)
+            state['timeouts'] += int(timeout.sum())
+            state['tries'] = np.where(ok | timeout, 0, nxt)
+            state['next_slot'] = s0 - proc_offset + n_proc_total
+        from neoradium_amd.engine import harq_stats
+        return harq_stats(state['tx'].numpy(), state['rx'].numpy(), state['tx_bits'].numpy(), state['rx_bits'].numpy(), int(state['timeouts'])), state
+
+
+def _harq_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from neoradium_amd.engine import run_harq_sharded
+    link = _StubHarqLink()
+    st, state = run_harq_sharded(link, 13, 5, 20.0, slot0=40)
+    st2, _ = run_harq_sharded(link, 13, 4, 20.0, state=state, slot0=40)          # continued from this rank's shard
+    q.put((rank, {k: np.asarray(v).tolist() for k, v in st2.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_harq_world2_equals_single_process():
+    """neoradium_amd.run_harq_sharded (HARQ processes split over the ranks as independent streams, harq.py:626-631, one all-reduce of
+    the per-try counters) with two gloo ranks gives every rank the statistics one process computes for all the processes."""
+    sys.path.insert(0, ROOT)
+    from neoradium_amd.engine import run_harq_sharded
+    link = _StubHarqLink()
+    _, state = run_harq_sharded(link, 13, 5, 20.0, slot0=40)
+    want, _ = run_harq_sharded(link, 13, 4, 20.0, state=state, slot0=40)
+    want = {k: np.asarray(v).tolist() for k, v in want.items()}
+    assert sum(want['txBlocks']) == 13 * 9 and want['numTimeouts'] >= 0
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 191) % 500
+    procs = [ctx.Process(target=_harq_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, got in res:
+        assert got == want
+
+
 def test_bench_gpus2_self_launch_gloo():
     """`python bench.py --gpus 2` without a launcher starts two ranks itself (torch.distributed.run children), each rank
     takes its own slot range, the counters are all-reduced and rank 0 prints ONE JSON line with n_gpus == 2.  Runs the

@@ -849,6 +849,34 @@ def test_engine_batched_harq_against_the_oracle(dev):
     assert st2['txBlocks'].sum() == P * R
 
 
+def test_engine_harq_sharded_by_process_streams(dev):
+    """run_harq on a share of the processes (proc_offset / n_proc_total: what run_harq_sharded gives each rank, harq.py:626-631) --
+    the shards' per-try counters add up to the single-process run of all processes, round after round, in throughput mode (device
+    generator keyed by the absolute slot); run_harq_sharded without a process group is the single-process run."""
+    import neoradium_amd as nr
+    from neoradium_amd.engine import harq_stats, run_harq_sharded
+    cfg = dict(seed=5, numRbs=24, spacing=30, mod='16QAM', layers=1, dm=dict(configType=1, additionalPos=1),
+               chan=('cdl', 'C', 100, 5, [1, 1], [1, 1]), slot0=0)
+    car, bwp, p, ch = _slot(nr, cfg)
+    link = nr.PdschLink(p, ch, 490 / 1024, numIter=10, decoder="f64")
+    P, R, MT = 7, 6, 4
+    whole, _ = link.run_harq(P, R, 0.0, seed=4, maxTries=MT, slot0=3)
+    assert whole['txBlocks'][1:].sum() > 0 and whole['rxBlocks'].sum() > 0            # retransmissions happen at this SNR
+    parts = []
+    for lo, cnt in ((0, 4), (4, 3)):
+        st, state = link.run_harq(cnt, 2, 0.0, seed=4, maxTries=MT, slot0=3, proc_offset=lo, n_proc_total=P)
+        st, state = link.run_harq(cnt, R - 2, 0.0, seed=4, maxTries=MT, state=state, proc_offset=lo, n_proc_total=P)     # continued shard
+        parts.append(st)
+    tot = harq_stats(*(sum(np.asarray(s[k]) for s in parts) for k in ('txBlocks', 'rxBlocks', 'txBits', 'rxBits')), sum(s['numTimeouts'] for s in parts))
+    for k in ('txBlocks', 'rxBlocks', 'txBits', 'rxBits'):
+        assert np.array_equal(tot[k], whole[k]), k
+    assert tot['numTimeouts'] == whole['numTimeouts'] and tot['throughput'] == whole['throughput'] and tot['meanTries'] == whole['meanTries']
+    one, _ = run_harq_sharded(link, P, R, 0.0, seed=4, maxTries=MT, slot0=3)
+    assert all(np.array_equal(one[k], whole[k]) for k in ('txBlocks', 'rxBlocks', 'txBits', 'rxBits')) and one['numTimeouts'] == whole['numTimeouts']
+    with pytest.raises(ValueError):
+        link.run_harq(4, 1, 0.0, proc_offset=5, n_proc_total=P)
+
+
 def test_engine_batched_harq_two_codewords_and_60khz(dev):
     """run_harq with two codewords per process (6 layers: harq.py:477, each codeword with its own try counter, redundancy
     version and soft buffer) and at 60 kHz (the slots of one round fall into two symbol geometries: the soft buffers of each
