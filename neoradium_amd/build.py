@@ -41,7 +41,7 @@ def compiler_id():
     global _compiler_id
     if _compiler_id is None:
         try:
-            _compiler_id = subprocess.run([_hipcc(), '--version'], capture_output=True, text=True).stdout.strip()
+            _compiler_id = subprocess.run([_hipcc(), '--version'], capture_output=True, text=True).stdout.strip() or 'unknown'
         except OSError:
             _compiler_id = 'unknown'
     return _compiler_id
@@ -101,7 +101,8 @@ def build(force=False, verbose=True):
     open(fh_path, 'w').write(flags_hash() + '\n')
     if jobs or force or not os.path.exists(LIB) or not stamp_ok():
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
-        open(STAMP, 'w').write(source_hash() + '\n' + lib_hash() + '\n')
+        # sources + flags + compiler | SHA-256 of the library | sources + flags alone (for a box where the compiler cannot be asked)
+        open(STAMP, 'w').write(source_hash() + '\n' + lib_hash() + '\n' + source_hash(with_compiler=False) + '\n')
         # the decoder's instruction counts of THIS binary, for bench.py's VALU-issue roofline (best effort: needs llvm-objdump);
         # written next to the library, not into profiles/ (a build must not touch tracked evidence)
         tool = os.path.join(HERE, '..', 'tools', 'isa_mix.py')
@@ -110,22 +111,24 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def read_stamp():
-    """(source hash, library SHA-256) recorded by the last link, or ('', '')."""
-    if not os.path.exists(STAMP):
-        return '', ''
-    lines = open(STAMP).read().split()
-    return (lines + ['', ''])[0], (lines + ['', ''])[1]
+def read_stamp(full=False):
+    """(source hash, library SHA-256) recorded by the last link, or ('', ''); ``full``: also the compiler-less source hash."""
+    lines = (open(STAMP).read().split() if os.path.exists(STAMP) else []) + ['', '', '']
+    return (lines[0], lines[1], lines[2]) if full else (lines[0], lines[1])
 
 
 def stamp_ok():
     """The library in the tree is the file the last link wrote (SHA-256) AND that link used exactly these sources, flags and
-    compiler.  (On a box without hipcc -- there is none without ROCm -- the compiler part of the hash cannot be formed and the
-    check falls back to sources + flags + the library's own hash.)"""
+    compiler.  On a box where `hipcc --version` cannot be run the compiler part of the hash cannot be formed: the check then uses
+    the stamp's third line, the hash of sources + flags alone (still together with the library's own SHA-256)."""
     if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return False
-    src, so = read_stamp()
-    return so == lib_hash() and src == source_hash()
+    src, so, src_nc = read_stamp(full=True)
+    if so != lib_hash():
+        return False
+    if compiler_id() in ('', 'unknown'):
+        return src_nc != '' and src_nc == source_hash(with_compiler=False)
+    return src == source_hash()
 
 
 if __name__ == '__main__':

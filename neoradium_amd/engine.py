@@ -301,7 +301,7 @@ class PdschLink:
         return self._gather[key]
 
     # ------------------------------------------------------------------------------------------------ run
-    def run(self, slot0, n_slots, snr_db, seed=0, tb_bits=None, noise=None, counters=None, details=False):
+    def run(self, slot0, n_slots, snr_db, seed=0, tb_bits=None, noise=None, counters=None, details=False, precoder=None):
         """Simulate absolute slots [slot0, slot0+n_slots).  Returns the int64[4] device counters
         (blockErrors, totalBlocks, bitErrors, totalBits) -- accumulated into ``counters`` when given.
         ``details=True`` also returns every intermediate of each geometry group, ``details="verdicts"`` only the
@@ -310,7 +310,9 @@ class PdschLink:
         Throughput mode (default): transport blocks and noise come from the counter-based device generator keyed by
         (seed, slot index), so results do not depend on batch size or on how slots are sharded over GPUs.
         Parity mode: pass ``tb_bits`` (n_slots, TBS) -- a list of two such tensors for a two-codeword PDSCH -- and
-        ``noise`` (standard-normal complex pairs, shape of the noisy signal) to reproduce a host NumPy PCG64 stream."""
+        ``noise`` (standard-normal complex pairs, shape of the noisy signal) to reproduce a host NumPy PCG64 stream; ``precoder``
+        (n_slots, Nt, Nl) complex: the wideband precoding matrices to use instead of the device SVD (pdsch.py:1125-1131 leaves each
+        singular vector's phase to LAPACK: replaying a reference run slot for slot takes its precoders as data)."""
         dev = self.dev
         if not (details is False or details is True or details is None or (isinstance(details, str) and details == "verdicts")):
             raise ValueError('details must be False, True or "verdicts"')
@@ -335,7 +337,8 @@ class PdschLink:
                 tbs_sel = [t[sel] for t in tb_bits]
             else:
                 tbs_sel = tb_bits[sel]
-            d = self._run_group(slots[sel], snr_db, seed, tbs_sel, None if noise is None else noise[sel], counters, details)
+            d = self._run_group(slots[sel], snr_db, seed, tbs_sel, None if noise is None else noise[sel], counters, details,
+                                precoder=None if precoder is None else precoder[sel])
             if details:
                 det.append((sel, d))
         return (counters, det) if details else counters
@@ -367,7 +370,7 @@ class PdschLink:
             dec.index_copy_(0, idx, part)
         return dec
 
-    def _channel_chain(self, slots, n, slots_dev):
+    def _channel_chain(self, slots, n, slots_dev, precoder=None):
         """Path gains, timing offset, channel matrix (where the link needs it), precoder(s) and -- time-domain link with a
         wideband precoder -- the gains with the precoder folded in, of the slots of one batch."""
         times = self.gain_times_dev(slots_dev)
@@ -386,7 +389,13 @@ class PdschLink:
             cir1, off = ops.cir(gains1, self.coeff, self.L)
         if need_h:
             H = ops.channel_matrix(cir1, off, self.L, self.K, self.nfft)
-        if self.prg:        # one SVD precoder per PRG: mean channel of the group -> right singular vectors
+        if precoder is not None:
+            if self.prg:
+                raise ValueError("precoder=: one wideband matrix per slot (this link precodes per PRG)")
+            F = torch.as_tensor(precoder).to(device=self.dev, dtype=torch.complex128).contiguous()
+            if tuple(F.shape) != (n, self.nt, self.nl):
+                raise ValueError(f"precoder must be (n_slots, Nt={self.nt}, Nl={self.nl}), got {tuple(F.shape)}")
+        elif self.prg:        # one SVD precoder per PRG: mean channel of the group -> right singular vectors
             hm = ops.group_mean(H, self.prg_k0, self.prg_nk)                    # (n, G, Nr, Nt)
             G = hm.shape[1]
             F = ops.svd_precoder(hm.reshape(n * G, 1, self.nr, self.nt), self.nl).reshape(n, G, self.nt, self.nl)
@@ -400,7 +409,7 @@ class PdschLink:
         gfold = None if (self.freqDomain or self.prg or self._sep_prec) else ops.fold_precoder(gains1, F)
         return gains1, off, H, F, gfold
 
-    def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details, harq=None):
+    def _run_group(self, slots, snr_db, seed, tb_bits, noise, counters, details, harq=None, precoder=None):
         """One batch of slots with identical geometry.  ``harq`` = one (rv, circ, reset) per codeword: per-slot redundancy
         versions (int32 device tensor), the resident soft buffers and the restart flags of a batched HARQ round."""
         dev, cfg = self.dev, self.cfg
@@ -419,7 +428,7 @@ class PdschLink:
         # the channel filter's gains the modulator does not wait for it either.  Running it on a second stream beside the Tx
         # chain was tried: its one-workgroup-per-slot kernels and the bit-chain kernels then share the CUs and each takes as
         # much longer as the overlap saves -- 36.04 against 36.04 ms per step -- so it stays on the one stream.)
-        ch = self._channel_chain(slots, n, slots_dev)
+        ch = self._channel_chain(slots, n, slots_dev, precoder=precoder)
 
         # ---- Tx
         grid = None if self.numCW == 1 else self.templates.index_select(0, sif)   # DMRS-filled (n, Nl, L, K)

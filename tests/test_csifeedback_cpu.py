@@ -65,3 +65,26 @@ def test_report_validation_and_unsupported_corners():
     # the restriction bitmaps prune the enumeration
     pruned = ma.CsiReport(cc, n1=4, n2=1, cbSubsetRestriction='0' * 8 + '1' * 24)
     assert all(i1[0] >= 8 for i1, _ in pruned.type1SpIndexes(1)) and len(list(pruned.type1SpIndexes(1))) == 8 * 4
+
+
+def test_multi_panel_codebooks_fail_in_the_reference_itself():
+    """Type-I multi-panel (csifeedback.py:566-577, 1040-1327): tests/golden/csifeedback_multipanel.json records what the REFERENCE's
+    getCodebook does for every Ng-N1-N2 combination of TS 38.214 Table 5.2.2.2.2-1 x codebook mode x 1..4 layers (tools/gen_golden.py
+    csifeedback_multipanel): mode 1 and every one-layer case raise, mode 2 with more layers returns arrays that are not
+    (ports x layers) -- no configuration yields a usable codebook.  neoradium_amd therefore raises NotImplementedError for the
+    codebook type (the constructor validates like the reference) instead of restating code that cannot be pinned."""
+    d = json.load(open(os.path.join(GOLD, 'csifeedback_multipanel.json')))
+    rows = d['rows']
+    assert len(rows) == 52 and {(r['ng'], r['n1'], r['n2']) for r in rows} == {(2, 2, 1), (2, 4, 1), (4, 2, 1), (2, 2, 2), (2, 8, 1), (4, 4, 1), (2, 4, 2), (4, 2, 2)}
+    assert not any(r.get('is_ports_by_layers') for r in rows)
+    raises = [r for r in rows if r['outcome'] == 'raises']
+    assert all(r['file'] == 'csifeedback.py' and 1040 <= r['line'] <= 1327 for r in raises)
+    assert all(r['outcome'] == 'raises' for r in rows if r['mode'] == 1 or r['layers'] == 1)
+    assert all(r['outcome'] == 'returns' and r['shape'][1:] != [r['ports'], r['layers']] for r in rows if r['mode'] == 2 and r['layers'] >= 2)
+    car = ma.Carrier(numRbs=24, spacing=15)
+    for r in rows[::7]:
+        ports = r['ports']
+        cc = ma.CsiRsConfig(csiType='NZP', bwp=car.curBwp, numPorts=ports, cdmSize=(2 if ports <= 12 else (4 if ports <= 16 else 8)))
+        rep = ma.CsiReport(cc, codebookType='Type1MP', ng=r['ng'], n1=r['n1'], n2=r['n2'], codebookMode=r['mode'])
+        with pytest.raises(NotImplementedError):
+            rep.getCodebook(r['layers'])

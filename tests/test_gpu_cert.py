@@ -64,6 +64,35 @@ def test_a_broken_certificate_is_caught(dev):
         assert int(diff.sum()) > 0, in_kernel
 
 
+def test_conditions_alone_on_blocks_whose_crc_passes(dev):
+    """flags = 1 (no sign / posterior / magnitude conditions (S), (Q)) and flags = 2 (no closure condition (M)) ALONE, with the CRC
+    filter on, at the iteration-8 check.  Every block the full certificate takes is taken without a condition as well; the closure
+    condition on its own REFUSES blocks whose CRC passes at 8 (it is what keeps a just-converged block running: strictly more blocks
+    stop without it), while (S) / (Q) refuse none of these CRC-passing blocks that (M) would let through -- their work is on blocks the
+    CRC filter has already removed (test_a_broken_certificate_is_caught, flags 7).  Both forms; the complete certificate's bits equal the
+    fixed schedule's on every block."""
+    fixed = _metric_link()
+    pay = fixed.cfg.cb_len - 24
+    _, d0 = fixed.run(50, 24, 31.0, seed=2, details="verdicts")
+    ok8 = None
+    for in_kernel in (True, False):
+        taken = {}
+        for flags in (0, 1, 2, 3):
+            link = _metric_link(certifiedExit=(8,), certFlags=flags, certInKernel=in_kernel)
+            _, d1 = link.run(50, 24, 31.0, seed=2, details="verdicts")
+            taken[flags] = (link.last_exit_iter == 8).cpu().numpy()
+            if flags == 0:
+                assert (d0[0][1]['tb_out'].reshape(-1, pay) == d1[0][1]['tb_out'].reshape(-1, pay)).all()
+        assert taken[0].sum() > 0
+        for flags in (1, 2, 3):
+            assert (taken[flags] | ~taken[0]).all(), (in_kernel, flags)                   # nothing certified is lost
+        assert taken[2].sum() > taken[0].sum(), (in_kernel, int(taken[2].sum()), int(taken[0].sum()))      # (M) binds on CRC-passing blocks
+        assert (taken[3] | ~taken[2]).all() and (taken[3] | ~taken[1]).all()
+        # with no condition left the certified set is the set of blocks whose CRC passes at iteration 8: the same for both forms
+        ok8 = taken[3] if ok8 is None else ok8
+        assert np.array_equal(taken[3], ok8)
+
+
 @pytest.mark.parametrize("tbs,qm,nl,e_bits", [(25000, 6, 4, 13000), (25000, 2, 1, 12300), (33000, 4, 2, 13000)])
 def test_fillers_zeros_saturation_and_both_instantiations(dev, tbs, qm, nl, e_bits):
     """Synthetic LLRs straight into the entries: F > 0 (the filler positions' posteriors sit at 1e10), exact zeros, one clean / one

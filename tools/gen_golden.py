@@ -13,6 +13,9 @@ Outputs (all data: inputs + the reference's outputs, nothing of its source):
   tests/golden/chest.npz         DMRS LS estimates (linear / polar subcarrier interpolation) + noise estimates
   tests/golden/prg.npz           per-PRG precoders (group lists + matrices) and the precoded grid
   tests/golden/polar.npz         polar DCI/PBCH/UCI chains: bits, LLRs, SCL candidate lists and path costs
+  tests/golden/csifeedback_multipanel.json  what the reference's Type-I multi-panel codebooks do (raise / wrong shapes)
+  tests/golden/snr.npz           SnrCalculations.ipynb noise-level anchors, useRxPower=False noise, seed-chain anchors
+  tests/golden/bler_notebook.npz PDSCH-BLER.ipynb table (Perfect CSI): per-block CRC verdicts at 5.8 / 5.6 / 5.4 dB, per-slot LAPACK precoders
   tests/golden/e2e_*.npz         whole PDSCH slots (inputs: seed-derived bits/noise; outputs: LLRs, bits, CRC)
 """
 import os
@@ -446,6 +449,40 @@ def csifeedback():
     np.savez_compressed(os.path.join(GOLD, 'csifeedback.npz'), **out)
 
 
+def csifeedback_multipanel():
+    """Type-I MULTI-panel codebooks (csifeedback.py:566-577, 1040-1327) in the reference itself, every Ng-N1-N2 combination of TS 38.214
+    Table 5.2.2.2.2-1 x codebook mode x 1..4 layers: what getCodebook does.  In v0.4.0 none of them yields a (ports x layers) codebook:
+    mode 1 and every one-layer case raise, mode 2 with >= 2 layers returns arrays of another shape.  The fixture records, per
+    configuration, the exception (type, start of the message, line of csifeedback.py) or the shape returned -- data that shows why
+    neoradium_amd raises NotImplementedError there instead of restating it."""
+    import json
+    import traceback
+    car = nr.Carrier(numRbs=24, spacing=15)
+    rows = []
+    for (ng, n1, n2) in ((2, 2, 1), (2, 4, 1), (4, 2, 1), (2, 2, 2), (2, 8, 1), (4, 4, 1), (2, 4, 2), (4, 2, 2)):
+        ports = 2 * ng * n1 * n2
+        for mode in (1, 2):
+            if ng == 4 and mode == 2:
+                continue                                      # (TS 38.214 5.2.2.2.2: mode 2 is not defined for Ng = 4; the constructor refuses it)
+            for nl in (1, 2, 3, 4):
+                cc = nr.CsiRsConfig(csiType='NZP', bwp=car.curBwp, numPorts=ports, cdmSize=(2 if ports <= 12 else (4 if ports <= 16 else 8)))
+                rep = nr.CsiReport(cc, codebookType='Type1MP', ng=ng, n1=n1, n2=n2, codebookMode=mode)
+                row = dict(ng=ng, n1=n1, n2=n2, ports=ports, mode=mode, layers=nl)
+                try:
+                    idx, cb = rep.getCodebook(nl)
+                    row.update(outcome='returns', shape=list(np.asarray(cb).shape), entries=len(idx),
+                               is_ports_by_layers=bool(np.asarray(cb).ndim == 3 and np.asarray(cb).shape[1:] == (ports, nl)))
+                except Exception as e:
+                    tb = traceback.extract_tb(e.__traceback__)[-1]
+                    row.update(outcome='raises', exception=type(e).__name__, message=str(e)[:60], line=int(tb.lineno),
+                               file=os.path.basename(tb.filename))
+                rows.append(row)
+    usable = [r for r in rows if r.get('is_ports_by_layers')]
+    print(len(rows), 'multi-panel configurations,', len(usable), 'yield a ports x layers codebook')
+    json.dump(dict(reference='InterDigitalInc/NeoRadium v0.4.0 csifeedback.py getCodebook(codebookType="Type1MP")', rows=rows),
+              open(os.path.join(GOLD, 'csifeedback_multipanel.json'), 'w'), indent=1)
+
+
 def ofdm_options():
     """The non-default kwargs of Grid.ofdmModulate / Waveform.ofdmDemodulate: two slots in one call, carrier up-conversion
     (f0 > 0), an FFT window that starts 30 % / 80 % into the CP.  Input grid from the seed; outputs stored."""
@@ -782,6 +819,116 @@ def polar():
     np.savez_compressed(os.path.join(GOLD, 'polar.npz'), **out)
 
 
+def snr_anchors():
+    """Playground/Others/SnrCalculations.ipynb cells 1-3 (52 PRB @30 kHz, 16QAM, 1 layer, seed 123, 0 dB): the published
+    Waveform.getNoiseStd / Grid.getNoiseStd values, the seed-chain anchors of SURVEY 8c (bits sha, rate-matched sum, DMRS sha), and
+    addNoise(snrDb=..., useRxPower=False) -- the MATLAB convention of waveform.py:142 / grid.py:1046 -- on the grid and the waveform."""
+    import hashlib
+    from neoradium.utils import toLinear
+    snr = toLinear(0)
+    carrier = nr.Carrier(numRbs=52, spacing=30)
+    bwp = carrier.curBwp
+    n_r, n_t = 2, 2
+    pdsch = nr.PDSCH(bwp, interleavingBundleSize=0, numLayers=1, modulation='16QAM', nID=carrier.cellId)
+    pdsch.setDMRS(prgSize=0, configType=2, additionalPos=2)
+    enc = nr.LdpcEncoder(baseGraphNo=1, modulation=pdsch.modems[0].modulation, txLayers=pdsch.numLayers, targetRate=490 / 1024)
+    nr.random.setSeed(123)
+    grid = pdsch.getGrid()
+    tbs = pdsch.getTxBlockSize(490 / 1024)
+    tb = nr.random.bits(tbs[0])
+    nb = pdsch.getBitSizes(grid)
+    rm = enc.getRateMatchedCodeBlocks(tb, nb[0])
+    dmrs_vals = grid.grid[grid.reTypeIds == grid.retNameToId["DMRS"]]
+    pdsch.populateGrid(grid, rm)
+    precoder = np.ones((n_t, pdsch.numLayers)) / np.sqrt(pdsch.numLayers)
+    tx = grid.precode(precoder).ofdmModulate()
+    rxw = nr.Waveform(tx.waveform / np.sqrt(n_r))
+    rxg = rxw.ofdmDemodulate(bwp)
+    std_t, std_f = rxw.getNoiseStd(snr, bwp), rxg.getNoiseStd(snr)
+    print('getNoiseStd time / freq', repr(std_t), repr(std_f))
+    # useRxPower=False on both containers (the generator continues from where the transport block left it)
+    ng = rxg.addNoise(snrDb=3.0, useRxPower=False)
+    nw = rxw.addNoise(snrDb=3.0, bwp=bwp, useRxPower=False)
+    nw2 = rxw.addNoise(snrDb=3.0, nFFT=bwp.nFFT)              # (default useRxPower, FFT size given directly)
+    np.savez_compressed(os.path.join(GOLD, 'snr.npz'), tbs=np.int64(tbs), G=np.int64(nb), tb_sha=np.array(hashlib.sha256(np.uint8(tb).tobytes()).hexdigest()[:16]),
+                        rm_sum=np.int64(rm.sum()), dmrs_sha=np.array(hashlib.sha256(np.complex128(dmrs_vals).tobytes()).hexdigest()[:16]),
+                        dmrs_sample=np.complex128(dmrs_vals[:64]), noise_std_time=np.float64(std_t), noise_std_freq=np.float64(std_f),
+                        grid_noise_var=np.float64(ng.noiseVar), grid_noisy_sample=ng.grid[:, ::3, ::41],
+                        wave_noise_var=np.float64(nw.noiseVar), wave_noisy_sample=nw.waveform[:, ::257],
+                        wave2_noise_var=np.float64(nw2.noiseVar), wave2_noisy_sample=nw2.waveform[:, ::257])
+    print('tb sha', hashlib.sha256(np.uint8(tb).tobytes()).hexdigest()[:16], 'rm sum', int(rm.sum()), 'dmrs sha',
+          hashlib.sha256(np.complex128(dmrs_vals).tobytes()).hexdigest()[:16], 'noiseVar', ng.noiseVar, nw.noiseVar)
+
+
+def bler_notebook(snrs=(5.8, 5.6, 5.4), num_slots=200):
+    """Playground/PDSCH/PDSCH-BLER.ipynb code cell 2, "Perfect" channel estimation (51 PRB @30 kHz, 16QAM, 2 layers, CDL-C 300 ns 16x4,
+    BG1 R = 490/1024, 20 iterations, frequency domain, seed 123 per SNR point): the reference itself, slot by slot.  Stored per SNR
+    point: the CRC verdicts of every code block and the bit errors of every slot (published totals: 5.8 dB 2 / 800 blocks,
+    5.6 dB 124 / 800, 5.4 dB 544 / 800); once (the channel, the transport blocks and the standard-normal draws are the same at every
+    point): the LAPACK precoder of every slot -- LAPACK fixes a singular vector only up to a unit phase, so the precoder is DATA for
+    whoever replays the table."""
+    import time
+    carrier = nr.Carrier(numRbs=51, spacing=30)
+    bwp = carrier.curBwp
+    pdsch = nr.PDSCH(bwp, interleavingBundleSize=0, numLayers=2, nID=carrier.cellId, modulation="16QAM")
+    pdsch.setDMRS(prgSize=0, configType=2, additionalPos=2)
+    rate = 490 / 1024
+    enc = nr.LdpcEncoder(baseGraphNo=1, modulation=pdsch.modems[0].modulation, txLayers=pdsch.numLayers, targetRate=rate)
+    dec = enc.getDecoder()
+    out = dict(snrs=np.float64(snrs), num_slots=np.int64(num_slots))
+    F_all = None
+    for snr in snrs:
+        nr.random.setSeed(123)
+        t0 = time.time()
+        carrier.slotNo = 0
+        ch = nr.CdlChannel(bwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                           txAntenna=nr.AntennaPanel([2, 4], polarization="x"), rxAntenna=nr.AntennaPanel([1, 2], polarization="x"))
+        crcs, biterrs, Fs, nvs = [], [], [], []
+        for s in range(num_slots):
+            grid = pdsch.getGrid()
+            tbs = pdsch.getTxBlockSize(rate)
+            tb = nr.random.bits(tbs[0])
+            nb = pdsch.getBitSizes(grid)
+            rm = enc.getRateMatchedCodeBlocks(tb, nb[0])
+            if s == 0 and F_all is None:       # the seed-chain anchors of SURVEY 8c (bits(30216) sha, rate-matched sum, DMRS sha)
+                import hashlib
+                dm = grid.grid[grid.reTypeIds == grid.retNameToId["DMRS"]]
+                out['tb_sha'] = np.array(hashlib.sha256(np.uint8(tb).tobytes()).hexdigest()[:16])
+                out['rm_sum'], out['G'] = np.int64(rm.sum()), np.int64(nb)
+                out['dmrs_sha'] = np.array(hashlib.sha256(np.complex128(dm).tobytes()).hexdigest()[:16])
+                out['dmrs_sample'] = np.complex128(dm[:64])
+                print('anchors: tb sha', out['tb_sha'], 'rm sum', int(rm.sum()), 'G', nb, 'dmrs sha', out['dmrs_sha'],
+                      '| int8 tb sha', hashlib.sha256(np.int8(tb).tobytes()).hexdigest()[:16],
+                      '| pilots sha', hashlib.sha256(np.complex128(pdsch.dmrs.getPilots()[0] if hasattr(pdsch.dmrs, 'getPilots') else dm).tobytes()).hexdigest()[:16], flush=True)
+            pdsch.populateGrid(grid, rm)
+            idx = pdsch.getReIndexes(grid, "PDSCH")
+            H = ch.getChannelMatrix()
+            F = pdsch.getPrecodingMatrix(H)
+            rx = grid.precode(F).applyChannel(H).addNoise(snrDb=snr, useRxPower=True)
+            eq, sc = rx.equalize(H @ F[None, ...])
+            llr = pdsch.getLLRsFromGrid(eq, idx, sc)
+            db = dec.decode(dec.recoverRate(llr[0], tbs[0]), numIter=20)
+            o, crc = dec.checkCrcAndMerge(db)
+            crcs.append(np.asarray(crc, bool))
+            biterrs.append(int(np.abs(o[:-24] - tb).sum()))
+            Fs.append(F)
+            nvs.append(rx.noiseVar)
+            ch.goNext()
+        crcs = np.stack(crcs)
+        print(f'{snr} dB: block errors {int((~crcs).sum())} / {crcs.size}, bit errors {sum(biterrs)}, {time.time() - t0:.1f} s', flush=True)
+        key = ('%.1f' % snr).replace('.', '_')
+        out['crc_' + key] = crcs
+        out['biterr_' + key] = np.int64(biterrs)
+        out['noise_var_' + key] = np.float64(nvs)
+        if F_all is None:
+            F_all = np.stack(Fs)
+            out['F'] = F_all
+            out['tbs'] = np.int64(tbs)
+        else:
+            assert np.array_equal(F_all, np.stack(Fs))
+    np.savez_compressed(os.path.join(GOLD, 'bler_notebook.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 1:                                 # regenerate selected fixture files only
@@ -796,11 +943,14 @@ if __name__ == '__main__':
     ptrs()
     csirs()
     csifeedback()
+    csifeedback_multipanel()
     ofdm_options()
     channels()
     channels_xiao()
     snr_walks()
     harq_loop()
+    snr_anchors()
+    bler_notebook()
     polar()
     chest()
     prg()
