@@ -1036,7 +1036,7 @@ constexpr int CS_THREADS = 512;
 constexpr int CS_NK = 12;      // subcarriers (one PRB)
 typedef const cd __attribute__((address_space(4))) * cgain_t;      // read-only in this kernel: wave-uniform rows come by scalar loads
 #ifdef NRX_CS_PROBE
-// developer build (tools/probe_chan_setup.py): s_memtime at the phase boundaries of wave 0 of every workgroup, summed:
+// developer build (tools/archive/probe_chan_setup.py): s_memtime at the phase boundaries of wave 0 of every workgroup, summed:
 // [0] tap matrix to LDS, [1] offset pass, [2] argmax, [3] twiddles, [4] matrix pass, [5] workgroups
 __device__ unsigned long long g_cs_probe[6];
 extern "C" int32_t nrx_debug_cs_probe(unsigned long long* out6, int32_t reset) {

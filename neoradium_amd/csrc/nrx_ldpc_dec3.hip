@@ -171,7 +171,7 @@ __device__ __forceinline__ void sel_fma_first(double& x, uint32_t& idx, uint64_t
 }
 
 #ifdef NRX_DEC3_PROBE
-// Developer build only (tools/probe_dec3.sh): s_memtime stamps at the phase boundaries of every layer, accumulated per
+// Developer build only (tools/archive/probe_dec3.sh): s_memtime stamps at the phase boundaries of every layer, accumulated per
 // wave in SGPRs and summed here.  [0..3] wide layers (degree > 10), [4..7] narrow layers: pass 1 (LDS reads + t = r - m),
 // min-sum, pass 2 (+ write drain + next layer's mask loads), barrier; [8] waves, [9] layers stamped.
 __device__ unsigned long long g_probe[14];   // [10] fill (+ its barrier), [11] tail (hard decisions / CRC + merge, + its barrier), [12] code-block rounds
@@ -204,6 +204,33 @@ __device__ unsigned long long g_probe[14];   // [10] fill (+ its barrier), [11] 
 #else
 #define LAYER_PRIO(Q) do {} while (0)
 #endif
+
+// ---- Barrier of ONE code block's six waves (round 5).  A workgroup holds two code blocks (slots) that share nothing, yet s_barrier
+// makes each wait for the other 11 times per iteration -- and a 384-thread workgroup per code block is not an option (a CU never
+// co-schedules two of them at this register count, profiles/r4_occ_test.txt).  So the layer barriers are done in software per slot:
+// every wave keeps a progress word in LDS (the padding in front of the columns); arriving = storing the barrier's number there (one
+// lane; the LDS executes a wave's instructions in order, so the word lands behind the layer's column writes and no drain is needed),
+// waiting = polling the slot's six words until none is behind.  The other slot's waves keep the SIMDs busy meanwhile.
+#ifndef NRX_DEC3_SLOTBAR
+#define NRX_DEC3_SLOTBAR 0
+#endif
+#ifndef NRX_DEC3_SLOT_SKEW
+#define NRX_DEC3_SLOT_SKEW 0                 // start of slot 1's iteration loop delayed by this many x 64 cycles
+#endif
+constexpr uint32_t SLOTBAR_BASE = 2048;      // byte offset inside the padding: [slot][8] words
+__device__ __forceinline__ void slot_barrier(uint32_t& k, uint32_t own_addr, uint32_t poll_addr) {
+  k += 1;
+  uint32_t kv = k, seen;
+  asm volatile("s_mov_b64 exec, 1\n\t"
+               "ds_write_b32 %[own], %[kv]\n\t"
+               "s_mov_b64 exec, -1\n"
+               "L_slotbar_%=:\n\t"
+               "ds_read_b32 %[seen], %[poll]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "v_cmp_gt_u32_e32 vcc, %[ks], %[seen]\n\t"
+               "s_cbranch_vccnz L_slotbar_%=\n\t"
+               : [seen] "=&v"(seen) : [own] "v"(own_addr), [kv] "v"(kv), [poll] "v"(poll_addr), [ks] "s"(k) : "vcc", "memory");
+}
 
 template <int BG> constexpr bool ext_shifts_are_zero() {
   using B = G<BG>;
@@ -338,6 +365,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   static_assert(Y::plan_rot.ok, "barrier placement leaves a column hazard");
   constexpr int NEXT = Y::n_ext() > 0 ? Y::n_ext() : 1;
 
+  // slot barrier (see slot_barrier): byte addresses of this wave's progress word and of the word this lane polls (wave lane % 6 of the slot)
+  const uint32_t sb_own = SLOTBAR_BASE + 32u * (uint32_t)slot + 4u * (uint32_t)__builtin_amdgcn_readfirstlane(z >> 6);
+  const uint32_t sb_poll = SLOTBAR_BASE + 32u * (uint32_t)slot + 4u * (uint32_t)((z & 63) % (ZC / 64));
+  uint32_t bar_k = 0;
   double m1[B::ROWS], m2[B::ROWS];
   double rext[NEXT];                                       // posterior of each layer's extension column, element z
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
@@ -525,6 +556,12 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         }
       }
     }
+#if NRX_DEC3_SLOTBAR
+    if constexpr (NS == 2) {                               // this wave's progress word back to zero (the fill's barrier publishes it)
+      if ((z & 63) == 0) *(volatile uint32_t*)((char*)Praw + sb_own) = 0u;
+      bar_k = 0;
+    }
+#endif
     if constexpr (!(FUSED && (MODE & 2))) {
       c0 = 0.0;                                            // punctured column (ldpc.py:1536-1538)
       static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
@@ -562,6 +599,12 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     });
 
     PROBE_STAMP(8);
+#if NRX_DEC3_SLOTBAR && NRX_DEC3_SLOT_SKEW > 0
+    // the two slots run the same program from the same barrier and stay in phase: both sit in the bubble behind a layer barrier
+    // (progress-word read, then the next layer's LDS reads) at the same time.  Slot 1 starts late by a fraction of a layer, so that one
+    // slot's bubble falls into the other's arithmetic.
+    if constexpr (NS == 2) { if (slot == 1) __builtin_amdgcn_s_sleep(NRX_DEC3_SLOT_SKEW); }
+#endif
     for (int it = 0; it < n_iter; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -744,7 +787,14 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           });
           PROBE_STAMP(WIDE ? 2 : 6);
         }
-        if constexpr (Y::plan_rot.need[(L + 1) % B::ROWS]) __syncthreads();
+        if constexpr (Y::plan_rot.need[(L + 1) % B::ROWS]) {
+#if NRX_DEC3_SLOTBAR
+          if constexpr (NS == 2) slot_barrier(bar_k, sb_own, sb_poll);
+          else __syncthreads();
+#else
+          __syncthreads();
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);   // nothing migrates between layers (register pressure)
       });
     }

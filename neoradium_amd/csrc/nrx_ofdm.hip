@@ -17,10 +17,10 @@
 constexpr int FILL_U = 8;
 
 #ifndef NRX_OFDM_ABLATE
-#define NRX_OFDM_ABLATE 0     // developer timing ablations (tools/probe_ofdm.py): 1 = no FFT passes, 2 = no global loads in the fill
+#define NRX_OFDM_ABLATE 0     // developer timing ablations (tools/archive/probe_ofdm.py): 1 = no FFT passes, 2 = no global loads in the fill
 #endif
 #ifdef NRX_OFDM_PROBE
-// Developer build only (tools/probe_ofdm.py): s_memtime stamps at the phase boundaries of the symbol-parallel modulator [0..4]
+// Developer build only (tools/archive/probe_ofdm.py): s_memtime stamps at the phase boundaries of the symbol-parallel modulator [0..4]
 // and the demodulator [8..12], summed over waves; [5] / [13] = waves stamped.
 __device__ unsigned long long g_ofdm_probe[16];
 #define OFDM_STAMP(K)                                                              \

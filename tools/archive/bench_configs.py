@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""The other BASELINE.json configurations through the batched engine (parity-test cases in the contract; this tool
+only reports their throughput and error counters on the GPU):
+
+  cfg1  the reference's own CPU-runnable case as a batch: 25 PRB @15 kHz, QPSK, 1 layer, SISO TDL-A 30 ns, BG2 R = 0.3, 5 iterations,
+        batch 4096 slots
+  cfg2  PDSCH BLER sweep point: 106 PRB @30 kHz, 64-QAM, 2 layers, 2x2 MMSE, CDL-C 300 ns, BG1, batch 1024 slots
+  cfg3  273 PRB / 100 MHz, 256-QAM, 4 layers, 4x4 MMSE, CDL-D (LOS) 300 ns, BG1 R = 0.75 (TBS 950 984, 113 code blocks), once
+        with the DMRS-LS estimate (every block fails at any SNR -- in the reference too, tests/golden/e2e_cfg3_*) and once with
+        perfect CSI (frequency-domain channel)
+
+    python tools/archive/bench_configs.py [--steps 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+DECODER = "f64"
+
+
+def build(nr, which):
+    nr.random.setSeed(123)
+    if which == 'cfg1':
+        car = nr.Carrier(numRbs=25, spacing=15)
+        bwp = car.curBwp
+        p = nr.PDSCH(bwp, numLayers=1, nID=car.cellId, modulation='QPSK')
+        p.setDMRS(configType=1, additionalPos=1)
+        ch = nr.TdlChannel(bwp, 'A', delaySpread=30, dopplerShift=5, txAntennaCount=1, rxAntennaCount=1)
+        return nr.PdschLink(p, ch, 0.3, baseGraphNo=2, numIter=5, freqDomain=False, chanEst="LS", decoder=DECODER), 4096, 4.0
+    if which == 'cfg2':
+        car = nr.Carrier(numRbs=106, spacing=30)
+        bwp = car.curBwp
+        p = nr.PDSCH(bwp, numLayers=2, nID=car.cellId, modulation='64QAM')
+        p.setDMRS(configType=1, additionalPos=1)
+        ch = nr.CdlChannel(bwp, 'C', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                           txAntenna=nr.AntennaPanel([1, 1], polarization="x"),
+                           rxAntenna=nr.AntennaPanel([1, 1], polarization="x"))
+        return nr.PdschLink(p, ch, 666 / 1024, baseGraphNo=1, numIter=50, freqDomain=False, chanEst="LS", decoder=DECODER), 1024, 20.0
+    car = nr.Carrier(numRbs=273, spacing=30)
+    bwp = car.curBwp
+    p = nr.PDSCH(bwp, numLayers=4, nID=car.cellId, modulation='256QAM')
+    p.setDMRS(configType=1, additionalPos=1)
+    ch = nr.CdlChannel(bwp, 'D', delaySpread=300, carrierFreq=4e9, dopplerShift=5,
+                       txAntenna=nr.AntennaPanel([1, 2], polarization="x"),
+                       rxAntenna=nr.AntennaPanel([1, 2], polarization="x"))
+    if which == 'cfg3_perfect':
+        return nr.PdschLink(p, ch, 0.75, baseGraphNo=1, numIter=50, freqDomain=True, chanEst="Perfect", decoder=DECODER), 48, 58.0
+    return nr.PdschLink(p, ch, 0.75, baseGraphNo=1, numIter=50, freqDomain=False, chanEst="LS", decoder=DECODER), 48, 42.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--decoder', default='f64', choices=['f32', 'f64'])
+    a = ap.parse_args()
+    global DECODER
+    DECODER = a.decoder
+    import neoradium_amd as nr
+    for which in ('cfg1', 'cfg2', 'cfg3', 'cfg3_perfect'):
+        link, B, snr = build(nr, which)
+        link.run(0, B, snr, seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c = torch.zeros(4, dtype=torch.int64, device=link.dev)
+        for k in range(a.steps):
+            link.run((k + 1) * B, B, snr, seed=1, counters=c)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c = c.cpu().numpy()
+        print(json.dumps({"config": which, "decoder": DECODER, "tbs": link.tbs, "code_blocks": link.cfg.C, "Zc": link.cfg.Zc, "batch": B,
+                          "snr_db": snr, "slots_per_s": B * a.steps / dt, "ms_per_step": 1e3 * dt / a.steps,
+                          "block_errors": int(c[0]), "blocks": int(c[1]), "bit_errors": int(c[2]), "bits": int(c[3])}))
+
+
+if __name__ == '__main__':
+    main()
