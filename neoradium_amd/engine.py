@@ -672,7 +672,8 @@ class PdschLink:
             outs = {}
             for _, sel in geoms.items():
                 whole = len(sel) == n_proc
-                sel_t = torch.as_tensor(sel, dtype=torch.int64, device=dev)
+                # (a host -> device copy waits for the stream to drain, i.e. for the previous round's decoder: only where a sub-batch needs it)
+                sel_t = None if whole else torch.as_tensor(sel, dtype=torch.int64, device=dev)
                 hq, rows_of = [], []
                 for q, c in enumerate(self.cw):
                     C = c['cfg'].C
