@@ -100,3 +100,28 @@ def test_bench_two_ranks_on_one_gpu_with_the_real_engine(dev):
     c = c.cpu().numpy()
     got = out['bler']
     assert [got['block_errors'], got['blocks'], got['bit_errors'], got['bits']] == [int(v) for v in c]
+
+
+def test_bench_cfg5_two_ranks_shard_the_harq_processes(dev):
+    """`bench.py --config cfg5 --gpus 2` with the REAL engine: two ranks on the one GPU of a test box (gloo collectives), each simulating
+    its own HARQ processes (harq.py:626-631: independent streams), ONE all-reduce of the per-try counters -- the statistics of the timed
+    rounds equal those of one process running all the processes (the generator is keyed by the absolute slot)."""
+    import neoradium_amd as nr
+    import bench
+    K, W, B = 3, 1, 8
+    env = dict(os.environ, NRX_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'cfg5', '--gpus', '2', '--steps', str(K), '--warmup', str(W),
+                        '--batch', str(B)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == K and out['unit'] == 'transmissions/s' and out['config']['name'] == 'cfg5'
+    assert sum(out['harq']['txBlocks']) == 2 * B * K and out['value'] > 0 and 0 < out['roofline']['frac'] < 1
+    link = bench.build_link(nr, decoder="f64")
+    _, st = link.run_harq(2 * B, W, out['config']['snr_db'], seed=123)
+    before = [st[k].clone() for k in ('tx', 'rx')]
+    stats, st = link.run_harq(2 * B, K, out['config']['snr_db'], seed=123, state=st)
+    assert (st['tx'] - before[0]).cpu().tolist() == out['harq']['txBlocks'] and (st['rx'] - before[1]).cpu().tolist() == out['harq']['rxBlocks']
