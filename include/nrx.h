@@ -643,6 +643,23 @@ int32_t nrx_effective_channel_prg_f64(const void* H, const void* F, int64_t f_st
                                       int32_t L, int32_t K, int32_t n_rx, int32_t n_tx, int32_t n_layers, void* out,
                                       void* stream);
 
+/* Grid.equalize (grid.py:626-694) on the harness's PERFECT channel state (PDSCH-BLER.ipynb cell 2: channelMatrix @ precoder) without a
+ * channel matrix in memory (nrx_mmse_paths.hip).  getChannelMatrix (channelmodel.py:362-400) is linear in the path gains, so
+ *   Hest[c][k][r][l] = exp(+2 pi i k' chan_off / nfft) * sum_p gains[c][r][l][p] * S_p[k],   k' = (k - K/2) mod nfft
+ * with S_p = the nfft-point spectrum of row p of the coefficient matrix at the K centred bins -- a constant of the channel:
+ * nrx_td_path_spectra_bins_f64 (taps (n_paths,flen) at column tap_off[p]) -> spec (n_paths,K) complex128, once per link.
+ * nrx_mmse_equalize_paths_f64: rx (n_batch,n_rx,L,K); gains (n_batch,n_sets>=L,n_rx,n_layers,n_paths) = the path gains with the wideband
+ * precoder folded in (nrx_fold_precoder_f64), gain set l = symbol l; chan_off (n_batch) = chanOffset (channelmodel.py:345-346);
+ * sym_mask: bit l set = symbol l is equalised (the others' outputs stay untouched) -> eq, scale (n_batch,n_layers,L,K) like
+ * nrx_mmse_equalize_f64.  Same values as nrx_channel_matrix_f64 -> nrx_effective_channel_f64 -> nrx_mmse_equalize_f64 up to rounding.
+ * NRX_E_UNSUPPORTED unless n_rx in {1,2,4} and n_layers <= 4. */
+int32_t nrx_td_path_spectra_bins_f64(const double* taps, const int32_t* tap_off, int32_t n_paths, int32_t flen, int32_t K, int32_t nfft,
+                                     void* spec, void* stream);
+int32_t nrx_mmse_equalize_paths_f64(const void* rx, const void* gains, int32_t n_sets, const void* spec, const int32_t* chan_off,
+                                    const double* noise_var, int32_t nv_stride, int32_t n_rx, int32_t n_layers, int32_t n_paths,
+                                    int32_t L, int32_t K, int32_t nfft, uint32_t sym_mask, void* eq, void* scale, int32_t n_batch,
+                                    void* stream);
+
 /* nrx_chest_ls_f64 + nrx_mmse_equalize_f64 in one call without materialising the (L, K, Nr, P) estimate (at most two
  * DMRS time groups): hk_ws is caller-owned scratch of n_batch * (n_ds/l_cdm) * (K + n_k/k_cdm) * nr * P complex128 (the
  * estimates at the DMRS time groups, then the CDM-group means they are interpolated from); eq (n,P,L,K) complex128,

@@ -242,6 +242,13 @@ class PdschLink:
         self.td_spec = None
         if not freqDomain and waveform == "f64" and not bool(int(os.environ.get('NRX_TD_PATHS', '0'))):
             self.td_spec = ops.td_path_spectra(self.taps, self.tap_off)
+        # perfect CSI on the time-domain link with a wideband precoder: the equaliser forms Hest = channelMatrix @ precoder from the
+        # folded path gains and the paths' spectra at the K subcarriers (ops.mmse_equalize_paths): no channel matrix is computed at all.
+        # NRX_PERFECT_MATRIX=1 keeps the matrix route (getChannelMatrix -> H @ F -> equalize, what details=True always takes).
+        self.bin_spec = None
+        if not freqDomain and chanEst == "Perfect" and self.nr in (1, 2, 4) and self.nl <= 4 and \
+                not bool(int(os.environ.get('NRX_PERFECT_MATRIX', '0'))):
+            self.bin_spec = ops.td_path_spectra_bins(self.taps, self.tap_off, self.K, self.nfft)
         self.max_delay = tb_['max_delay']
         self.fs = bwp.sampleRate
         self.window = windowing
@@ -370,7 +377,7 @@ class PdschLink:
             dec.index_copy_(0, idx, part)
         return dec
 
-    def _channel_chain(self, slots, n, slots_dev, precoder=None):
+    def _channel_chain(self, slots, n, slots_dev, precoder=None, no_matrix=False):
         """Path gains, timing offset, channel matrix (where the link needs it), precoder(s) and -- time-domain link with a
         wideband precoder -- the gains with the precoder folded in, of the slots of one batch."""
         times = self.gain_times_dev(slots_dev)
@@ -381,7 +388,7 @@ class PdschLink:
             gains1 = ops.cdl_gains(D(np.stack([a for a, _ in per])), D(np.stack([v for _, v in per])), times,
                                    A_los=self.Alos, nu_los=self.nulos)
         H = hsub = None
-        need_h = self.freqDomain or self.chanEst == "Perfect" or self.prg
+        need_h = self.freqDomain or (self.chanEst == "Perfect" and not no_matrix) or self.prg
         fusedcs = None if need_h else ops.chan_setup(gains1, self.coeff, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
         if fusedcs is not None:     # time-domain link, estimated channel, wideband precoder: the CIR is needed for nothing else
             hsub, off = fusedcs
@@ -428,7 +435,9 @@ class PdschLink:
         # the channel filter's gains the modulator does not wait for it either.  Running it on a second stream beside the Tx
         # chain was tried: its one-workgroup-per-slot kernels and the bit-chain kernels then share the CUs and each takes as
         # much longer as the overlap saves -- 36.04 against 36.04 ms per step -- so it stays on the one stream.)
-        ch = self._channel_chain(slots, n, slots_dev, precoder=precoder)
+        # (perfect CSI without a channel matrix: see bin_spec; the precoder must be folded into the gains, details=True wants the matrix)
+        pp = self.bin_spec is not None and details is not True and not self.prg and not self._sep_prec
+        ch = self._channel_chain(slots, n, slots_dev, precoder=precoder, no_matrix=pp)
 
         # ---- Tx
         grid = None if self.numCW == 1 else self.templates.index_select(0, sif)   # DMRS-filled (n, Nl, L, K)
@@ -498,7 +507,12 @@ class PdschLink:
 
         # ---- Rx
         hest = None
-        if self.chanEst == "Perfect":
+        if self.chanEst == "Perfect" and pp:
+            got = ops.mmse_equalize_paths(rxg, gfold, self.bin_spec, off, nv, self.nfft, sym_mask=self.data_sym_mask)
+            if got is None:
+                raise RuntimeError("nrx_mmse_equalize_paths_f64 declined a configuration PdschLink selected it for")
+            eq, sc = got
+        elif self.chanEst == "Perfect":
             hest = ops.effective_channel_prg(H, F, self.prg_k2g) if self.prg else ops.effective_channel(H, F)
             eq, sc = ops.mmse_equalize(rxg, hest, nv)
         elif self.polarInt:

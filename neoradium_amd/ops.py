@@ -711,6 +711,49 @@ def mmse_equalize(rx, hf, noise_var):
     return eq, sc
 
 
+def td_path_spectra_bins(taps, tap_off, K, nfft):
+    """nrx_td_path_spectra_bins_f64: (P, flen) taps at columns tap_off -> (P, K) complex128, the nfft-point spectrum of every row of the
+    coefficient matrix at the K centred subcarriers (a constant of the channel: once per link; see mmse_equalize_paths)."""
+    if not (isinstance(taps, torch.Tensor) and taps.is_cuda):
+        raise ValueError("td_path_spectra_bins: taps must be a GPU tensor")
+    dev = _dev(taps)
+    taps = taps.to(torch.float64).contiguous()
+    P, flen = taps.shape
+    tap_off = _i32(tap_off, dev)
+    spec = torch.empty((P, int(K)), dtype=torch.complex128, device=dev)
+    check(lib().nrx_td_path_spectra_bins_f64(ptr(taps), ptr(tap_off), P, flen, int(K), int(nfft), ptr(spec), stream()))
+    return spec
+
+
+def mmse_equalize_paths(rx, gains, spec, chan_off, noise_var, nfft, sym_mask=None):
+    """Grid.equalize on the harness's perfect CSI (channelMatrix @ precoder) with no channel matrix in memory
+    (nrx_mmse_equalize_paths_f64): rx (n,Nr,L,K) complex128, gains (n,T>=L,Nr,Nl,P) = the path gains with the wideband precoder folded
+    in, spec from td_path_spectra_bins, chan_off (n,) int32 -> eq (n,Nl,L,K), llrScales (n,Nl,L,K); None where there is no
+    instantiation (the caller forms the matrix)."""
+    if rx.dtype != torch.complex128:
+        return None
+    rx = rx.contiguous()
+    gains = gains.to(torch.complex128).contiguous()
+    n, nr, L, K = rx.shape
+    if gains.shape[0] != n or gains.shape[1] < L or gains.shape[2] != nr or spec.shape != (gains.shape[4], K):
+        raise ValueError("mmse_equalize_paths: gains / path spectra do not match the received grid")
+    nl, P = gains.shape[3], gains.shape[4]
+    dev = _dev(rx)
+    chan_off = chan_off.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+    if chan_off.numel() != n:
+        raise ValueError("mmse_equalize_paths: one timing offset per item")
+    nv = torch.as_tensor(noise_var, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+    eq = torch.empty((n, nl, L, K), dtype=torch.complex128, device=dev)
+    sc = torch.empty((n, nl, L, K), dtype=torch.float64, device=dev)
+    mask = (1 << L) - 1 if sym_mask is None else int(sym_mask)
+    rc = lib().nrx_mmse_equalize_paths_f64(ptr(rx), ptr(gains), gains.shape[1], ptr(spec), ptr(chan_off), ptr(nv), 0 if nv.numel() == 1 else 1,
+                                           nr, nl, P, L, K, int(nfft), mask & 0xffffffff, ptr(eq), ptr(sc), n, stream())
+    if rc == -3:                 # NRX_E_UNSUPPORTED
+        return None
+    check(rc)
+    return eq, sc
+
+
 def noise_level(x, snr_lin=None, mult=1.0, nv_mult=1.0, gather=None):
     """Complex variance per batch item (np.var) and, with ``snr_lin``, sigma = sqrt(var*mult/snr), nv = sigma^2*nv_mult."""
     flat = x.reshape(x.shape[0], -1).contiguous()

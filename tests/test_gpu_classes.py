@@ -221,6 +221,12 @@ def test_engine_matches_class_surface(dev, freqDomain, chanEst, prg):
         ch.goNext()
     c = counters.cpu().numpy()
     assert c[0] == blk_err and c[1] == n_slots * link.cfg.C and c[3] == n_slots * link.tbs
+    # the throughput path of the same link (fused stages; perfect CSI on the time-domain link: the equaliser forms channelMatrix @
+    # precoder from the folded path gains, ops.mmse_equalize_paths, no channel matrix) ends on the same verdicts and bits
+    c2, dv = link.run(0, n_slots, snr, tb_bits=torch.from_numpy(tb), noise=D(zc), details="verdicts")
+    assert torch.equal(dv[0][1]['cb_ok'].reshape(-1), d['cb_ok'].reshape(-1)) and torch.equal(c2, counters)
+    if chanEst == "Perfect" and not freqDomain and not prg:
+        assert link.bin_spec is not None
 
 
 @pytest.mark.parametrize("name", ['cfg2_cdl_c_2x2', 'cfg3_cdl_d_4x4_ls', 'cfg3_cdl_d_4x4_perfect'])

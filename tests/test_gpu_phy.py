@@ -305,6 +305,42 @@ def test_tdl_chain(dev):
     assert rel(gs.cpu().numpy(), np.einsum('bcrtp,tl->bcrlp', ref_g, F[0])) < 1e-13
 
 
+@pytest.mark.parametrize("nr,nl,nfft,K", [(4, 4, 4096, 3276), (2, 2, 1024, 612), (4, 3, 512, 300), (1, 1, 256, 144)])
+def test_perfect_csi_equaliser_from_path_spectra(dev, nr, nl, nfft, K):
+    """nrx_mmse_equalize_paths_f64 (Hest = exp(2 pi i k' o / N) sum_p g_p S_p[k] formed per RE from the folded path gains, no channel
+    matrix in memory) against the matrix route nrx_cir -> nrx_channel_matrix (FFT of the CIR advanced by chanOffset,
+    channelmodel.py:362-400) -> nrx_mmse_equalize: equalised symbols and LLR scales; the path spectra against NumPy's FFT of the
+    coefficient matrix; a symbol mask leaves the other symbols' outputs alone."""
+    import torch
+    from neoradium_amd import ops
+    rng = np.random.default_rng(nr * 100 + nl * 10 + nfft)
+    n, N, L = 3, 9, 14
+    fs = 30.72e6 * nfft / 1024
+    g = crandn(rng, n, L + 1, nr, nl, N + 1)
+    delays = np.sort(rng.uniform(0, 2500, N + 1))
+    delays[0] = 0
+    coeff, _ = op.coeff_matrix(delays, fs, op.build_firs())
+    taps, offs = ops.path_taps(coeff)
+    spec = ops.td_path_spectra_bins(T(taps, dev), offs, K, nfft)
+    c = np.zeros((N + 1, nfft))
+    c[:, :coeff.shape[1]] = coeff
+    pick = np.append(np.arange(K // 2) + nfft - K // 2, np.arange(K // 2))
+    assert rel(spec.cpu().numpy(), np.fft.fft(c, axis=1)[:, pick]) < 1e-13
+    cir, off = ops.cir(T(g, dev), T(coeff, dev), L)
+    assert int(off.max()) > 0                                      # (the circular advance is exercised)
+    H = ops.channel_matrix(cir, off, L, K, nfft)                  # (n, L, K, nr, nl): the gains play the folded ones
+    rx = crandn(rng, n, nr, L, K)
+    nv = np.array([0.01, 0.2, 1e-12])
+    eq0, sc0 = ops.mmse_equalize(T(rx, dev), H, T(nv, dev))
+    eq1, sc1 = ops.mmse_equalize_paths(T(rx, dev), T(g, dev), spec, off, T(nv, dev), nfft)
+    assert rel(eq1.cpu().numpy(), eq0.cpu().numpy()) < 1e-10 and rel(sc1.cpu().numpy(), sc0.cpu().numpy()) < 1e-10
+    mask = 0b01010110011101
+    eq2, sc2 = ops.mmse_equalize_paths(T(rx, dev), T(g, dev), spec, off, T(nv, dev), nfft, sym_mask=mask)
+    keep = [l for l in range(L) if (mask >> l) & 1]
+    assert torch.equal(eq2[:, :, keep], eq1[:, :, keep]) and torch.equal(sc2[:, :, keep], sc1[:, :, keep])
+    assert ops.mmse_equalize_paths(T(crandn(rng, n, 3, L, K), dev), T(crandn(rng, n, L + 1, 3, nl, N + 1), dev), spec, off, T(nv, dev), nfft) is None
+
+
 @pytest.mark.parametrize("nx,max_delay_ns,nfft,mu", [(4, 900, 1024, 1), (4, 19000, 1024, 1), (2, 5000, 512, 2), (1, 300, 256, 3), (4, 2600, 4096, 1)])
 def test_overlap_save_filter_equals_the_path_form(dev, nx, max_delay_ns, nfft, mu):
     """nrx_apply_td_os_f64 (1024-point overlap-save, the Nr x Nt spectra of a gain set in registers) against the oracle's
