@@ -211,6 +211,9 @@ __device__ unsigned long long g_probe[14];   // [10] fill (+ its barrier), [11] 
 // every wave keeps a progress word in LDS (the padding in front of the columns); arriving = storing the barrier's number there (one
 // lane; the LDS executes a wave's instructions in order, so the word lands behind the layer's column writes and no drain is needed),
 // waiting = polling the slot's six words until none is behind.  The other slot's waves keep the SIMDs busy meanwhile.
+#ifndef NRX_DEC3_WSPEC
+#define NRX_DEC3_WSPEC 0      // one copy of the iteration loop per wave index (see iter_loop); default off: measured slower / no faster
+#endif
 #ifndef NRX_DEC3_SLOTBAR
 #define NRX_DEC3_SLOTBAR 0
 #endif
@@ -377,6 +380,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   double c0 = 0.0;                                         // element z of column 0 (Lay::sigma: every layer meets it in its own lane)
   double f1 = 0.0;                                         // column 1 handed from a layer to its successor (Lay::fwd1)
   static_assert(RC == RA || (!FUSED && MODE == 0 && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
+  constexpr bool WSPEC = NRX_DEC3_WSPEC != 0 && FUSED && MODE == 0 && RC == RA && RA <= 15 && NS == 2 && ZC == 384;
   constexpr bool HYB = RC < RA;
   constexpr int PF = NRX_DEC3_HYB_PF;                      // streamed layers fetched ahead
   static_assert(!HYB || (RA - RC > PF && (RA - RC) % PF == 0), "the ring slot of a streamed layer is (L - RC) mod PF in every iteration");
@@ -605,6 +609,11 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     // slot's bubble falls into the other's arithmetic.
     if constexpr (NS == 2) { if (slot == 1) __builtin_amdgcn_s_sleep(NRX_DEC3_SLOT_SKEW); }
 #endif
+    // WV = this wave's index inside its code block, or -1 (generic): with the wave known at compile time the wrap-around of an
+    // edge is wave-uniform for every wave but the one whose lanes straddle the column end (64 WV + lane + shift >= Zc), and the
+    // per-lane address select goes (NRX_DEC3_WSPEC: VERDICT r4 #4 -- six copies of the loop, one per wave; measured in DESIGN 4.1).
+    auto iter_loop = [&](auto wvc) __attribute__((always_inline)) {
+    constexpr int WV = decltype(wvc)::value;
     for (int it = 0; it < n_iter; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -654,7 +663,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               t[j] = f1;
             } else {
               constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
-              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
+              constexpr int sh = Y::eff_shift(ILS, ZC, L, E0 + j);
+              constexpr bool w_none = WV >= 0 && 64 * WV + 63 + sh < ZC, w_all = WV >= 0 && 64 * WV + sh >= ZC;
+              const bool wraps = (w_none || w_all) ? w_all : __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
               if constexpr (off < 65536) t[j] = *(const double*)((const char*)Praw + (wraps ? zbw : zb) + off);
               else t[j] = *(const double*)((const char*)Praw + (wraps ? zbwh : zbh) + (off - HI));
             }
@@ -744,7 +755,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               f1 = t[j];                                    // the next layer takes it from here and writes the column itself
             } else if constexpr (col < B::CORE) {
               constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
-              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
+              constexpr int sh = Y::eff_shift(ILS, ZC, L, E0 + j);
+              constexpr bool w_none = WV >= 0 && 64 * WV + 63 + sh < ZC, w_all = WV >= 0 && 64 * WV + sh >= ZC;
+              const bool wraps = (w_none || w_all) ? w_all : __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
               if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
               else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
             } else {
@@ -797,6 +810,19 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         }
         __builtin_amdgcn_sched_barrier(0);   // nothing migrates between layers (register pressure)
       });
+    }
+    };
+    if constexpr (WSPEC) {
+      switch (__builtin_amdgcn_readfirstlane(z >> 6)) {
+        case 0: iter_loop(std::integral_constant<int, 0>{}); break;
+        case 1: iter_loop(std::integral_constant<int, 1>{}); break;
+        case 2: iter_loop(std::integral_constant<int, 2>{}); break;
+        case 3: iter_loop(std::integral_constant<int, 3>{}); break;
+        case 4: iter_loop(std::integral_constant<int, 4>{}); break;
+        default: iter_loop(std::integral_constant<int, 5>{}); break;
+      }
+    } else {
+      iter_loop(std::integral_constant<int, -1>{});
     }
     __syncthreads();
     PROBE_STAMP(-1);
