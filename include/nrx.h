@@ -653,6 +653,13 @@ int32_t nrx_effective_channel_prg_f64(const void* H, const void* F, int64_t f_st
  * sym_mask: bit l set = symbol l is equalised (the others' outputs stay untouched) -> eq, scale (n_batch,n_layers,L,K) like
  * nrx_mmse_equalize_f64.  Same values as nrx_channel_matrix_f64 -> nrx_effective_channel_f64 -> nrx_mmse_equalize_f64 up to rounding.
  * NRX_E_UNSUPPORTED unless n_rx in {1,2,4} and n_layers <= 4. */
+/* nrx_chan_setup_f64 (chanOffset + the channel matrix at n_k subcarriers from k0 on, channelmodel.py:343-346, 362-400) with the sums over the
+ * cl taps taken out of the per-row work: the offset from G[r][p] = sum_{c,t} gains, the matrix from the paths' spectra (spec (n_paths,
+ * spec_stride >= K) of nrx_td_path_spectra_bins_f64): H (n_items,nc,n_k,n_rx,n_tx) = exp(2 pi i k' o / nfft) sum_p gains[c][rt][p] S_p[k].  Same
+ * values up to the order of the sums (~1e-16); any n_k, any path count. */
+int32_t nrx_chan_setup_paths_f64(const void* gains, const double* coeff, const void* spec, int64_t spec_stride, int32_t n_items, int32_t n_t,
+                                 int32_t nc, int32_t n_rx, int32_t n_tx, int32_t n_paths, int32_t cl, int32_t K, int32_t nfft, int32_t k0,
+                                 int32_t n_k, int32_t* chan_offset, void* H, void* stream);
 int32_t nrx_td_path_spectra_bins_f64(const double* taps, const int32_t* tap_off, int32_t n_paths, int32_t flen, int32_t K, int32_t nfft,
                                      void* spec, void* stream);
 int32_t nrx_mmse_equalize_paths_f64(const void* rx, const void* gains, int32_t n_sets, const void* spec, const int32_t* chan_off,

@@ -105,6 +105,7 @@ SIGNATURES.update({
                                          _i32p, vp]),
     'nrx_td_path_spectra_f64': (i32, [vp, vp, i32, i32, vp, vp]),
     'nrx_apply_td_os_f64': (i32, [vp, i32, i32, i64, vp, i32, i32, i32, vp, i32, _i32p, vp, i32, vp, i64, _i32p, vp]),
+    'nrx_chan_setup_paths_f64': (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'nrx_td_path_spectra_bins_f64': (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     'nrx_mmse_equalize_paths_f64': (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_uint32, vp, vp, i32, vp]),
     'nrx_noise_level_finish_f64': (i32, [vp, i32, i64, i32, vp, vp, i32, f64, vp, vp, f64, vp]),

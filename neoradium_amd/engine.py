@@ -249,6 +249,11 @@ class PdschLink:
         if not freqDomain and chanEst == "Perfect" and self.nr in (1, 2, 4) and self.nl <= 4 and \
                 not bool(int(os.environ.get('NRX_PERFECT_MATRIX', '0'))):
             self.bin_spec = ops.td_path_spectra_bins(self.taps, self.tap_off, self.K, self.nfft)
+        # chanOffset + the first-PRB channel matrix (for the wideband precoder) from the same spectra instead of a DFT over the CIR's
+        # taps (ops.chan_setup_paths); NRX_CHAN_SETUP_DFT=1 keeps nrx_chan_setup_f64 (bit-identical to cir + channel_matrix_sub)
+        self.setup_spec = None
+        if not freqDomain and self.nfft <= 8192 and not bool(int(os.environ.get('NRX_CHAN_SETUP_DFT', '0'))):
+            self.setup_spec = self.bin_spec if self.bin_spec is not None else ops.td_path_spectra_bins(self.taps, self.tap_off, self.K, self.nfft)
         self.max_delay = tb_['max_delay']
         self.fs = bwp.sampleRate
         self.window = windowing
@@ -389,7 +394,12 @@ class PdschLink:
                                    A_los=self.Alos, nu_los=self.nulos)
         H = hsub = None
         need_h = self.freqDomain or (self.chanEst == "Perfect" and not no_matrix) or self.prg
-        fusedcs = None if need_h else ops.chan_setup(gains1, self.coeff, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+        if need_h:
+            fusedcs = None
+        elif self.setup_spec is not None:
+            fusedcs = ops.chan_setup_paths(gains1, self.coeff, self.setup_spec, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
+        else:
+            fusedcs = ops.chan_setup(gains1, self.coeff, self.L, self.K, self.nfft, 12 * self.first_prb, 12)
         if fusedcs is not None:     # time-domain link, estimated channel, wideband precoder: the CIR is needed for nothing else
             hsub, off = fusedcs
         else:

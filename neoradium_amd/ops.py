@@ -946,6 +946,22 @@ def chan_setup(gains, coeff, nc, K, nfft, k0, n_k):
     return H, off
 
 
+def chan_setup_paths(gains, coeff, spec, nc, K, nfft, k0, n_k):
+    """chan_setup from the paths' spectra (nrx_chan_setup_paths_f64): gains (n,T,Nr,Nt,P), coeff (P,cl), spec (P,K) from
+    td_path_spectra_bins -> (H_sub (n, nc, n_k, Nr, Nt), off (n,) int32); the values of ``chan_setup`` up to the order of the sums."""
+    gains = gains.to(torch.complex128).contiguous()
+    n, T, nr, nt, P = gains.shape
+    dev = _dev(gains)
+    coeff = coeff.to(device=dev, dtype=torch.float64).contiguous()
+    if coeff.shape[0] != P or tuple(spec.shape) != (P, K) or not spec.is_contiguous():
+        raise ValueError("coefficient matrix / path spectra do not match the gains")
+    H = torch.empty((n, nc, n_k, nr, nt), dtype=torch.complex128, device=dev)
+    off = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib().nrx_chan_setup_paths_f64(ptr(gains), ptr(coeff), ptr(spec), K, n, T, nc, nr, nt, P, coeff.shape[1], K, nfft, k0, n_k, ptr(off),
+                                         ptr(H), stream()))
+    return H, off
+
+
 def channel_matrix(cir_t, off, nc, K, nfft):
     """ChannelModel.getChannelMatrix: cir (n,T,Nr,Nt,cl) -> H (n,nc,K,Nr,Nt)."""
     cir_t = cir_t.contiguous()

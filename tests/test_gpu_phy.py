@@ -477,3 +477,10 @@ def test_fused_channel_setup_equals_the_separate_entries(dev, profile, nr_, nt_,
     assert got is not None
     assert torch.equal(got[1], off) and torch.equal(got[0], want)
     assert ops.chan_setup(gains, link.coeff, link.L, link.K, link.nfft, 12 * first, 24) is None      # two PRBs: the separate entries
+    # ... and from the paths' spectra (nrx_chan_setup_paths_f64: the sums over the taps taken out of the per-row work): the same offsets, the
+    # same matrix up to the order of the sums
+    spec = ops.td_path_spectra_bins(link.taps, link.tap_off, link.K, link.nfft)
+    hp, op_ = ops.chan_setup_paths(gains, link.coeff, spec, link.L, link.K, link.nfft, 12 * first, 12)
+    assert torch.equal(op_, off) and rel(hp.cpu().numpy(), want.cpu().numpy()) < 1e-13
+    h24, o24 = ops.chan_setup_paths(gains, link.coeff, spec, link.L, link.K, link.nfft, 12 * first, 24)
+    assert torch.equal(o24, off) and rel(h24.cpu().numpy(), ops.channel_matrix_sub(cir1, off, link.L, link.K, link.nfft, 12 * first, 24).cpu().numpy()) < 1e-13
