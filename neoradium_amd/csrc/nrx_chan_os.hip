@@ -452,6 +452,7 @@ extern "C" int32_t nrx_apply_td_os_f64(const void* x, int32_t n_items, int32_t n
     *n_part = n_sets * waves;
   }
   if (n_items == 0) return NRX_OK;
+  NRX_REQUIRE(n_items <= 65535, NRX_E_SHAPE, "nrx_apply_td_os: %d items exceed the grid's 65535 (split the batch)", n_items);
   const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_apply_td_os: FFT twiddle table unavailable");
   const size_t lds = sizeof(cd) * ((size_t)n_rx * OS_ELEMS + OS_TWL);      // (the set's Nr x Nt x n_paths gains fit the transform buffers)

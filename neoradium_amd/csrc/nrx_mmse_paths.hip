@@ -247,6 +247,8 @@ extern "C" int32_t nrx_mmse_equalize_paths_f64(const void* rx, const void* gains
     return NRX_E_UNSUPPORTED;
   }
   if (n_batch == 0) return NRX_OK;
+  NRX_REQUIRE((int64_t)n_batch * L <= 65535, NRX_E_SHAPE, "nrx_mmse_equalize_paths: n_batch x L = %lld exceeds the grid's 65535 (split the batch)",
+              (long long)n_batch * L);
   const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_mmse_equalize_paths: FFT twiddle table unavailable");
   const dim3 grid((K + 127) / 128, (unsigned)(n_batch * L));
