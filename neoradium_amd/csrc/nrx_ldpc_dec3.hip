@@ -33,6 +33,20 @@
 #ifndef NRX_DEC3_HYB_PF
 #define NRX_DEC3_HYB_PF 2
 #endif
+// NRX_DEC3_NT=1 marks the streamed-once global traffic (the LLRs of the fill, the parked decoder state and its reload) non-temporal, so
+// that it does not push the certificate's slack scratch (nrx_ldpc_certcore.h) out of the XCD's L2.  Measured (tools/r5/nt_experiment.sh,
+// DESIGN.md 4.3): stage-1 traffic of the certified schedule 17.1 -> 16.1 GB, step 24.3 -> 24.5 ms -- the scratch of the workgroups of one
+// XCD (5.5 MB) does not fit its 4 MB L2 either way.  Default off.
+#ifndef NRX_DEC3_NT
+#define NRX_DEC3_NT 0
+#endif
+#if NRX_DEC3_NT
+#define NRX_LD_STREAM(p) __builtin_nontemporal_load(p)
+#define NRX_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define NRX_LD_STREAM(p) (*(p))
+#define NRX_ST_STREAM(p, v) (*(p) = (v))
+#endif
 namespace nrx_dec3 {
 using namespace nrx_ldpc;
 
@@ -483,31 +497,31 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       const double* st = fuse_args()->state + (size_t)cbq * SL::NF * ZC + zl;
       static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value + 1;
-        Ps[c * ZS + zl] = st[(size_t)(SL::COL + c - 1) * ZC];
+        Ps[c * ZS + zl] = NRX_LD_STREAM(&st[(size_t)(SL::COL + c - 1) * ZC]);
       });
-      c0 = st[(size_t)SL::C0 * ZC];
-      f1 = st[(size_t)SL::F1 * ZC];
+      c0 = NRX_LD_STREAM(&st[(size_t)SL::C0 * ZC]);
+      f1 = NRX_LD_STREAM(&st[(size_t)SL::F1 * ZC]);
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
-        m1[L] = st[(size_t)(SL::M1 + L) * ZC];
-        m2[L] = st[(size_t)(SL::M2 + L) * ZC];
-        if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC];
+        m1[L] = NRX_LD_STREAM(&st[(size_t)(SL::M1 + L) * ZC]);
+        m2[L] = NRX_LD_STREAM(&st[(size_t)(SL::M2 + L) * ZC]);
+        if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = NRX_LD_STREAM(&st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC]);
       });
       static_for<SL::NW>([&](auto i) __attribute__((always_inline)) {
-        sgw[decltype(i)::value] = (uint32_t)__double_as_longlong(st[(size_t)(SL::WORDS + decltype(i)::value) * ZC]);
+        sgw[decltype(i)::value] = (uint32_t)__double_as_longlong(NRX_LD_STREAM(&st[(size_t)(SL::WORDS + decltype(i)::value) * ZC]));
       });
       static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
-        sgn[decltype(i)::value] = (uint32_t)__double_as_longlong(st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC]);
+        sgn[decltype(i)::value] = (uint32_t)__double_as_longlong(NRX_LD_STREAM(&st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC]));
       });
     } else {
       double xs[B::CORE - 2 + NEXT];      // (the hybrid only touches the entries of its on-chip rows)
       static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        xs[c] = in[addr(c * ZC, 0)];
+        xs[c] = NRX_LD_STREAM(&in[addr(c * ZC, 0)]);
       });
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
-        if constexpr (Y::has_ext(L) && L < RC) xs[B::CORE - 2 + Y::ext_idx(L)] = in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))];   // element of row (z + sigma_L)
+        if constexpr (Y::has_ext(L) && L < RC) xs[B::CORE - 2 + Y::ext_idx(L)] = NRX_LD_STREAM(&in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))]);   // element of row (z + sigma_L)
       });
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (HYB) {       // streamed rows: zero minima, the extension LLR (or 0 beyond the rows that run) straight to the workspace
@@ -889,25 +903,25 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
           static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value + 1;
-            st[(size_t)(SL::COL + c - 1) * ZC] = Ps[c * ZS + zt];
+            NRX_ST_STREAM(&st[(size_t)(SL::COL + c - 1) * ZC], Ps[c * ZS + zt]);
           });
-          st[(size_t)SL::F1 * ZC] = f1;
+          NRX_ST_STREAM(&st[(size_t)SL::F1 * ZC], f1);
         };
         if (parks) {      // park the state for the continuation launch
           using SL = StateLay<BG, RA>;
           double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
-          st[(size_t)SL::C0 * ZC] = c0;
+          NRX_ST_STREAM(&st[(size_t)SL::C0 * ZC], c0);
           static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
             constexpr int L = decltype(lc)::value;
-            st[(size_t)(SL::M1 + L) * ZC] = m1[L];
-            st[(size_t)(SL::M2 + L) * ZC] = m2[L];
-            if constexpr (Y::has_ext(L)) st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC] = rext[Y::ext_idx(L)];
+            NRX_ST_STREAM(&st[(size_t)(SL::M1 + L) * ZC], m1[L]);
+            NRX_ST_STREAM(&st[(size_t)(SL::M2 + L) * ZC], m2[L]);
+            if constexpr (Y::has_ext(L)) NRX_ST_STREAM(&st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC], rext[Y::ext_idx(L)]);
           });
           static_for<SL::NW>([&](auto i) __attribute__((always_inline)) {
-            st[(size_t)(SL::WORDS + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgw[decltype(i)::value]);
+            NRX_ST_STREAM(&st[(size_t)(SL::WORDS + decltype(i)::value) * ZC], __longlong_as_double((long long)sgw[decltype(i)::value]));
           });
           static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
-            st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgn[decltype(i)::value]);
+            NRX_ST_STREAM(&st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC], __longlong_as_double((long long)sgn[decltype(i)::value]));
           });
           if (!cert_here) park_columns();
         }
