@@ -271,8 +271,10 @@ def decoder_isa(kernel_key):
     for name, k in d['kernels'].items():
         if kernel_key in name:
             c = k['by_class']
+            # NRX_DEC3_SKIPZ: a second copy of the iteration loop without the last layer (the waves whose last layer is all zero run it)
+            skip = [o for o in k.get('other_loops', []) if 0.85 * c.get('valu', 0) <= o['valu'] < c.get('valu', 0)]
             return dict(kernel_symbol=name, valu=c.get('valu', 0), all=k['loop_instructions'], vgpr=k['vgpr'], scratch_bytes=k['scratch_bytes'],
-                        by_class=c, source=src, library_sha256=sha)
+                        valu_without_last_layer=skip[0]['valu'] if skip else None, by_class=c, source=src, library_sha256=sha)
     return None
 
 
@@ -523,7 +525,16 @@ def main():
         rows_run = next(r for r in built if r >= rows)
         if f64 and rows > 15:
             rows_run = rows                                # (the workspace kernel takes the row count at run time)
-        edge_visits = B * cfg.C * link.numIter * BG1_ROW_START[rows_run] * cfg.Zc
+        # check rows of the LAST layer that run whose extension LLR was received (the others are exact no-ops, DESIGN 4.2a, and the waves
+        # that hold only such rows leave the layer out: NRX_DEC3_SKIPZ): E_r + F - (first position of that extension column), all code
+        # blocks alike at the bench's configurations
+        e_r = link.cw[0]['G'] // cfg.C if 'G' in link.cw[0] else None
+        last_fill = cfg.Zc
+        if e_r is not None and cfg.C > 0 and link.cw[0]['G'] % cfg.C == 0 and 4 < rows_run <= 46:
+            last_fill = 0 if rows < rows_run else max(0, min(cfg.Zc, e_r + cfg.F - (24 + rows_run - 5) * cfg.Zc))
+        deg_last = BG1_ROW_START[rows_run] - BG1_ROW_START[rows_run - 1]
+        # WORK = the edge-visits of the check rows that are not no-ops
+        edge_visits = B * cfg.C * link.numIter * (BG1_ROW_START[rows_run - 1] * cfg.Zc + deg_last * last_fill)
         ev_s = edge_visits / (dec_ms * 1e-3)
         # What bounds the decoder is VALU issue, not HBM: a SIMD issues one wave64 VALU instruction per 4 cycles
         # whatever the mix (tools/ubench/issue_probe.hip, profiles/r3_issue_probe.txt: sustained v_fma_f64 77.5 TFLOP/s = 4.0
@@ -549,11 +560,16 @@ def main():
         n_waves = B * cfg.C * (cfg.Zc // 64)                      # one wave = 64 check rows of one code block
         valu_issue = None
         if isa:
-            valu_instr = n_waves * isa['valu'] * link.numIter     # wave64 VALU instructions of a launch (iteration loop only)
+            wpb = cfg.Zc // 64
+            w_run = wpb if not isa.get('valu_without_last_layer') else -(-last_fill // 64)      # waves of a code block that run the last layer
+            valu_mean = (w_run * isa['valu'] + (wpb - w_run) * (isa.get('valu_without_last_layer') or isa['valu'])) / wpb
+            valu_instr = n_waves * valu_mean * link.numIter       # wave64 VALU instructions of a launch (iteration loop only)
             peak_rate = N_SIMD * CLOCK / CYC_PER_VALU             # the chip's VALU issue rate, wave64 instructions / s
             ach_rate = valu_instr / (dec_ms * 1e-3)
             valu_issue = {"achieved": ach_rate / 1e9, "peak": peak_rate / 1e9, "unit": "G wave64 VALU instructions/s", "frac": ach_rate / peak_rate,
                           "valu_instr_per_wave_iteration": isa['valu'], "all_instr_per_wave_iteration": isa['all'],
+                          "valu_instr_per_wave_iteration_without_last_layer": isa.get('valu_without_last_layer'),
+                          "waves_per_code_block_running_the_last_layer": w_run, "last_layer_rows_received": last_fill,
                           "valu_instr_per_wave_edge_visit": isa['valu'] / BG1_ROW_START[rows_run],
                           "vgpr": isa['vgpr'], "scratch_bytes": isa['scratch_bytes'], "kernel_symbol": isa['kernel_symbol'],
                           "isa_source": isa['source'], "library_sha256": isa['library_sha256'],

@@ -40,6 +40,16 @@
 #ifndef NRX_DEC3_NT
 #define NRX_DEC3_NT 0
 #endif
+// NRX_DEC3_SKIPZ=1 (default): a wave whose 64 check rows of the LAST layer all have an extension LLR of exactly 0 leaves that layer out --
+// each of those rows is the exact no-op of DESIGN 4.2a (min1 = 0 at the extension edge: +-0 to every other column), here per wave
+// instead of per layer.  The last transmitted extension column is the one that is partly filled: 72 of 384 rows of layer 14 at the
+// metric configuration, i.e. four of a code block's six waves skip 7 of the 157 edges.  Two copies of the iteration loop (with and
+// without the last layer's body, same barriers) behind a wave-uniform branch: a test per layer inside ONE loop turned the layer's
+// register updates into copies at the join (+112 VALU instructions per iteration).  Whole decodes only (MODE 0): a parked state keeps
+// the posteriors of the extension columns, from which the zero LLR cannot be read back.
+#ifndef NRX_DEC3_SKIPZ
+#define NRX_DEC3_SKIPZ 1
+#endif
 #if NRX_DEC3_NT
 #define NRX_LD_STREAM(p) __builtin_nontemporal_load(p)
 #define NRX_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
@@ -396,6 +406,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   static_assert(RC == RA || (!FUSED && MODE == 0 && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
   constexpr bool WSPEC = NRX_DEC3_WSPEC != 0 && FUSED && MODE == 0 && RC == RA && RA <= 15 && NS == 2 && ZC == 384;
   constexpr bool HYB = RC < RA;
+  constexpr int LAST = B::ROWS - 1;
+  constexpr bool SKIPZ = NRX_DEC3_SKIPZ != 0 && MODE == 0 && !HYB && Y::has_ext(LAST) && !Y::fwd1(LAST) && !Y::give1(LAST) && !Y::fwd1(0);
   constexpr int PF = NRX_DEC3_HYB_PF;                      // streamed layers fetched ahead
   static_assert(!HYB || (RA - RC > PF && (RA - RC) % PF == 0), "the ring slot of a streamed layer is (L - RC) mod PF in every iteration");
   double pf_m1[PF] = {}, pf_m2[PF] = {}, pf_rx[PF] = {};
@@ -425,6 +437,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     int one = 1;
     asm volatile("" : "+s"(one));                          // keeps the per-layer `if (live)` a real branch (see dec2)
     const bool live = cbi < n_cb && one != 0;
+    bool last_zero = false;                                 // SKIPZ: the last layer's extension LLRs are all zero in this wave
     const int cbl = live ? cbi : n_cb - 1;                  // (a wave without a code block loads an existing one)
     const int cbq = sel ? sel[cbl] : cbl;                   // the code block itself
     const int cb = cbq;
@@ -556,6 +569,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         if constexpr (Y::has_ext(L)) {
           rext[Y::ext_idx(L)] = value(xs[B::CORE - 2 + Y::ext_idx(L)], (Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L));
           if constexpr (!FUSED) rext[Y::ext_idx(L)] = L < rows_live ? rext[Y::ext_idx(L)] : 0.0;      // (wave-uniform)
+          if constexpr (SKIPZ && L == LAST) last_zero = __builtin_amdgcn_ballot_w64(rext[Y::ext_idx(L)] != 0.0) == 0;
           if constexpr (FUSED && (MODE & 4) != 0) {
             lmax_all = __builtin_fmax(lmax_all, __builtin_fabs(rext[Y::ext_idx(L)]));
             lmax_pe = __builtin_fmax(lmax_pe, __builtin_fabs(rext[Y::ext_idx(L)]));
@@ -626,8 +640,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     // WV = this wave's index inside its code block, or -1 (generic): with the wave known at compile time the wrap-around of an
     // edge is wave-uniform for every wave but the one whose lanes straddle the column end (64 WV + lane + shift >= Zc), and the
     // per-lane address select goes (NRX_DEC3_WSPEC: VERDICT r4 #4 -- six copies of the loop, one per wave; measured in DESIGN 4.1).
-    auto iter_loop = [&](auto wvc) __attribute__((always_inline)) {
+    // SL: the copy without the last layer's body (NRX_DEC3_SKIPZ)
+    auto iter_loop = [&](auto wvc, auto slc) __attribute__((always_inline)) {
     constexpr int WV = decltype(wvc)::value;
+    constexpr bool SL = decltype(slc)::value;
     for (int it = 0; it < n_iter; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -657,7 +673,15 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         }
         // byte addresses of element z of column 0 of this slot: plain, wrapped (- Zc), and both + HI
         const uint32_t zb = zbo, zbw = zbo - zc8, zbh = zbo + HI, zbwh = zbo - zc8 + HI;
-        if (__builtin_expect(live, 1)) {
+        if constexpr (SL && L == LAST) {
+          if (live) {      // the layer is left out; the next layer's masks are still wanted
+            constexpr int Ln = (L + 1) % B::ROWS;
+            constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
+            static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
+              wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
+            });
+          }
+        } else if (__builtin_expect(live, 1)) {
           double t[D];
 #ifdef NRX_DEC3_PROBE
           PROBE_STAMP((Y::wide((L + B::ROWS - 1) % B::ROWS) ? 3 : 7));   // barrier of the previous layer
@@ -828,15 +852,18 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     };
     if constexpr (WSPEC) {
       switch (__builtin_amdgcn_readfirstlane(z >> 6)) {
-        case 0: iter_loop(std::integral_constant<int, 0>{}); break;
-        case 1: iter_loop(std::integral_constant<int, 1>{}); break;
-        case 2: iter_loop(std::integral_constant<int, 2>{}); break;
-        case 3: iter_loop(std::integral_constant<int, 3>{}); break;
-        case 4: iter_loop(std::integral_constant<int, 4>{}); break;
-        default: iter_loop(std::integral_constant<int, 5>{}); break;
+        case 0: iter_loop(std::integral_constant<int, 0>{}, std::false_type{}); break;
+        case 1: iter_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
+        case 2: iter_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
+        case 3: iter_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
+        case 4: iter_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
+        default: iter_loop(std::integral_constant<int, 5>{}, std::false_type{}); break;
       }
+    } else if constexpr (SKIPZ) {
+      if (last_zero) iter_loop(std::integral_constant<int, -1>{}, std::true_type{});
+      else iter_loop(std::integral_constant<int, -1>{}, std::false_type{});
     } else {
-      iter_loop(std::integral_constant<int, -1>{});
+      iter_loop(std::integral_constant<int, -1>{}, std::false_type{});
     }
     __syncthreads();
     PROBE_STAMP(-1);

@@ -294,6 +294,30 @@ def test_punctured_rows_are_exact_no_ops(dev, bg, zc, n_tx_cols):
         ops.ldpc_decode(torch.from_numpy(llr).to(dev), cfg, 5, rows=rows, belief=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fill", [0, 1, 64, 72, 200, 383])
+def test_waves_leave_out_an_all_zero_last_layer(dev, fill):
+    """NRX_DEC3_SKIPZ (nrx_ldpc_dec3.hip): a wave whose 64 rows of the last layer all have a zero extension LLR runs the copy of the
+    iteration loop without that layer.  `fill` received LLRs in the last layer's extension column (metric configuration: 72 of 384):
+    none of the six waves, one, two ... all of them run the layer; hard bits against the oracle's float64 decoder (ldpc.py:1495-1581)
+    and against the run with every row."""
+    import torch
+    from neoradium_amd import ops, _lib
+    from oracle import coding as oc
+    zc, rows = 384, 15
+    cfg = _lib.LdpcCfg()
+    cfg.bg, cfg.Zc, cfg.iLS, cfg.K, cfg.N, cfg.F, cfg.C, cfg.B, cfg.cb_len = 1, zc, 1, 22 * zc, 66 * zc, 0, 1, 0, 0
+    rng = np.random.default_rng(900 + fill)
+    llr = 2 / 0.95 ** 2 + (2 / 0.95) * rng.standard_normal((6, cfg.N))
+    llr[:, 34 * zc + fill:] = 0.0                          # column 36 = the extension column of layer 14
+    llr[0, 34 * zc:] = 0.0                                 # (one block whose last layer is empty whatever `fill` says)
+    x = torch.from_numpy(llr).to(dev)
+    got = ops.ldpc_decode(x, cfg, 12, rows=rows)
+    assert torch.equal(got, ops.ldpc_decode(x, cfg, 12))
+    want = oc.decode(llr, 1, 1, zc, num_iter=12, rows=rows)
+    assert np.array_equal(np.asarray(want).astype(np.uint8), got.cpu().numpy())
+
+
 @pytest.mark.parametrize("tbs,qm,nl,g_extra", [(25000, 6, 4, 0), (25000, 6, 4, 7), (33000, 4, 2, 3), (16700, 8, 1, 0)])
 def test_fused_recover_decode_merge_equals_separate_stages(dev, tbs, qm, nl, g_extra):
     """nrx_ldpc_recover_decode_merge_f64 (initial fill = rate recovery gathering straight from the demapper LLRs, tail =

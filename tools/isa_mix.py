@@ -73,7 +73,7 @@ def main():
                 if op.startswith('s_cbranch') or op == 's_branch':
                     off = int(args.split()[0])
                     off -= 65536 if off >= 32768 else 0
-                    if off < 0 and op != 's_branch':
+                    if off < 0:      # (the iteration loop may be closed by an unconditional branch behind its exit test)
                         loops.append((at.get(a + 4 + 4 * off), i))
             loops = [lp for lp in loops if lp[0] is not None and lp[1] - lp[0] > 500]
             meta = re.search(re.escape(name) + r'.*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?\.vgpr_count:\s+(\d+)',
@@ -91,7 +91,14 @@ def main():
                 cls = collections.Counter()
                 for op, n in c.items():
                     cls[classify(op)] += n
-                report['kernels'][name] = {'scratch_bytes': int(meta.group(1)) if meta else None, 'sgpr': int(meta.group(2)) if meta else None,
+                # further loops of the same size class behind the first (a second copy of the iteration loop: NRX_DEC3_SKIPZ)
+                more, last_hi = [], hi
+                for lo2, hi2 in loops[1:]:
+                    if lo2 > last_hi and hi2 - lo2 > (hi - lo) // 2:
+                        b2 = ins[lo2:hi2 + 1]
+                        more.append({'loop_instructions': len(b2), 'valu': sum(1 for _, op, _ in b2 if classify(op) == 'valu')})
+                        last_hi = hi2
+                report['kernels'][name] = {'other_loops': more, 'scratch_bytes': int(meta.group(1)) if meta else None, 'sgpr': int(meta.group(2)) if meta else None,
                                            'vgpr': int(meta.group(3)) if meta else None, 'loop_instructions': len(body),
                                            'by_class': dict(cls), 'scratch_ops_in_loop': scr, 'by_opcode': dict(c.most_common())}
     if out_json:
