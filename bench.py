@@ -561,7 +561,12 @@ def main():
         valu_issue = None
         if isa:
             wpb = cfg.Zc // 64
-            w_run = wpb if not isa.get('valu_without_last_layer') else -(-last_fill // 64)      # waves of a code block that run the last layer
+            # waves of a code block that run the last layer: lane z holds check row (z + sigma) mod Zc of it, sigma = Zc - (shift of the layer's
+            # column-0 edge) -- 77 / 142 for layers 12 / 14 of BG1 at Zc 384 (ldpc.py:46-654, set 1) -- and the received rows are 0 .. last_fill-1
+            w_run = wpb
+            if isa.get('valu_without_last_layer') and cfg.Zc == 384 and rows_run in (13, 15):
+                sg = 384 - {13: 77, 15: 142}[rows_run]
+                w_run = len({z // 64 for z in range(384) if (z + sg) % 384 < last_fill})
             valu_mean = (w_run * isa['valu'] + (wpb - w_run) * (isa.get('valu_without_last_layer') or isa['valu'])) / wpb
             valu_instr = n_waves * valu_mean * link.numIter       # wave64 VALU instructions of a launch (iteration loop only)
             peak_rate = N_SIMD * CLOCK / CYC_PER_VALU             # the chip's VALU issue rate, wave64 instructions / s
@@ -580,6 +585,9 @@ def main():
                           "ideal_valu_instr_per_edge_visit": 7.0,
                           "ideal_instruction_frac": 7.0 / (isa['valu'] / BG1_ROW_START[rows_run]) * (ach_rate / peak_rate),
                           "ideal_achieved": 7.0 * ev_s / 64.0 / 1e9,
+                          # (rounds 3-4 counted every check row of the last layer, received or not: 157 edges x 384 rows)
+                          "ideal_instruction_frac_counting_the_no_op_rows_of_the_last_layer":
+                              7.0 * (B * cfg.C * link.numIter * BG1_ROW_START[rows_run] * cfg.Zc / (dec_ms * 1e-3)) / 64.0 / peak_rate,
                           "bound_edge_visits_per_s": peak_rate / (isa['valu'] / BG1_ROW_START[rows_run]) * 64}
         traffic = None
         try:                                              # HBM bytes per launch from the committed PMC passes
@@ -614,7 +622,9 @@ def main():
             # contain, 15.6 per edge-visit -- is the sub-field issue_slot_occupancy.)
             "roofline": ({"bound": "valu", "kernel": kname, "achieved": valu_issue["ideal_achieved"], "peak": valu_issue["peak"],
                           "unit": valu_issue["unit"], "frac": valu_issue["ideal_instruction_frac"],
-                          "issue_slot_occupancy": valu_issue["frac"]} if valu_issue else
+                          "issue_slot_occupancy": valu_issue["frac"],
+                          "frac_counting_the_no_op_rows_of_the_last_layer": valu_issue["ideal_instruction_frac_counting_the_no_op_rows_of_the_last_layer"]}
+                         if valu_issue else
                          {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0}),
             "env": {k: v for k, v in os.environ.items() if k.startswith('NRX_')},
             "library": library_identity(args.stub),

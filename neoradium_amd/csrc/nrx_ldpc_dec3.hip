@@ -42,8 +42,8 @@
 #endif
 // NRX_DEC3_SKIPZ=1 (default): a wave whose 64 check rows of the LAST layer all have an extension LLR of exactly 0 leaves that layer out --
 // each of those rows is the exact no-op of DESIGN 4.2a (min1 = 0 at the extension edge: +-0 to every other column), here per wave
-// instead of per layer.  The last transmitted extension column is the one that is partly filled: 72 of 384 rows of layer 14 at the
-// metric configuration, i.e. four of a code block's six waves skip 7 of the 157 edges.  Two copies of the iteration loop (with and
+// instead of per layer.  The last transmitted extension column is the one that is partly filled: 48 of 384 rows of layer 14 at the
+// metric configuration (E_r - 34 Zc, no fillers), all in one wave: five of a code block's six waves skip 7 of the 157 edges.  Two copies of the iteration loop (with and
 // without the last layer's body, same barriers) behind a wave-uniform branch: a test per layer inside ONE loop turned the layer's
 // register updates into copies at the join (+112 VALU instructions per iteration).  Whole decodes only (MODE 0): a parked state keeps
 // the posteriors of the extension columns, from which the zero LLR cannot be read back.

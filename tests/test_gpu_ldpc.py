@@ -295,10 +295,10 @@ def test_punctured_rows_are_exact_no_ops(dev, bg, zc, n_tx_cols):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fill", [0, 1, 64, 72, 200, 383])
+@pytest.mark.parametrize("fill", [0, 1, 48, 64, 72, 200, 383])
 def test_waves_leave_out_an_all_zero_last_layer(dev, fill):
     """NRX_DEC3_SKIPZ (nrx_ldpc_dec3.hip): a wave whose 64 rows of the last layer all have a zero extension LLR runs the copy of the
-    iteration loop without that layer.  `fill` received LLRs in the last layer's extension column (metric configuration: 72 of 384):
+    iteration loop without that layer.  `fill` received LLRs in the last layer's extension column (metric configuration: 48 of 384):
     none of the six waves, one, two ... all of them run the layer; hard bits against the oracle's float64 decoder (ldpc.py:1495-1581)
     and against the run with every row."""
     import torch
