@@ -1,11 +1,11 @@
-"""Round-5 tool (GPU box): "BLER match vs CPU ref" of the headline metric on a sample larger than bench.py's parity block.
+"""Round-5 evidence script (GPU box; lives under tests/ because it calls the oracle, which only tests may do): "BLER match vs CPU ref" of the headline metric on a sample larger than bench.py's parity block.
 
 The metric configuration (273 PRB, 64-QAM, 4 x 4, BG1) over CDL through the HIP chain and through oracle/ (the NumPy float64
 restatement of the reference) on IDENTICAL inputs -- transport blocks, noise draws and the precoder as data -- at several SNR points
 across the waterfall.  Per point: both block error rates, the number of code-block CRC verdicts and hard bits that differ, the decoder
 alone on the oracle's LLRs (must be bit-identical).  The oracle runs one single-threaded process per host core.
 
-    python tools/r5/bler_match.py [--snrs 29 31 33] [--slots 64] [--procs 16] [--out gpurun_out/r5/r5_bler_match.json]
+    python tests/bler_match.py [--snrs 29 31 33] [--slots 64] [--procs 16] [--out gpurun_out/r5/r5_bler_match.json]
 """
 import argparse
 import json
@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import neoradium_amd as nr                    # noqa: E402
 from neoradium_amd import ops                 # noqa: E402
 from neoradium_amd._dev import D              # noqa: E402
