@@ -403,9 +403,14 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   u32x2 uv = {0u, 0u};                                     // register pair of the +-1.0 / +-0.75 units: low word stays 0
   double c0 = 0.0;                                         // element z of column 0 (Lay::sigma: every layer meets it in its own lane)
   double f1 = 0.0;                                         // column 1 handed from a layer to its successor (Lay::fwd1)
-  static_assert(RC == RA || (!FUSED && MODE == 0 && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
+  static_assert(RC == RA || (!FUSED && (MODE == 0 || MODE == 8) && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
+  static_assert((MODE & 8) == 0 || RC < RA, "MODE bit 3 belongs to the hybrid");
   constexpr bool WSPEC = NRX_DEC3_WSPEC != 0 && FUSED && MODE == 0 && RC == RA && RA <= 15 && NS == 2 && ZC == 384;
   constexpr bool HYB = RC < RA;
+  // MODE bit 3 (hybrid): the layers beyond the caller's row count are left out instead of run as no-ops.  A separate instantiation: the
+  // test costs 1.5-3 % more VALU instructions per iteration (copies at the joins), which a launch that runs every row need not pay.
+  constexpr bool SKIPR = HYB && (MODE & 8) != 0;
+  auto skippable = [](int L) constexpr -> bool { return SKIPR && Y::has_ext(L) && !Y::fwd1(L) && !Y::give1(L); };
   constexpr int LAST = B::ROWS - 1;
   constexpr bool SKIPZ = NRX_DEC3_SKIPZ != 0 && MODE == 0 && !HYB && Y::has_ext(LAST) && !Y::fwd1(LAST) && !Y::give1(LAST) && !Y::fwd1(0);
   constexpr int PF = NRX_DEC3_HYB_PF;                      // streamed layers fetched ahead
@@ -667,10 +672,16 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           cm1 = pf_m1[k];
           cm2 = pf_m2[k];
           crx = pf_rx[k];
-          pf_m1[k] = *wsL(wsb, ws_off(Lp, 0), zo8);
-          pf_m2[k] = *wsL(wsb, ws_off(Lp, 1), zo8);
-          if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(wsb, ws_off(Lp, 2), zo8);
+          if (!skippable(Lp) || Lp < rows_live) {           // (kernel-uniform: a layer that is left out is not fetched either)
+            pf_m1[k] = *wsL(wsb, ws_off(Lp, 0), zo8);
+            pf_m2[k] = *wsL(wsb, ws_off(Lp, 1), zo8);
+            if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(wsb, ws_off(Lp, 2), zo8);
+          }
         }
+        // hybrid: a layer beyond the caller's row count has all-zero extension LLRs -- every row of it the exact no-op of DESIGN 4.2a --
+        // and is left out (kernel-uniform test; its barrier and the next layer's mask loads stay)
+        bool runs = live;
+        if constexpr (SKIPR) runs = live && (!skippable(L) || L < rows_live);
         // byte addresses of element z of column 0 of this slot: plain, wrapped (- Zc), and both + HI
         const uint32_t zb = zbo, zbw = zbo - zc8, zbh = zbo + HI, zbwh = zbo - zc8 + HI;
         if constexpr (SL && L == LAST) {
@@ -681,7 +692,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
             });
           }
-        } else if (__builtin_expect(live, 1)) {
+        } else if (__builtin_expect(runs, 1)) {
           double t[D];
 #ifdef NRX_DEC3_PROBE
           PROBE_STAMP((Y::wide((L + B::ROWS - 1) % B::ROWS) ? 3 : 7));   // barrier of the previous layer
@@ -837,6 +848,14 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
           });
           PROBE_STAMP(WIDE ? 2 : 6);
+        } else if constexpr (SKIPR) {
+          if (live) {      // the layer is left out; the next layer's masks are still wanted
+            constexpr int Ln = (L + 1) % B::ROWS;
+            constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
+            static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
+              wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
+            });
+          }
         }
         if constexpr (Y::plan_rot.need[(L + 1) % B::ROWS]) {
 #if NRX_DEC3_SLOTBAR
@@ -1057,11 +1076,18 @@ int32_t nrx_ldpc_decode_chip64_launch(const double* llr, int32_t n_cb, const nrx
     fa.ws = (double*)ws;
     fa.sel = sel;
     fa.n_sel = n_sel;
-    if (ra == 31)
+    // (fewer rows than the instantiation has: the copy that leaves the layers beyond n_rows out, MODE bit 3)
+    if (ra == 31 && n_rows == 31)
       hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 31, false, 2, 0, HYB_RC31>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard,
                          (mtab_t)wt, fa);
-    else
+    else if (ra == 31)
+      hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 31, false, 2, 8, HYB_RC31>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard,
+                         (mtab_t)wt, fa);
+    else if (n_rows == 46)
       hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 46, false, 2, 0, HYB_RC46>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard,
+                         (mtab_t)wt, fa);
+    else
+      hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, 46, false, 2, 8, HYB_RC46>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, hard,
                          (mtab_t)wt, fa);
     NRX_CHECK_LAUNCH("nrx_ldpc_decode_f64(hybrid)");
     return NRX_OK;

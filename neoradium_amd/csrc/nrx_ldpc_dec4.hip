@@ -155,6 +155,7 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
   using Y = Lay<BG, RA>;
   static_assert(Y::plan_rot.ok, "barrier placement leaves a column hazard");
   constexpr bool HYB = RC < RA;
+  auto skippable = [](int L) constexpr -> bool { return Y::has_ext(L) && !Y::fwd1(L) && !Y::give1(L); };
   constexpr int PF = 2;                                    // streamed layers fetched ahead
   static_assert(!HYB || (RC >= 4 && RA - RC > PF && (RA - RC) % PF == 0), "the ring slot of a streamed layer is (L - RC) mod PF in every iteration");
   extern __shared__ __attribute__((aligned(16))) double Praw[];     // [ZS padding][NS][CORE][ZS]
@@ -285,12 +286,18 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
           cm1 = pf_m1[k];
           cm2 = pf_m2[k];
           crx = pf_rx[k];
-          pf_m1[k] = *wsL(Lp, 0, zo8);
-          pf_m2[k] = *wsL(Lp, 1, zo8);
-          if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(Lp, 2, zo8);
+          if (!skippable(Lp) || Lp < rows_live) {           // (kernel-uniform: a layer that is left out is not fetched either)
+            pf_m1[k] = *wsL(Lp, 0, zo8);
+            pf_m2[k] = *wsL(Lp, 1, zo8);
+            if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(Lp, 2, zo8);
+          }
         }
+        // A layer beyond the caller's row count has all-zero extension LLRs: every one of its rows is the exact no-op of DESIGN 4.2a and
+        // the layer is left out (kernel-uniform test; its barrier and the next layer's table loads stay).  Not a layer that takes
+        // column 1 from, or leaves it to, a neighbour in a register: the hand-over is its job.
+        const bool runs = !skippable(L) || L < rows_live;
         if (__builtin_expect(live, 1)) {
-          if (lane_ok) {
+          if (lane_ok && runs) {
             // the wave's valid lanes.  (Read by an asm the compiler cannot see through: as ballot(true) it is a COPY of exec,
             //  which copy propagation hands to the blocks below as their operand -- "s_mov_b64 exec, exec" restores nothing.)
             uint64_t vm;
