@@ -404,13 +404,22 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   double c0 = 0.0;                                         // element z of column 0 (Lay::sigma: every layer meets it in its own lane)
   double f1 = 0.0;                                         // column 1 handed from a layer to its successor (Lay::fwd1)
   static_assert(RC == RA || (!FUSED && (MODE == 0 || MODE == 8) && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
-  static_assert((MODE & 8) == 0 || RC < RA, "MODE bit 3 belongs to the hybrid");
+  static_assert((MODE & 8) == 0 || MODE == 8, "MODE bit 3 goes with a whole decode");
   constexpr bool WSPEC = NRX_DEC3_WSPEC != 0 && FUSED && MODE == 0 && RC == RA && RA <= 15 && NS == 2 && ZC == 384;
   constexpr bool HYB = RC < RA;
-  // MODE bit 3 (hybrid): the layers beyond the caller's row count are left out instead of run as no-ops.  A separate instantiation: the
-  // test costs 1.5-3 % more VALU instructions per iteration (copies at the joins), which a launch that runs every row need not pay.
-  constexpr bool SKIPR = HYB && (MODE & 8) != 0;
-  auto skippable = [](int L) constexpr -> bool { return SKIPR && Y::has_ext(L) && !Y::fwd1(L) && !Y::give1(L); };
+  // MODE bit 3 (whole decodes: the hybrids and the fused entry): the layers beyond the caller's row count (FuseGeom::rows_live) are left
+  // out instead of run as no-ops.  A separate instantiation: the test costs 1.5-3 % more VALU instructions per iteration (copies at the
+  // joins), which a launch that runs every row need not pay.
+  constexpr bool SKIPR = (MODE & 8) != 0;
+  // layer L of a launch that needs the first n rows: a layer that takes column 1 from its predecessor's register (fwd1) runs as long as
+  // the predecessor does -- the pair is left out together, column 1 then simply stays in LDS; the last layer is kept when it hands
+  // column 1 to layer 0
+  auto runs_at = [](int L, int n) constexpr -> bool {
+    if (!SKIPR || !Y::has_ext(L)) return true;
+    if (Y::fwd1(L)) return L <= n;
+    if (Y::give1(L) && L == B::ROWS - 1) return true;
+    return L < n;
+  };
   constexpr int LAST = B::ROWS - 1;
   constexpr bool SKIPZ = NRX_DEC3_SKIPZ != 0 && MODE == 0 && !HYB && Y::has_ext(LAST) && !Y::fwd1(LAST) && !Y::give1(LAST) && !Y::fwd1(0);
   constexpr int PF = NRX_DEC3_HYB_PF;                      // streamed layers fetched ahead
@@ -449,7 +458,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     const double* in = FUSED ? llr : llr + (size_t)cbq * N;
     int fE = 0, foff = 0;                                  // FUSED: E_r and the offset of the block in the LLR stream
     int rows_live = B::ROWS;
-    if constexpr (!FUSED) rows_live = fuse_args()->g.rows_live;
+    if constexpr (!FUSED || SKIPR) rows_live = fuse_args()->g.rows_live;
     FuseGeom fg{};
     if constexpr (FUSED) {
       const fargs_t fa = fuse_args();
@@ -672,7 +681,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           cm1 = pf_m1[k];
           cm2 = pf_m2[k];
           crx = pf_rx[k];
-          if (!skippable(Lp) || Lp < rows_live) {           // (kernel-uniform: a layer that is left out is not fetched either)
+          if (runs_at(Lp, rows_live)) {                     // (kernel-uniform: a layer that is left out is not fetched either)
             pf_m1[k] = *wsL(wsb, ws_off(Lp, 0), zo8);
             pf_m2[k] = *wsL(wsb, ws_off(Lp, 1), zo8);
             if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(wsb, ws_off(Lp, 2), zo8);
@@ -681,7 +690,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         // hybrid: a layer beyond the caller's row count has all-zero extension LLRs -- every row of it the exact no-op of DESIGN 4.2a --
         // and is left out (kernel-uniform test; its barrier and the next layer's mask loads stay)
         bool runs = live;
-        if constexpr (SKIPR) runs = live && (!skippable(L) || L < rows_live);
+        if constexpr (SKIPR) runs = live && runs_at(L, rows_live);
         // byte addresses of element z of column 0 of this slot: plain, wrapped (- Zc), and both + HI
         const uint32_t zb = zbo, zbw = zbo - zc8, zbh = zbo + HI, zbwh = zbo - zc8 + HI;
         if constexpr (SL && L == LAST) {
@@ -1176,7 +1185,11 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   hipStream_t st = (hipStream_t)stream;
 #define NRX_FUSED_LAUNCH(RA_, MODE_) \
   hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, RA_, true, 2, MODE_>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa)
-  if (n_rows <= 13) {
+  // a whole decode that needs two or more rows fewer than its instantiation has: the copy that leaves them out (one row fewer: the waves
+  // see the all-zero last layer themselves, NRX_DEC3_SKIPZ)
+  fg.rows_live = n_rows;
+  if (mode == 0 && n_rows <= 11) NRX_FUSED_LAUNCH(13, 8);
+  else if (n_rows <= 13) {
     if (mode == 0) NRX_FUSED_LAUNCH(13, 0); else if (mode == 1) NRX_FUSED_LAUNCH(13, 1); else if (mode == 2) NRX_FUSED_LAUNCH(13, 2); else if (mode == 3) NRX_FUSED_LAUNCH(13, 3);
     else if (mode == 5) NRX_FUSED_LAUNCH(13, 5); else NRX_FUSED_LAUNCH(13, 7);
   } else {

@@ -155,7 +155,15 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
   using Y = Lay<BG, RA>;
   static_assert(Y::plan_rot.ok, "barrier placement leaves a column hazard");
   constexpr bool HYB = RC < RA;
-  auto skippable = [](int L) constexpr -> bool { return Y::has_ext(L) && !Y::fwd1(L) && !Y::give1(L); };
+  // layer L of a launch that needs the first n rows (as nrx_ldpc_dec3.hip's MODE bit 3): a layer that takes column 1 from its
+  // predecessor's register runs as long as the predecessor does (the pair is left out together: column 1 then stays in LDS); the last
+  // layer is kept when it hands column 1 to layer 0
+  auto runs_at = [](int L, int n) constexpr -> bool {
+    if (!Y::has_ext(L)) return true;
+    if (Y::fwd1(L)) return L <= n;
+    if (Y::give1(L) && L == B::ROWS - 1) return true;
+    return L < n;
+  };
   constexpr int PF = 2;                                    // streamed layers fetched ahead
   static_assert(!HYB || (RC >= 4 && RA - RC > PF && (RA - RC) % PF == 0), "the ring slot of a streamed layer is (L - RC) mod PF in every iteration");
   extern __shared__ __attribute__((aligned(16))) double Praw[];     // [ZS padding][NS][CORE][ZS]
@@ -286,16 +294,15 @@ ldpc_dec_chipz_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uint
           cm1 = pf_m1[k];
           cm2 = pf_m2[k];
           crx = pf_rx[k];
-          if (!skippable(Lp) || Lp < rows_live) {           // (kernel-uniform: a layer that is left out is not fetched either)
+          if (runs_at(Lp, rows_live)) {                     // (kernel-uniform: a layer that is left out is not fetched either)
             pf_m1[k] = *wsL(Lp, 0, zo8);
             pf_m2[k] = *wsL(Lp, 1, zo8);
             if constexpr (Y::has_ext(Lp)) pf_rx[k] = *wsL(Lp, 2, zo8);
           }
         }
         // A layer beyond the caller's row count has all-zero extension LLRs: every one of its rows is the exact no-op of DESIGN 4.2a and
-        // the layer is left out (kernel-uniform test; its barrier and the next layer's table loads stay).  Not a layer that takes
-        // column 1 from, or leaves it to, a neighbour in a register: the hand-over is its job.
-        const bool runs = !skippable(L) || L < rows_live;
+        // the layer is left out (kernel-uniform test; its barrier and the next layer's table loads stay).
+        const bool runs = runs_at(L, rows_live);
         if (__builtin_expect(live, 1)) {
           if (lane_ok && runs) {
             // the wave's valid lanes.  (Read by an asm the compiler cannot see through: as ballot(true) it is a COPY of exec,
