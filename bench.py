@@ -525,16 +525,16 @@ def main():
         rows_run = next(r for r in built if r >= rows)
         if f64 and rows > 15:
             rows_run = rows                                # (the workspace kernel takes the row count at run time)
-        # check rows of the LAST layer that run whose extension LLR was received (the others are exact no-ops, DESIGN 4.2a, and the waves
-        # that hold only such rows leave the layer out: NRX_DEC3_SKIPZ): E_r + F - (first position of that extension column), all code
-        # blocks alike at the bench's configurations
+        # WORK = the edge-visits of the check rows that are not no-ops: the rows the code rate needs, and of the last of them
+        # only the check rows whose extension LLR was received -- E_r + F - (first position of that extension column), all code blocks
+        # alike at the bench's configurations.  (The kernels leave the others out: whole layers beyond `rows` by a kernel-uniform test,
+        # MODE bit 3; the last layer per wave, NRX_DEC3_SKIPZ.)
         e_r = link.cw[0]['G'] // cfg.C if 'G' in link.cw[0] else None
-        last_fill = cfg.Zc
-        if e_r is not None and cfg.C > 0 and link.cw[0]['G'] % cfg.C == 0 and 4 < rows_run <= 46:
-            last_fill = 0 if rows < rows_run else max(0, min(cfg.Zc, e_r + cfg.F - (24 + rows_run - 5) * cfg.Zc))
-        deg_last = BG1_ROW_START[rows_run] - BG1_ROW_START[rows_run - 1]
-        # WORK = the edge-visits of the check rows that are not no-ops
-        edge_visits = B * cfg.C * link.numIter * (BG1_ROW_START[rows_run - 1] * cfg.Zc + deg_last * last_fill)
+        need_fill = cfg.Zc
+        if e_r is not None and cfg.C > 0 and link.cw[0]['G'] % cfg.C == 0 and 4 < rows <= 46:
+            need_fill = max(0, min(cfg.Zc, e_r + cfg.F - (24 + rows - 5) * cfg.Zc))
+        last_fill = need_fill if rows == rows_run else (0 if rows < rows_run else cfg.Zc)      # ... of the last layer of the instantiation
+        edge_visits = B * cfg.C * link.numIter * (BG1_ROW_START[rows - 1] * cfg.Zc + (BG1_ROW_START[rows] - BG1_ROW_START[rows - 1]) * need_fill)
         ev_s = edge_visits / (dec_ms * 1e-3)
         # What bounds the decoder is VALU issue, not HBM: a SIMD issues one wave64 VALU instruction per 4 cycles
         # whatever the mix (tools/ubench/issue_probe.hip, profiles/r3_issue_probe.txt: sustained v_fma_f64 77.5 TFLOP/s = 4.0
@@ -556,7 +556,11 @@ def main():
             key = f"chip64_kernelILi1ELi50ELi{rows_run}ELb1ELi2ELi0E" if on_chip else None      # <BG1, Zc 384, rows, FUSED, NS 2, MODE 0>
         else:
             key = f"fast_kernelILi1ELi50ELi2ELi{rows_run}E"
+        if on_chip and f64 and rows < rows_run - 1:
+            key = None            # (the copy that leaves the layers beyond `rows` out runs: its instruction count depends on `rows`; no occupancy figure)
         isa = decoder_isa(key) if (key and not args.stub) else None
+        peak_rate = 256 * 4 * CLOCK / 4.0                         # the chip's VALU issue rate, wave64 instructions / s
+        work_frac = 7.0 * ev_s / 64.0 / peak_rate                 # 7 irreducible VALU instructions per edge-visit
         n_waves = B * cfg.C * (cfg.Zc // 64)                      # one wave = 64 check rows of one code block
         valu_issue = None
         if isa:
@@ -583,7 +587,7 @@ def main():
                           # VALU instructions (subtract, three min/max, add, two LDS address selects), so the fraction of an
                           # IDEAL-instruction bound is 7 / (instructions per edge-visit) x the issue fraction
                           "ideal_valu_instr_per_edge_visit": 7.0,
-                          "ideal_instruction_frac": 7.0 / (isa['valu'] / BG1_ROW_START[rows_run]) * (ach_rate / peak_rate),
+                          "ideal_instruction_frac": work_frac,
                           "ideal_achieved": 7.0 * ev_s / 64.0 / 1e9,
                           # (rounds 3-4 counted every check row of the last layer, received or not: 157 edges x 384 rows)
                           "ideal_instruction_frac_counting_the_no_op_rows_of_the_last_layer":
@@ -620,7 +624,11 @@ def main():
             # WORK-based: achieved = the 7 irreducible VALU instructions of an edge-visit x edge-visits / 64 lanes / launch time against the
             # chip's VALU issue rate.  (The share of issue slots the kernel FILLS -- which counts every instruction its ISA happens to
             # contain, 15.6 per edge-visit -- is the sub-field issue_slot_occupancy.)
-            "roofline": ({"bound": "valu", "kernel": kname, "achieved": valu_issue["ideal_achieved"], "peak": valu_issue["peak"],
+            "roofline": ({"bound": "valu", "kernel": kname, "achieved": 7.0 * ev_s / 64.0 / 1e9, "peak": peak_rate / 1e9,
+                          "unit": "G wave64 VALU instructions/s", "frac": work_frac, "issue_slot_occupancy": None,
+                          "note": "the copy of the kernel that leaves the layers beyond the needed rows out: instruction count per iteration "
+                                  "depends on the row count, no occupancy figure"} if (on_chip and f64 and not valu_issue and not args.stub) else
+                         {"bound": "valu", "kernel": kname, "achieved": valu_issue["ideal_achieved"], "peak": valu_issue["peak"],
                           "unit": valu_issue["unit"], "frac": valu_issue["ideal_instruction_frac"],
                           "issue_slot_occupancy": valu_issue["frac"],
                           "frac_counting_the_no_op_rows_of_the_last_layer": valu_issue["ideal_instruction_frac_counting_the_no_op_rows_of_the_last_layer"]}
