@@ -50,6 +50,15 @@
 #ifndef NRX_DEC3_SKIPZ
 #define NRX_DEC3_SKIPZ 1
 #endif
+// NRX_DEC3_PREFETCH=1: the elements of the next layer that no layer since the previous barrier has written are read AHEAD of the barrier
+// in front of it (Lay::pre_edge; 56 of the 110 LDS reads of the 11 layers with a barrier in front), so that behind the barrier a wave
+// starts on them at once.  Built, bit-identical, and SLOWER (tools/r5/prefetch_experiment.sh: 32.0 against 31.1 ms per step): behind a
+// barrier the first data is back before the SIMD's three waves have issued their 3 x 18 selects + loads anyway, while a wave now waits
+// for its read-ahead loads in front of the barrier (the last wave's wait delays everyone), and the values live across the barrier cost
+// 12 scratch accesses per iteration instead of 4.  Default off.
+#ifndef NRX_DEC3_PREFETCH
+#define NRX_DEC3_PREFETCH 0
+#endif
 #if NRX_DEC3_NT
 #define NRX_LD_STREAM(p) __builtin_nontemporal_load(p)
 #define NRX_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
@@ -420,6 +429,8 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     if (Y::give1(L) && L == B::ROWS - 1) return true;
     return L < n;
   };
+  constexpr bool PREF = NRX_DEC3_PREFETCH != 0 && MODE == 0 && !HYB && !WSPEC && Y::max_pre() > 0;
+  constexpr int NPRE = PREF ? Y::max_pre() : 1;
   constexpr int LAST = B::ROWS - 1;
   constexpr bool SKIPZ = NRX_DEC3_SKIPZ != 0 && MODE == 0 && !HYB && Y::has_ext(LAST) && !Y::fwd1(LAST) && !Y::give1(LAST) && !Y::fwd1(0);
   constexpr int PF = NRX_DEC3_HYB_PF;                      // streamed layers fetched ahead
@@ -658,6 +669,32 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     auto iter_loop = [&](auto wvc, auto slc) __attribute__((always_inline)) {
     constexpr int WV = decltype(wvc)::value;
     constexpr bool SL = decltype(slc)::value;
+    // read-ahead values of the layer that comes next and the LDS byte address each came from (its write-back goes there)
+    double tp[NPRE];
+    uint32_t ap[NPRE];
+    // the read-ahead loads of layer Ln (its wrap masks are in wcur): issued at the end of the layer in front of it
+    auto read_ahead = [&](auto lnc, uint32_t zb, uint32_t zbw, uint32_t zbh, uint32_t zbwh) __attribute__((always_inline)) {
+      constexpr int Ln = decltype(lnc)::value;
+      constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
+      static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int e = B::row_start(Ln) + j;
+        if constexpr (Y::pre_edge(Ln, e)) {
+          constexpr int k = Y::pre_idx(Ln, e);
+          constexpr uint32_t off = 8u * (uint32_t)(B::col(e) * ZS + Y::eff_shift(ILS, ZC, Ln, e));
+          const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
+          if constexpr (off < 65536) { ap[k] = wraps ? zbw : zb; tp[k] = *(const double*)((const char*)Praw + ap[k] + off); }
+          else { ap[k] = wraps ? zbwh : zbh; tp[k] = *(const double*)((const char*)Praw + ap[k] + (off - HI)); }
+        }
+      });
+    };
+    if constexpr (PREF) {
+      if (live) {
+        uint32_t zq0 = zb0;
+        asm volatile("" : "+v"(zq0));
+        read_ahead(std::integral_constant<int, 0>{}, zq0, zq0 - zc8, zq0 + HI, zq0 - zc8 + HI);
+      }
+    }
     for (int it = 0; it < n_iter; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -700,6 +737,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
               wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
             });
+            if constexpr (PREF && Y::plan_rot.need[Ln]) read_ahead(std::integral_constant<int, Ln>{}, zb, zbw, zbh, zbwh);
           }
         } else if (__builtin_expect(runs, 1)) {
           double t[D];
@@ -710,6 +748,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // priority steps at about a quarter, a half and three quarters of the layer's VALU work (5 + 4 + 5 per edge)
           constexpr int PQ1 = (7 * D) / 10 < D - 1 ? (7 * D) / 10 : D - 1, PQ2 = D / 2 < 2 ? 2 : D / 2, PQ3 = (3 * D) / 10 < 1 ? 1 : (3 * D) / 10;
           LAYER_PRIO(Y::prio_q(L, 0));
+          uint32_t ad[DC > 0 ? DC : 1];      // LDS byte address (without the immediate) of each core edge's element
           // ---- pass 1a: issue every LDS read of the layer, first edge first (the order pass 1b consumes them in).  Column 0
           // is the lane's own register; a handed-over column 1 comes from the predecessor's register (Lay::sigma, Lay::fwd1).
           static_for<DC>([&](auto jc) __attribute__((always_inline)) {
@@ -719,13 +758,21 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               t[j] = c0;
             } else if constexpr (col == 1 && Y::fwd1(L)) {
               t[j] = f1;
+              if constexpr (PREF && !Y::give1(L)) {         // (this layer writes the column back to LDS: the address of its element)
+                constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
+                const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
+                ad[j] = off < 65536 ? (wraps ? zbw : zb) : (wraps ? zbwh : zbh);
+              }
+            } else if constexpr (PREF && Y::pre_edge(L, E0 + j)) {
+              t[j] = tp[Y::pre_idx(L, E0 + j)];             // read ahead of the barrier by the layer in front
+              ad[j] = ap[Y::pre_idx(L, E0 + j)];
             } else {
               constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
               constexpr int sh = Y::eff_shift(ILS, ZC, L, E0 + j);
               constexpr bool w_none = WV >= 0 && 64 * WV + 63 + sh < ZC, w_all = WV >= 0 && 64 * WV + sh >= ZC;
               const bool wraps = (w_none || w_all) ? w_all : __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
-              if constexpr (off < 65536) t[j] = *(const double*)((const char*)Praw + (wraps ? zbw : zb) + off);
-              else t[j] = *(const double*)((const char*)Praw + (wraps ? zbwh : zbh) + (off - HI));
+              if constexpr (off < 65536) { ad[j] = wraps ? zbw : zb; t[j] = *(const double*)((const char*)Praw + ad[j] + off); }
+              else { ad[j] = wraps ? zbwh : zbh; t[j] = *(const double*)((const char*)Praw + ad[j] + (off - HI)); }
             }
           });
           __builtin_amdgcn_sched_barrier(0);
@@ -748,14 +795,32 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // ---- pass 1b: t_j = r_j - msg_old_j = fma(-u_j, argmin ? pm2 : pm1, r_j)  (ldpc.py:1550-1553); the extension
           // column's r comes from its register
           if constexpr (EXT) t[D - 1] = L < RC ? rext[Y::ext_idx(L)] : crx;
-          uint32_t wrun = word << (top - (D - 1));           // sign of edge 0 at bit 31; doubled per edge
-          static_for<D>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            const double u = unit_of(uv, wrun);
-            if constexpr (j < D - 1) wrun = dbl(wrun);
-            if constexpr (j == PQ1 && Y::prio_q(L, 1) != Y::prio_q(L, 0)) LAYER_PRIO(Y::prio_q(L, 1));
-            t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
-          });
+          if constexpr (!PREF) {
+            uint32_t wrun = word << (top - (D - 1));           // sign of edge 0 at bit 31; doubled per edge
+            static_for<D>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = decltype(jc)::value;
+              const double u = unit_of(uv, wrun);
+              if constexpr (j < D - 1) wrun = dbl(wrun);
+              if constexpr (j == PQ1 && Y::prio_q(L, 1) != Y::prio_q(L, 0)) LAYER_PRIO(Y::prio_q(L, 1));
+              t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
+            });
+          } else {
+            // the edges whose value is in a register already first (column 0, a handed-over column 1, the extension column, the
+            // elements read ahead of the barrier), then the ones whose loads were issued behind it; the sign of edge j by its own shift
+            auto early = [](int j) constexpr -> bool {
+              const int col = B::col(E0 + j);
+              return col == 0 || (col == 1 && Y::fwd1(L)) || col >= B::CORE || Y::pre_edge(L, E0 + j);
+            };
+            static_for<2 * D>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = decltype(jc)::value % D;
+              constexpr bool first = decltype(jc)::value < D;
+              if constexpr (early(j) == first) {
+                const double u = unit_of(uv, word << (top - (D - 1) + j));
+                t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
+              }
+              if constexpr (!first && j == PQ1 && Y::prio_q(L, 1) != Y::prio_q(L, 0)) LAYER_PRIO(Y::prio_q(L, 1));
+            });
+          }
           PROBE_STAMP(WIDE ? 0 : 4);
           // ---- min-sum (ldpc.py:1556-1564): two smallest magnitudes by min/max; the signs of the t_j are collected (edge 0
           // ends highest) and their parity is a population count
@@ -801,6 +866,18 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             *wsL(wsb, ws_off(L, 1), zo8) = nm2;
           }
           PROBE_STAMP(WIDE ? 1 : 5);
+          if constexpr (PREF) {
+            // the masks of the next layer, here: every LDS read of this layer has been consumed (scalar loads return out of order, so
+            // with one of them in flight a wait for LDS data can only be a wait for everything), the write-back goes to the addresses
+            // kept in ad[], and pass 2 is long enough for them to arrive before the read-ahead at its end
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int Lm = (L + 1) % B::ROWS;
+            constexpr int DCm = Y::has_ext(Lm) ? Y::deg(Lm) - 1 : Y::deg(Lm);
+            static_for<DCm>([&](auto jc) __attribute__((always_inline)) {
+              wcur[decltype(jc)::value] = wml[B::row_start(Lm) + decltype(jc)::value];
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          }
           // ---- pass 2: r_j = t_j + msg_new_j = fma(u_j, first argmin ? pm2 : pm1, t_j), written back to the element it was
           // read from.  The FIRST entry equal to min1 gets min2 (np.argmin, ldpc.py:1558-1570).
           uint32_t idx = 0;
@@ -815,9 +892,14 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
               constexpr int sh = Y::eff_shift(ILS, ZC, L, E0 + j);
               constexpr bool w_none = WV >= 0 && 64 * WV + 63 + sh < ZC, w_all = WV >= 0 && 64 * WV + sh >= ZC;
-              const bool wraps = (w_none || w_all) ? w_all : __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
-              if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
-              else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
+              if constexpr (PREF) {      // (the address this element was read from)
+                if constexpr (off < 65536) *(double*)((char*)Praw + ad[j] + off) = t[j];
+                else *(double*)((char*)Praw + ad[j] + (off - HI)) = t[j];
+              } else {
+                const bool wraps = (w_none || w_all) ? w_all : __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
+                if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
+                else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
+              }
             } else {
               if constexpr (L < RC) rext[Y::ext_idx(L)] = t[j];
               else *wsL(wsb, ws_off(L, 2), zo8) = t[j];
@@ -852,10 +934,14 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // the masks of the next layer: their last use in this layer is behind us
           __builtin_amdgcn_sched_barrier(0);
           constexpr int Ln = (L + 1) % B::ROWS;
-          constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
-          static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
-            wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
-          });
+          if constexpr (!PREF) {
+            constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
+            static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
+              wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
+            });
+          } else if constexpr (Y::plan_rot.need[Ln]) {
+            read_ahead(std::integral_constant<int, Ln>{}, zb, zbw, zbh, zbwh);      // ahead of the barrier in front of the next layer
+          }
           PROBE_STAMP(WIDE ? 2 : 6);
         } else if constexpr (SKIPR) {
           if (live) {      // the layer is left out; the next layer's masks are still wanted
