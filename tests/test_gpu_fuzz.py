@@ -110,9 +110,70 @@ def test_random_link_against_the_oracle(dev, seed):
     run_case(seed)
 
 
+def run_fused_case(seed):
+    """The fused decoder entry (nrx_ldpc_recover_decode_merge_f64: BG1, Zc 384, <= 15 rows) at a random geometry -- bits per code block
+    anywhere between 4 and 15 rows' worth, unequal E_r, any Qm x layers -- against the oracle's rate recovery + decode + CRC (ldpc.py:1330-1619)
+    on noisy LLRs: covers the last-layer skip of the waves (NRX_DEC3_SKIPZ) and the copies that leave whole layers out (MODE bit 3)."""
+    import torch
+    from neoradium_amd import ops, _lib
+    from neoradium_amd._dev import D
+    from oracle import coding as oc
+    r = np.random.default_rng(77_000 + seed)
+    C = int(r.integers(2, 7))
+    cfg = None
+    for _ in range(50):
+        tbs = int(r.integers(8000 * C - 7000, 8424 * C - 24))
+        cfg = _lib.ldpc_config(1, tbs + 24)
+        if cfg.Zc == 384 and cfg.C == C:
+            break
+    assert cfg.Zc == 384 and cfg.C == C
+    qm, nl = int(r.choice([2, 4, 6, 8])), int(r.choice([1, 2, 3, 4]))
+    f = qm * nl
+    e_lo = cfg.K - 2 * 384 - cfg.F + 384            # at least one parity column
+    e = int(r.integers(e_lo, 13300)) // f * f
+    g_extra = int(r.integers(0, C))
+    G = C * e + g_extra * f
+    lens = _lib.ldpc_cb_lens(G, C, nl, qm)
+    rows = ops.ldpc_active_rows(cfg, max(lens))
+    if rows > 15 or not ops.ldpc_fused_supported(cfg, nl, qm, G, rows):
+        return dict(seed=seed, skipped=True, rows=rows)
+    n_tb, n_it = 2, int(r.integers(3, 10))
+    tb = torch.from_numpy(r.integers(0, 2, (n_tb, tbs)).astype(np.uint8)).to(torch.device('cuda:0'))
+    coded = ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg)
+    bits = ops.ldpc_rate_match(coded, cfg, G, nl, qm).cpu().numpy().astype(np.float64)
+    sig = r.uniform(0.45, 0.9, (n_tb, 1))
+    llr = (2 / sig ** 2) * ((1 - 2 * bits) + sig * r.standard_normal(bits.shape))
+    llr[r.random(llr.shape) < 0.001] = 0.0
+    xd = np.stack([deinterleave_per_code_block(x, C, G, nl, qm) for x in llr])
+    tb_out, ok = ops.ldpc_recover_decode_merge(D(xd), cfg, nl, qm, n_it, rows=rows)
+    pp = oc.LdpcParams(1, tbs + 24)
+    assert (pp.C, pp.Zc, pp.F) == (cfg.C, cfg.Zc, cfg.F)
+    for t in range(n_tb):
+        rr, _ = oc.rate_recover(llr[t], pp, nl, qm)
+        dec = oc.decode(rr, 1, pp.iLS, pp.Zc, n_it)
+        out, crc = oc.crc_check_and_merge(dec, pp)
+        assert np.array_equal(ok[t].cpu().numpy().astype(bool), crc), (seed, "CRC verdicts")
+        assert np.array_equal(tb_out[t].cpu().numpy()[:len(out)], out.astype(np.uint8)), (seed, "hard bits")
+    return dict(seed=seed, C=C, tbs=tbs, qm=qm, nl=nl, G=G, rows=rows, F=cfg.F, n_it=n_it, ok=int(ok.sum()), blocks=int(ok.numel()))
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_fused_entry_random_geometry_against_the_oracle(dev, seed):
+    run_fused_case(seed)
+
+
 if __name__ == '__main__':
     a, b = int(sys.argv[1]), int(sys.argv[2])
     bad = 0
+    if len(sys.argv) > 3 and sys.argv[3] == 'fused':
+        for sd in range(a, b):
+            try:
+                print(sd, "ok", run_fused_case(sd), flush=True)
+            except Exception as e:
+                bad += 1
+                print(sd, "FAIL", repr(e)[:400], flush=True)
+        print("failed:", bad, flush=True)
+        sys.exit(1 if bad else 0)
     for sd in range(a, b):
         try:
             i = run_case(sd)
@@ -123,3 +184,4 @@ if __name__ == '__main__':
             print(sd, "FAIL", draw(sd), repr(e)[:400], flush=True)
     print("failed:", bad, flush=True)
     sys.exit(1 if bad else 0)
+
