@@ -315,8 +315,9 @@ template <uint32_t K> __device__ __forceinline__ uint32_t gf2_mulc24(uint32_t a)
 // (ldpc.py:1584-1619) are done by the tail.  Geometry as nrx_ldpc_enc.hip's RmGeom.
 struct FuseGeom {
   int C, e_small, n_small, f, qm, sys_len, F, llr_len, cb_len, payload;
-  int rows_live;   // unfused entry: the caller's row count (<= RA of the instantiation that runs): the extension LLRs of the
-                   // rows beyond it are taken as zero, which makes those rows the no-ops the workspace kernel does not run at all
+  int rows_live;   // the row count the launch needs (<= RA of the instantiation that runs).  Unfused entry: the extension LLRs of the
+                   // rows beyond it are taken as zero, which makes those rows the no-ops the workspace kernel does not run at all;
+                   // MODE bit 3 (hybrids, fused whole decodes): the layers beyond it are left out
 };
 struct FuseArgs {
   FuseGeom g;
@@ -367,6 +368,8 @@ __device__ __forceinline__ fargs_t fuse_args() {
 // n1 + n2 iterations for them -- the continuation form of the multi-pass schedule: no pass repeats an earlier pass's iterations.
 // Bit 2 (with bit 0): EVERY block parks its state, whatever its CRC says, and a launch that fills from the LLRs also leaves the
 // block's two LLR maxima in fa.lam: the stages of the certified early exit (ldpc_certify_kernel reads the parked state).
+// Bit 3 (alone: a whole decode): the layers beyond FuseGeom::rows_live are left out (a kernel-uniform test per layer) instead of run as
+// no-ops -- the copies a launch takes when it needs fewer rows than its instantiation has.
 // RC = rows whose check-node state stays in registers (default: all RA of them).  RC < RA: the HYBRID for more rows than fit --
 // rates below ~0.6, HARQ retransmissions, all 46 rows: everything of this kernel (rotated rows, unit x pm under EXEC, DS
 // immediates, the barrier plan) applies to every row, and the rows >= RC, the sparse ones, keep pm1 / pm2 / extension posterior in
