@@ -19,7 +19,6 @@ import neoradium_amd as nr                    # noqa: E402
 from neoradium_amd import ops                 # noqa: E402
 import bench                                  # noqa: E402
 
-BG2_ROW_START = None
 
 
 def link_of(num_rbs, spacing, mod, layers, panel, rate, bg, num_iter, chan=('C', 300, 5)):
