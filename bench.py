@@ -112,9 +112,10 @@ class DecodeTimer:
 
     NAMES = ('ldpc_decode', 'ldpc_recover_decode_merge', 'ldpc_decode_selected')      # the separate decoder entry, the fused one, the work-list one (HARQ)
 
-    def __init__(self, ops, enabled=True):
-        self.ops, self.events, self.on, self.enabled = ops, [], False, enabled
-        self.orig = {n: getattr(ops, n) for n in self.NAMES}
+    def __init__(self, ops, enabled=True, names=None, target=None):
+        self.ops, self.events, self.on, self.enabled = (target if target is not None else ops), [], False, enabled
+        self.NAMES = tuple(names) if names else self.NAMES
+        self.orig = {n: getattr(self.ops, n) for n in self.NAMES}
 
     def __enter__(self):
         import torch
@@ -370,7 +371,9 @@ def main_harq(args, nr, ops, dist, rank, world, backend, workload, metric, unit)
     dev = link.dev
     n_total = world * B
     kw = dict(seed=123, proc_offset=rank * B, n_proc_total=n_total)
-    with DecodeTimer(ops, True) as timer:
+    # (the decoder launches of a round -- new blocks, retransmissions -- run on two streams: the round's decoder time is the span of
+    #  PdschLink._harq_decode on the caller's stream, not the sum of the launches)
+    with DecodeTimer(ops, True, names=('_harq_decode',), target=link) as timer:
         _, st = link.run_harq(B, max(W, 1), args.snr, **kw)              # warm-up rounds: the processes get into their steady mix of tries
         torch.cuda.synchronize()
         before = torch.cat([st['tx'], st['rx'], st['tx_bits'], st['rx_bits'], st['timeouts'].reshape(-1)]).clone()

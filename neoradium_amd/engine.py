@@ -264,6 +264,10 @@ class PdschLink:
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
         self._enc_buf = {}        # codeword -> ((batch size, rows), coded-bit buffer) reused from batch to batch (ops.ldpc_encode out=)
+        # run_harq: the decoder launches of a round's new blocks and of its retransmissions on two streams (NRX_HARQ_ONE_STREAM=1: one after
+        # the other on the caller's stream; read at construction)
+        self.harq_two_streams = not bool(int(os.environ.get('NRX_HARQ_ONE_STREAM', '0')))
+        self._side_stream = None
         self._sep_rr = bool(int(os.environ.get('NRX_SEPARATE_RATE_RECOVERY', '0')))    # developer switch: demap, then rate recovery
         # developer switch: the reference's operation order for the wideband precoder (precode the grid, then modulate the ports and
         # filter with the plain gains) instead of folding it into the filter's gains (same arithmetic up to reassociation of the precoder)
@@ -366,7 +370,24 @@ class PdschLink:
             is_new = new_flags.to(torch.uint8).reshape(-1, 1).expand(-1, C).reshape(-1).contiguous()
             s_re, n_re = ops.select_zero(is_new)                              # retransmissions
             s_nw, n_nw = ops.select_zero(1 - is_new)                          # new blocks
-            if ops.ldpc_decode_selected(rr, ccfg, self.numIter, 46 if ccfg.bg == 1 else 42, s_re, n_re, dec) and \
+            # the two launches side by side on two streams: each is a few rounds of whole-CU workgroups (2 304 code blocks = 4.5 rounds of
+            # 256), so one's last round leaves CUs to the other; they read rr and write disjoint rows of dec
+            if self.harq_two_streams and rr.is_cuda:
+                main = torch.cuda.current_stream()
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=rr.device)
+                side = self._side_stream
+                ready, done = torch.cuda.Event(), torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    ok_nw = ops.ldpc_decode_selected(rr, ccfg, self.numIter, rows_new, s_nw, n_nw, dec)
+                    done.record(side)
+                ok_re = ops.ldpc_decode_selected(rr, ccfg, self.numIter, 46 if ccfg.bg == 1 else 42, s_re, n_re, dec)
+                main.wait_event(done)
+                if ok_re and ok_nw:
+                    return dec
+            elif ops.ldpc_decode_selected(rr, ccfg, self.numIter, 46 if ccfg.bg == 1 else 42, s_re, n_re, dec) and \
                     ops.ldpc_decode_selected(rr, ccfg, self.numIter, rows_new, s_nw, n_nw, dec):
                 return dec
         fresh = new_flags.to(torch.bool).cpu()
