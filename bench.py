@@ -537,7 +537,9 @@ def main():
         if e_r is not None and cfg.C > 0 and link.cw[0]['G'] % cfg.C == 0 and 4 < rows <= 46:
             need_fill = max(0, min(cfg.Zc, e_r + cfg.F - (24 + rows - 5) * cfg.Zc))
         last_fill = need_fill if rows == rows_run else (0 if rows < rows_run else cfg.Zc)      # ... of the last layer of the instantiation
-        edge_visits = B * cfg.C * link.numIter * (BG1_ROW_START[rows - 1] * cfg.Zc + (BG1_ROW_START[rows] - BG1_ROW_START[rows - 1]) * need_fill)
+        edge_visits_strict = B * cfg.C * link.numIter * (BG1_ROW_START[rows - 1] * cfg.Zc + (BG1_ROW_START[rows] - BG1_ROW_START[rows - 1]) * need_fill)
+        # the unit of rounds 3-4 (and of `frac`): every check row of the layers the code rate needs, whether its extension LLR was received or not
+        edge_visits = B * cfg.C * link.numIter * BG1_ROW_START[rows] * cfg.Zc
         ev_s = edge_visits / (dec_ms * 1e-3)
         # What bounds the decoder is VALU issue, not HBM: a SIMD issues one wave64 VALU instruction per 4 cycles
         # whatever the mix (tools/ubench/issue_probe.hip, profiles/r3_issue_probe.txt: sustained v_fma_f64 77.5 TFLOP/s = 4.0
@@ -564,6 +566,7 @@ def main():
         isa = decoder_isa(key) if (key and not args.stub) else None
         peak_rate = 256 * 4 * CLOCK / 4.0                         # the chip's VALU issue rate, wave64 instructions / s
         work_frac = 7.0 * ev_s / 64.0 / peak_rate                 # 7 irreducible VALU instructions per edge-visit
+        strict_frac = 7.0 * (edge_visits_strict / (dec_ms * 1e-3)) / 64.0 / peak_rate      # ... counting only the check rows that are not no-ops
         n_waves = B * cfg.C * (cfg.Zc // 64)                      # one wave = 64 check rows of one code block
         valu_issue = None
         if isa:
@@ -592,9 +595,9 @@ def main():
                           "ideal_valu_instr_per_edge_visit": 7.0,
                           "ideal_instruction_frac": work_frac,
                           "ideal_achieved": 7.0 * ev_s / 64.0 / 1e9,
-                          # (rounds 3-4 counted every check row of the last layer, received or not: 157 edges x 384 rows)
-                          "ideal_instruction_frac_counting_the_no_op_rows_of_the_last_layer":
-                              7.0 * (B * cfg.C * link.numIter * BG1_ROW_START[rows_run] * cfg.Zc / (dec_ms * 1e-3)) / 64.0 / peak_rate,
+                          # (stricter numerator: of the last needed layer only the check rows whose extension LLR was received --
+                          #  the others are exact no-ops and the kernel leaves them out)
+                          "ideal_instruction_frac_without_the_no_op_rows_of_the_last_layer": strict_frac,
                           "bound_edge_visits_per_s": peak_rate / (isa['valu'] / BG1_ROW_START[rows_run]) * 64}
         traffic = None
         try:                                              # HBM bytes per launch from the committed PMC passes
@@ -629,12 +632,13 @@ def main():
             # contain, 15.6 per edge-visit -- is the sub-field issue_slot_occupancy.)
             "roofline": ({"bound": "valu", "kernel": kname, "achieved": 7.0 * ev_s / 64.0 / 1e9, "peak": peak_rate / 1e9,
                           "unit": "G wave64 VALU instructions/s", "frac": work_frac, "issue_slot_occupancy": None,
+                          "frac_without_the_no_op_rows_of_the_last_layer": strict_frac,
                           "note": "the copy of the kernel that leaves the layers beyond the needed rows out: instruction count per iteration "
                                   "depends on the row count, no occupancy figure"} if (on_chip and f64 and not valu_issue and not args.stub) else
                          {"bound": "valu", "kernel": kname, "achieved": valu_issue["ideal_achieved"], "peak": valu_issue["peak"],
                           "unit": valu_issue["unit"], "frac": valu_issue["ideal_instruction_frac"],
                           "issue_slot_occupancy": valu_issue["frac"],
-                          "frac_counting_the_no_op_rows_of_the_last_layer": valu_issue["ideal_instruction_frac_counting_the_no_op_rows_of_the_last_layer"]}
+                          "frac_without_the_no_op_rows_of_the_last_layer": valu_issue["ideal_instruction_frac_without_the_no_op_rows_of_the_last_layer"]}
                          if valu_issue else
                          {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0}),
             "env": {k: v for k, v in os.environ.items() if k.startswith('NRX_')},
