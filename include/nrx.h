@@ -375,9 +375,13 @@ int32_t nrx_add_noise_f32(const void* x, const void* z, const void* sigma, int32
                           void* out, int32_t n_batch, void* stream);
 int32_t nrx_add_noise_f64(const void* x, const void* z, const void* sigma, int32_t sigma_stride, int64_t n_per,
                           void* out, int32_t n_batch, void* stream);
-/* Throughput-mode AWGN: Philox4x32-10 counter RNG keyed by (seed, stream_id, item, element) + Box-Muller in float64;
- * independent of launch geometry, batch split and GPU count.  item of batch entry b = item_ids[b] when item_ids (nullable,
+/* Throughput-mode AWGN: Philox4x32-10 counter RNG keyed by (seed, stream_id, item, element) + Box-Muller; independent of launch
+ * geometry, batch split and GPU count.  The transform runs on the float32 transcendental unit by default (normals of float32
+ * precision in the caller's type) or in float64 like the reference's normals (random.py:203): nrx_set_noise_precision(1), or
+ * NRX_RNG_F64=1 in the environment at the first launch.  Process-wide; every value of the synthetic noise changes with it.  item of batch entry b = item_ids[b] when item_ids (nullable,
  * device int64[n_batch]: e.g. the absolute slot numbers of a non-contiguous slot selection) is given, else batch_offset+b. */
+int32_t nrx_set_noise_precision(int32_t f64);
+int32_t nrx_get_noise_precision(void);
 int32_t nrx_awgn_f32(const void* x, const void* sigma, int32_t sigma_stride, int64_t n_per, void* out,
                      int32_t n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset, const int64_t* item_ids,
                      void* stream);

@@ -30,6 +30,8 @@ _cfgp = C.POINTER(LdpcCfg)
 SIGNATURES = {
     'nrx_version': (i32, []),
     'nrx_last_error': (i32, [C.c_char_p, i32]),
+    'nrx_set_noise_precision': (i32, [i32]),
+    'nrx_get_noise_precision': (i32, []),
     'nrx_gold_sequence': (i32, [C.c_uint32, i64, C.c_char_p]),
     'nrx_crc': (i32, [vp, i32, i64, i64, i32, vp, vp]),
     'nrx_ldpc_config': (i32, [i32, i32, _cfgp]),

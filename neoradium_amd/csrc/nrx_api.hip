@@ -15,6 +15,25 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int32_t nrx_version(void) { return 100; }  // 0.1.0
 
+// Precision of the device noise generator's Box-Muller transform (nrx_rng.h): 0 = float32 transcendental unit (default), 1 = float64
+// (random.py:203 draws float64 normals).  Process-wide; read by the launches that follow.
+namespace nrx {
+static int g_noise_f64 = -1;
+bool noise_f64() {
+  if (g_noise_f64 < 0) {
+    const char* e = getenv("NRX_RNG_F64");
+    g_noise_f64 = (e && e[0] && e[0] != '0') ? 1 : 0;
+  }
+  return g_noise_f64 == 1;
+}
+}  // namespace nrx
+extern "C" int32_t nrx_set_noise_precision(int32_t f64) {
+  NRX_REQUIRE(f64 == 0 || f64 == 1, NRX_E_ARG, "nrx_set_noise_precision: 0 (float32 transform) or 1 (float64 transform)");
+  nrx::g_noise_f64 = f64;
+  return NRX_OK;
+}
+extern "C" int32_t nrx_get_noise_precision(void) { return nrx::noise_f64() ? 1 : 0; }
+
 extern "C" int32_t nrx_last_error(char* buf, int32_t buf_len) {
   if (!buf || buf_len <= 0) return NRX_E_ARG;
   strncpy(buf, nrx::g_err, (size_t)buf_len - 1);

@@ -332,7 +332,7 @@ add_noise_kernel(const cx<T>* __restrict__ x, const cx<T>* __restrict__ z, const
 
 using nrx::philox4x32;
 
-template <typename T>
+template <typename T, bool F64N>
 __global__ void __launch_bounds__(256)
 awgn_philox_kernel(const cx<T>* __restrict__ x, const T* __restrict__ sigma, int sigma_stride, int64_t n_per,
                    cx<T>* __restrict__ out, int n_batch, uint64_t seed, uint64_t stream_id, int64_t batch_offset,
@@ -341,7 +341,7 @@ awgn_philox_kernel(const cx<T>* __restrict__ x, const T* __restrict__ sigma, int
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(g / n_per);
     const int64_t e = g - (int64_t)b * n_per;
-    out[g] = nrx::awgn_add<T>(x[g], (double)sigma[(size_t)b * sigma_stride], seed, stream_id,
+    out[g] = nrx::awgn_add<T, F64N>(x[g], (double)sigma[(size_t)b * sigma_stride], seed, stream_id,
                                (uint64_t)(item_ids ? item_ids[b] : batch_offset + b), e);
   }
 }
@@ -515,7 +515,8 @@ static int32_t awgn_entry(const void* x, const void* sigma, int32_t sigma_stride
                           void* stream) {
   NRX_REQUIRE(x && sigma && out, NRX_E_ARG, "nrx_awgn: NULL buffer");
   if (n_per == 0 || n_batch == 0) return NRX_OK;
-  hipLaunchKernelGGL(awgn_philox_kernel<T>, dim3(nrx::stream_grid((long)n_per * n_batch, 256)), dim3(256), 0,
+  auto kern = nrx::noise_f64() ? awgn_philox_kernel<T, true> : awgn_philox_kernel<T, false>;
+  hipLaunchKernelGGL(kern, dim3(nrx::stream_grid((long)n_per * n_batch, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const cx<T>*)x, (const T*)sigma, sigma_stride, n_per, (cx<T>*)out, n_batch,
                      seed, stream_id, batch_offset, item_ids);
   NRX_CHECK_LAUNCH("nrx_awgn");

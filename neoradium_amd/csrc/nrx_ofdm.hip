@@ -126,7 +126,7 @@ ofdm_mod_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymG
 // No-window variant is the same kernel with w = 0 (tail/head loops vanish).
 
 // One FFT per (item, antenna, symbol); workgroups loop over tasks so the twiddle table is built once.
-template <typename T, typename TO = T>       // TO: element type of the grid written (float32 transform, float64 grid: _f32o64)
+template <typename T, typename TO = T, bool F64N = false>       // TO: element type of the grid written (float32 transform, float64 grid: _f32o64); F64N: nrx_rng.h
 __global__ void __launch_bounds__(256, 2)   // two 68 KB workgroups per CU = two waves per SIMD: 256 registers each
 ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t wave_len,
                   const int32_t* __restrict__ t_off, int t_off_stride, int n_ant, int K, int nfft, int log2n, SymGeom g,
@@ -175,7 +175,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
         for (int u = 0; u < FILL_U; ++u) {
           const int i = i0 + u * blockDim.x;
           const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));
-          nz[u] = nrx::awgn_noise(sg, seed, stream_id, nid, (int64_t)(row - item * n_ant) * wave_len + s);
+          nz[u] = nrx::awgn_noise<F64N>(sg, seed, stream_id, nid, (int64_t)(row - item * n_ant) * wave_len + s);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -421,7 +421,7 @@ int32_t demod_entry(const void* wave, int64_t wave_stride, int64_t wave_len, con
   const cx<double>* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_ofdm_demodulate: FFT twiddle table unavailable");
   const size_t lds = sizeof(cx<T>) * nrx::fft_lds_elems((size_t)nfft);
-  auto kern = ofdm_demod_kernel<T, TO>;
+  auto kern = (sigma && nrx::noise_f64()) ? ofdm_demod_kernel<T, TO, true> : ofdm_demod_kernel<T, TO, false>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid_dim = n_tasks < 4096 ? n_tasks : 4096;
   hipLaunchKernelGGL(kern, dim3(grid_dim), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)wave, wave_stride, wave_len,

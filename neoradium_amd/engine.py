@@ -629,7 +629,9 @@ class PdschLink:
                 d['cw'] = [dict(cb_ok=c['cb_ok'], tb_out=c['tb_out']) for c in per_cw]
             return d
         if details:
-            d = dict(per_cw[0], eq=eq, hest=hest, rxg=rxg, F=F, off=off, nv=nv, sigma=sigma, grid=grid)
+            d = dict(per_cw[0], eq=eq, sc=sc, hest=hest, rxg=rxg, F=F, off=off, nv=nv, sigma=sigma, grid=grid, bits=tx_bits[0])
+            if not self.freqDomain:     # the waveforms either side of the channel filter (tools/r6/stage_diff.py)
+                d.update(tx=tx, ry=ry)
             if self.numCW > 1:
                 d['cw'] = per_cw
             return d
@@ -772,10 +774,9 @@ def harq_stats(tx, rx, txb, rxb, nto):
 def shard_slots(slot0, n_slots, world, rank):
     """Contiguous share of [slot0, slot0 + n_slots) owned by ``rank`` (slots are independent given their
     absolute index, so a sweep shards by slot range with no data-path communication)."""
-    per = -(-int(n_slots) // int(world))
-    lo = min(int(n_slots), rank * per)
-    hi = min(int(n_slots), lo + per)
-    return slot0 + lo, hi - lo
+    q, r = divmod(int(n_slots), int(world))                # balanced: the first r ranks take one more, none is left empty while another holds two
+    lo = rank * q + min(rank, r)
+    return slot0 + lo, q + (1 if rank < r else 0)
 
 
 def run_harq_sharded(link, n_proc, n_rounds, snr_db, state=None, **kw):

@@ -193,7 +193,8 @@ class LdpcDecoder(LdpcBase):
         out = ops.ldpc_rate_recover(D(np.float64(rxBlock)[None]), cfg, self.txLayers, self.qm, rv, self.nRef, circ)
         if harq is not None:
             harq.decBuffer = circ
-        return N(out)
+        # (C, Ncb) like the reference (ldpc.py:1414-1418); the library's N-wide matrix has zeros beyond a limited buffer
+        return N(out)[:, :ncb]
 
     def decode(self, rxCodeBlock, numIter=5, onlyInfoBits=True, outputBelief=False, certifiedExit=None):
         """Layered normalised min-sum (ldpc.py:1495-1581).  float64 input -> the bit-exact float64 kernel;
@@ -206,6 +207,10 @@ class LdpcDecoder(LdpcBase):
         rx = np.asarray(rxCodeBlock)
         if rx.dtype != np.float32:
             rx = np.float64(rx)
+        if self._cfg is not None and self.nRef and rx.ndim == 2 and rx.shape[1] == min(self._cfg.N, self.nRef) < self._cfg.N:
+            # limited buffer (LBRM): the positions beyond Ncb were never transmitted -- LLR 0, like any punctured bit.  (The reference's
+            # decode stops on this shape, ldpc.py:1538; TS 38.212 5.4.2.1 decodes it so.)
+            rx = np.concatenate([rx, np.zeros((rx.shape[0], self._cfg.N - rx.shape[1]), dtype=rx.dtype)], axis=1)
         if self._cfg is None or rx.shape[1] != self._cfg.N:
             raise ValueError("decode: call recoverRate first (or the block length does not match the configuration)")
         if certifiedExit is not None:

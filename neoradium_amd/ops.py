@@ -798,6 +798,17 @@ def _item_ids(item_ids, n, dev):
     return item_ids.contiguous()
 
 
+def set_noise_precision(f64):
+    """Transform of the device noise generator (throughput mode's synthetic AWGN): False = Box-Muller on the float32 transcendental
+    unit (default: normals of float32 precision), True = in float64 like the reference's normals (random.py:203).  Process-wide."""
+    check(lib().nrx_set_noise_precision(1 if f64 else 0))
+
+
+def noise_precision():
+    """'f64' or 'f32': the transform the device noise generator uses (see :func:`set_noise_precision`; NRX_RNG_F64=1 sets the default)."""
+    return 'f64' if lib().nrx_get_noise_precision() else 'f32'
+
+
 def awgn(x, sigma, seed, stream_id=0, batch_offset=0, item_ids=None):
     """x + complex AWGN of std sigma[b] from the counter-based device generator (throughput mode), keyed by
     (seed, stream_id, item, element) with item = item_ids[b] if given else batch_offset + b."""

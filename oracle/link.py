@@ -72,13 +72,15 @@ def run_slots_parallel(jobs, n_procs):
                 os.environ[k] = v
 
 
-def run_slot(st, slot, snr_db, tb, z, F=None, chan_slot=None):
+def run_slot(st, slot, snr_db, tb, z, F=None, chan_slot=None, keep=None):
     """One slot.  tb: (TBS,) bits; z: standard-normal complex array shaped like the noisy signal
     ((Nr,L,K) in frequency-domain mode, (Nr, slotLen+maxDelay) in time-domain mode).  Returns a dict with
     the per-code-block CRC verdicts, the decoded transport block and the LLRs.
     ``chan_slot``: slot whose start is the channel's time origin when it differs from the carrier's slot number (the
     reference advances the channel clock only when the channel has been applied since the last goNext,
-    channelmodel.py:180-193, 326, 349: n consecutive goNext() calls leave it at slot min(n, 1))."""
+    channelmodel.py:180-193, 326, 349: n consecutive goNext() calls leave it at slot min(n, 1)).
+    ``keep``: a dict that receives every intermediate (rate-matched bits, grids, waveforms, estimate, equalised symbols) for
+    stage-by-stage comparisons (tools/r6/stage_diff.py)."""
     nl, qm, K, L, nfft = st['nl'], st['qm'], st['K'], st['L'], st['nfft']
     # ---- Tx: CRC24A, segmentation, LDPC encode, rate match (ldpc.py:1167-1204)
     rm, d = oc.encode_chain(tb, st['bg'], st['G'], nl, qm)
@@ -116,6 +118,8 @@ def run_slot(st, slot, snr_db, tb, z, F=None, chan_slot=None):
         cir1, _ = op.cir_from_gains(gains, st['coeff'])
         y = _apply_cir(w, cir1, sl)
         sigma = op.noise_std_waveform(y, nfft, cps, st['n_rb'], snr_db)            # waveform.py:119-142
+        if keep is not None:
+            keep.update(tx=w, ry=y)
         y = y + (sigma / np.sqrt(2)) * z
         rxg = op.ofdm_demodulate(y[:, off:], nfft, cps, K)                         # sync + demodulate
         nv = sigma * sigma * nfft                                                  # waveform.py:523
@@ -130,6 +134,8 @@ def run_slot(st, slot, snr_db, tb, z, F=None, chan_slot=None):
     rr, _ = oc.rate_recover(llr, p, nl, qm)
     dec = oc.decode(rr, st['bg'], p.iLS, p.Zc, st['num_iter'])
     out, crc = oc.crc_check_and_merge(dec, p)
+    if keep is not None:
+        keep.update(bits=rm, grid=grid, pgrid=pg, sigma=sigma, rxg=rxg, hest=hest, eq=eq, sc=sc, nv=nv, llr=llr, dec=dec)
     return dict(crc=crc, tb_out=out, llr=llr, F=F, off=off, nv=nv, p=p)
 
 

@@ -101,34 +101,8 @@ def test_sharded_sweep_world2_equals_single_process():
         assert table == want
 
 
-class _StubHarqLink:
-    """Stands in for PdschLink.run_harq on the host: whether process p's transmission of round k decodes is a pure function of its
-    ABSOLUTE slot (slot0 + k * n_proc_total + p) -- what the device generator's keying gives the real engine -- and the per-try
-    bookkeeping is the engine's (harq.py:185-199)."""
-    dev = torch.device('cpu')
-
-    def run_harq(self, n_proc, n_rounds, snr_db, state=None, maxTries=4, slot0=0, proc_offset=0, n_proc_total=None, **kw):
-        n_proc_total = n_proc if n_proc_total is None else n_proc_total
-        if state is None:
-            state = dict(tries=np.zeros(n_proc, dtype=np.int64), tx=torch.zeros(maxTries, dtype=torch.int64), rx=torch.zeros(maxTries, dtype=torch.int64),
-                         tx_bits=torch.zeros(maxTries, dtype=torch.int64), rx_bits=torch.zeros(maxTries, dtype=torch.int64),
-                         timeouts=torch.zeros(1, dtype=torch.int64), next_slot=int(slot0))
-        for _ in range(n_rounds):
-            s0 = state['next_slot'] + proc_offset
-            slots = np.arange(s0, s0 + n_proc)
-            ok = ((slots * 2654435761 + 17 * state['tries']) % 11) < (2 + 2 * state['tries'])      # later tries decode more often
-            for t, o in zip(state['tries'], ok):
-                state['tx'][t] += 1
-                state['tx_bits'][t] += 1000
-                state['rx'][t] += int(o)
-                state['rx_bits'][t] += 1000 * int(o)
-            nxt = state['tries'] + 1
-            timeout = (~ok) & (nxt == maxTries)
-            state['timeouts'] += int(timeout.sum())
-            state['tries'] = np.where(ok | timeout, 0, nxt)
-            state['next_slot'] = s0 - proc_offset + n_proc_total
-        from neoradium_amd.engine import harq_stats
-        return harq_stats(state['tx'].numpy(), state['rx'].numpy(), state['tx_bits'].numpy(), state['rx_bits'].numpy(), int(state['timeouts'])), state
+sys.path.insert(0, ROOT)
+from bench import StubHarqLink as _StubHarqLink      # noqa: E402  (the host stand-in for PdschLink.run_harq; also behind `bench.py --config cfg5 --stub`)
 
 
 def _harq_worker(rank, world, port, q):
@@ -195,3 +169,85 @@ def test_bench_gpus2_self_launch_gloo():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--stub', '--no-cpu'], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and 'WORLD_SIZE' in r2.stderr
+
+
+def _harq_worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from neoradium_amd.engine import run_harq_sharded, shard_slots
+    link = _StubHarqLink()
+    st, state = run_harq_sharded(link, 13, 5, 20.0, slot0=40)               # 13 processes over 8 ranks: shares of 2 and 1
+    st2, _ = run_harq_sharded(link, 13, 4, 20.0, state=state, slot0=40)
+    st3, _ = run_harq_sharded(link, 5, 3, 20.0, slot0=7)                     # fewer processes than ranks: empty shards join the collective
+    q.put((rank, {k: np.asarray(v).tolist() for k, v in st2.items()}, {k: np.asarray(v).tolist() for k, v in st3.items()},
+           shard_slots(0, 13, world, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_harq_world8_process_count_not_divisible_by_the_world_size():
+    """First-8-GPU-run insurance (VERDICT r5 #8): eight gloo ranks, 13 HARQ processes (shares of 2 and 1) and 5 processes (three empty
+    shards): contiguous disjoint shares that cover every process, and every rank ends with the single-process statistics."""
+    sys.path.insert(0, ROOT)
+    from neoradium_amd.engine import run_harq_sharded
+    link = _StubHarqLink()
+    _, state = run_harq_sharded(link, 13, 5, 20.0, slot0=40)
+    want, _ = run_harq_sharded(link, 13, 4, 20.0, state=state, slot0=40)
+    want = {k: np.asarray(v).tolist() for k, v in want.items()}
+    want5, _ = run_harq_sharded(link, 5, 3, 20.0, slot0=7)
+    want5 = {k: np.asarray(v).tolist() for k, v in want5.items()}
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 311) % 500
+    procs = [ctx.Process(target=_harq_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    shares = [r[3] for r in res]
+    assert sum(c for _, c in shares) == 13 and all(shares[i][0] + shares[i][1] == shares[i + 1][0] for i in range(world - 1))
+    assert max(c for _, c in shares) - min(c for _, c in shares) <= 1
+    for _, got, got5, _ in res:
+        assert got == want and got5 == want5
+
+
+@pytest.mark.parametrize("config", ["metric", "cfg3", "cfg5"])
+def test_bench_gpus8_self_launch_gloo(config):
+    """`python bench.py --gpus 8 --config ...` on the host (gloo + the --stub links; no GPU, no measurement): eight ranks, local rank ->
+    device index mapping, disjoint slot ranges / process streams per rank, ONE JSON line from rank 0 whose counters are 8 x a
+    single rank's share -- the code path the driver's first 8-GPU run takes (VERDICT r5 #8)."""
+    import json
+    import subprocess
+    env = dict(os.environ, NRX_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    K, W, B = 3, 1, 8
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--config', config, '--steps', str(K), '--warmup', str(W),
+                        '--batch', str(B), '--stub', '--no-cpu'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['steps'] == K and out['scaling'] == 'weak' and out['config']['name'] == config
+    if config != 'cfg5':
+        assert out['bler']['blocks'] == 8 * K * B * 72
+        # rank r's timed slots: [r (K + W) B + W B, (r + 1)(K + W) B) -- disjoint, the union is what the counters saw
+        slots = np.concatenate([np.arange(r_ * (K + W) * B + W * B, (r_ + 1) * (K + W) * B) for r_ in range(8)])
+        assert len(np.unique(slots)) == 8 * K * B
+        assert out['bler']['block_errors'] == int(((slots * 2654435761 + 123) % 97 < 13).sum() * 3)
+        one = int(((np.arange(W * B, (K + W) * B) * 2654435761 + 123) % 97 < 13).sum() * 3)      # (rank 0's own share differs: other slots)
+        assert out['bler']['bits'] == 8 * K * B * 606504 and one >= 0
+        assert abs(out['value'] - 8 * K * B / (out['ms_per_step'] * 1e-3 * K)) < 1e-6 * out['value']
+    else:
+        # 8 ranks x B process streams, K timed rounds: every process transmits once per round, and the sharded run equals ONE process
+        # simulating all 8 B streams (same absolute slots)
+        assert sum(out['harq']['txBlocks']) == 8 * B * K
+        link = _StubHarqLink()
+        _, st = link.run_harq(8 * B, W, 27.0, seed=123)
+        before = [st['tx'].clone(), st['rx'].clone()]
+        _, st = link.run_harq(8 * B, K, 27.0, seed=123, state=st)
+        assert (st['tx'] - before[0]).tolist() == out['harq']['txBlocks'] and (st['rx'] - before[1]).tolist() == out['harq']['rxBlocks']

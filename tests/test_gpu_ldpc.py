@@ -130,6 +130,71 @@ def test_harq_soft_combining(dev):
         assert np.array_equal(circ_dev.cpu().numpy(), circ_ref)
 
 
+def test_limited_buffer_rate_matching_vs_reference(dev):
+    """nRef > 0 (LBRM; ldpc.py:1093-1159, 1347-1418) against the reference's own outputs (tests/golden/coding_lbrm.npz): rate-matched
+    bits, rate-recovered LLRs (the library's matrix is N wide: the reference's (C, Ncb) columns, zeros beyond), HARQ buffers after
+    three redundancy versions, both through the C ABI and through the class surface; then a decode through the limited buffer."""
+    import os
+    import torch
+    from neoradium_amd import ops, _lib, LdpcEncoder, LdpcDecoder
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'coding_lbrm.npz'))
+    unpack = lambda a, shape: np.unpackbits(a)[:int(np.prod(shape))].reshape(shape).astype(np.uint8)   # noqa: E731
+    mods = {2: 'QPSK', 4: '16QAM', 6: '64QAM', 8: '256QAM'}
+    for i, (bg, A, G, nl, qm, rv, nref) in enumerate(g['cases'].tolist()):
+        p_ = f'c{i}_'
+        tb = g[p_ + 'tb'].astype(np.uint8)
+        cfg = _lib.ldpc_config(bg, A + 24)
+        C_, Zc, K, F, ncb = g[p_ + 'params'].tolist()
+        assert (cfg.C, cfg.Zc, cfg.K, cfg.F) == (C_, Zc, K, F) and ncb == min(cfg.N, nref)
+        coded = ops.ldpc_encode(ops.ldpc_segment(_t(tb[None], dev), cfg), cfg)
+        assert np.array_equal(coded.cpu().numpy().reshape(cfg.C, cfg.N), unpack(g[p_ + 'coded'], (cfg.C, cfg.N)))
+        rm = ops.ldpc_rate_match(coded, cfg, G, nl, qm, rv, nref)
+        rm_ref = unpack(g[p_ + 'rm'], (G,))
+        assert np.array_equal(rm.cpu().numpy()[0], rm_ref)
+        llr = np.float64(g[p_ + 'llr'])
+        circ = torch.zeros((cfg.C, ncb - cfg.F), dtype=torch.float64, device=dev)
+        rr = ops.ldpc_rate_recover(_t(llr[None], dev), cfg, nl, qm, rv, nref, circ=circ).cpu().numpy()
+        ref = g[p_ + 'rr']
+        assert rr.shape == (cfg.C, cfg.N) and not rr[:, ncb:].any()
+        assert np.array_equal(np.where(rr[:, :ncb] > 1e19, np.inf, rr[:, :ncb]), ref)
+        buf_ref = np.concatenate([ref[:, :cfg.K - 2 * cfg.Zc - cfg.F], ref[:, cfg.K - 2 * cfg.Zc:]], axis=1)
+        assert np.array_equal(circ.cpu().numpy(), buf_ref)
+        # class surface: same calls as the reference's (LdpcEncoder(nRef=...).rateMatch, LdpcDecoder(nRef=...).recoverRate)
+        enc = LdpcEncoder(baseGraphNo=bg, modulation=mods[qm], txLayers=nl, nRef=nref)
+        cw = enc.encode(enc.doSegmentation(enc.appendCrc(tb.astype(np.int8), '24A')))
+        assert np.array_equal(enc.rateMatch(cw, G, rv=rv), rm_ref.astype(np.int8))
+        dec = LdpcDecoder(bg, mods[qm], nl, nRef=nref)
+        rr_c = dec.recoverRate(llr, A)
+        if rv == 0:
+            assert rr_c.shape == ref.shape and np.array_equal(np.where(rr_c > 1e19, np.inf, rr_c), ref)
+        else:
+            assert rr_c.shape == ref.shape        # (without a HARQ object the reference takes rv 0)
+    bg, A, G, nl, qm, nref = g['harq_params'].tolist()
+    cfg = _lib.ldpc_config(bg, A + 24)
+    ncb = min(cfg.N, nref)
+    circ = torch.zeros((cfg.C, ncb - cfg.F), dtype=torch.float64, device=dev)
+    for t, rv in enumerate((0, 2, 3)):
+        rr = ops.ldpc_rate_recover(_t(np.float64(g[f'harq_llr{t}'])[None], dev), cfg, nl, qm, rv, nref, circ=circ)
+    assert np.array_equal(circ.cpu().numpy(), g['harq_buf'])
+    # ... and the soft-combined limited buffer decodes (library: N-wide matrix; class surface: the (C, Ncb) matrix padded by decode)
+    hard = ops.ldpc_decode(rr, cfg, 20)
+    tb_out, ok, _ = ops.ldpc_crc_merge(hard, cfg)
+    assert bool(ok.all()) and np.array_equal(tb_out.cpu().numpy()[0, :A], g['harq_tb'].astype(np.uint8))
+    dec = LdpcDecoder(bg, mods[qm], nl, nRef=nref)
+
+    class H:
+        pass
+    h = H()
+    h.decBuffer, h.rv = None, 0
+    for t, rv in enumerate((0, 2, 3)):
+        h.rv = rv
+        rr_c = dec.recoverRate(np.float64(g[f'harq_llr{t}']), A, harq=h)
+    assert rr_c.shape == (cfg.C, ncb)
+    bits = dec.decode(rr_c, numIter=20)
+    merged, crc = dec.checkCrcAndMerge(bits)
+    assert np.all(crc) and np.array_equal(merged[:A], g['harq_tb'])
+
+
 def test_errors_are_valueerrors(dev):
     import torch
     from neoradium_amd import ops, _lib

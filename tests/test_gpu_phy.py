@@ -4,6 +4,8 @@ Tolerances (written out per the north star): complex128 paths <= 1e-10 relative 
 interpolation and 4x4 solves are mathematically defined; only rounding order differs); LLRs <= 1e-9 absolute in
 float64 and <= 1e-5 relative to the LLR scale in float32.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -132,24 +134,43 @@ def test_noise_level_and_noise(dev):
     s = sigma.cpu().numpy()
     ref = x + (z * (s / np.sqrt(2))[:, None, None, None, None]) @ np.array([1, 1j])
     assert rel(y, ref) < 1e-15
-    # counter-based generator: statistics + independence of the batch split
+    # counter-based generator: statistics + independence of the batch split, for both transforms (nrx_rng.h normal_pair: Box-Muller on
+    # the float32 transcendental unit = the default, or in float64 like the reference's normals, random.py:203)
     big = torch.zeros((4, 200000), dtype=torch.complex128, device=dev)
     sg = torch.tensor([1.0, 2.0, 0.5, 1.0], dtype=torch.float64, device=dev)
-    a = ops.awgn(big, sg, seed=99).cpu().numpy()
-    for i in range(4):
-        assert abs(np.var(a[i]) - sg[i].item() ** 2) < 0.02 * sg[i].item() ** 2
-        assert abs(a[i].mean()) < 0.02 and abs(np.var(a[i].real) - np.var(a[i].imag)) < 0.03 * sg[i].item() ** 2
-    b = ops.awgn(big[2:], sg[2:], seed=99, batch_offset=2).cpu().numpy()
-    assert np.array_equal(a[2:], b)
-    # ... and its shape: the components are N(0, sigma^2 / 2) (nrx_rng.h normal_pair: Box-Muller on the float32 transcendental
-    # unit) -- fourth moment, 3-sigma tail mass, no correlation between the components, uniform phase
-    for i in range(4):
-        c = np.concatenate([a[i].real, a[i].imag]) / (sg[i].item() / np.sqrt(2))
-        assert abs(np.mean(c ** 4) - 3.0) < 0.06 and abs(np.mean(np.abs(c) > 3.0) - 0.0026998) < 3e-4
-        assert abs(np.mean(a[i].real * a[i].imag)) < 0.01 * sg[i].item() ** 2
-        ph = np.histogram(np.angle(a[i]), bins=16, range=(-np.pi, np.pi))[0] / a[i].size
-        assert np.abs(ph - 1 / 16).max() < 0.004
-    assert np.abs(a[0]).max() > 3.0 and np.isfinite(a).all()
+    assert ops.noise_precision() == ('f64' if os.environ.get('NRX_RNG_F64', '0') not in ('', '0') else 'f32')
+    was = ops.noise_precision() == 'f64'
+    draws = {}
+    try:
+        for f64 in (False, True):
+            ops.set_noise_precision(f64)
+            assert ops.noise_precision() == ('f64' if f64 else 'f32')
+            a = draws[f64] = ops.awgn(big, sg, seed=99).cpu().numpy()
+            for i in range(4):
+                assert abs(np.var(a[i]) - sg[i].item() ** 2) < 0.02 * sg[i].item() ** 2
+                assert abs(a[i].mean()) < 0.02 and abs(np.var(a[i].real) - np.var(a[i].imag)) < 0.03 * sg[i].item() ** 2
+            b = ops.awgn(big[2:], sg[2:], seed=99, batch_offset=2).cpu().numpy()
+            assert np.array_equal(a[2:], b)
+            # ... and its shape: the components are N(0, sigma^2 / 2) -- fourth moment, 3-sigma tail mass, no correlation between the
+            # components, uniform phase
+            for i in range(4):
+                c = np.concatenate([a[i].real, a[i].imag]) / (sg[i].item() / np.sqrt(2))
+                assert abs(np.mean(c ** 4) - 3.0) < 0.06 and abs(np.mean(np.abs(c) > 3.0) - 0.0026998) < 3e-4
+                assert abs(np.mean(a[i].real * a[i].imag)) < 0.01 * sg[i].item() ** 2
+                ph = np.histogram(np.angle(a[i]), bins=16, range=(-np.pi, np.pi))[0] / a[i].size
+                assert np.abs(ph - 1 / 16).max() < 0.004
+            assert np.abs(a[0]).max() > 3.0 and np.isfinite(a).all()
+        # the same counters give the same normals up to the float32 transform's error (24-bit angle, radius steps near u1 -> 1);
+        # item 0 has sigma 1: the float32 ones are float32 numbers / sqrt 2, the float64 ones are not
+        assert 0 < np.abs(draws[True] - draws[False]).max() < 2e-3
+        z32, z64 = draws[False][0].real * np.sqrt(2), draws[True][0].real * np.sqrt(2)
+        assert np.mean(np.abs(np.float64(np.float32(z32)) - z32) <= 2e-16 * np.abs(z32)) > 0.99
+        assert np.mean(np.float64(np.float32(z64)) == z64) < 0.01
+    finally:
+        ops.set_noise_precision(was)
+    with pytest.raises(ValueError):
+        from neoradium_amd import _lib
+        _lib.check(_lib.lib().nrx_set_noise_precision(2))
 
 
 @pytest.mark.parametrize("mu,nfft,K,slot", [(0, 2048, 300, 0), (1, 1024, 612, 1), (1, 4096, 3276, 0), (2, 512, 240, 2)])

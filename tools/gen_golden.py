@@ -7,6 +7,7 @@ in the development container.  The reference never travels to the GPU box; these
 Outputs (all data: inputs + the reference's outputs, nothing of its source):
   tests/golden/matlab_ldpc/*.mat, matlab_polar/*.mat   MATLAB 5G-Toolbox vectors the reference's own notebooks assert on
   tests/golden/coding.npz        CRC / segmentation / encode / rate-match / rate-recover / decode at several configs
+  tests/golden/coding_lbrm.npz   the same with a limited buffer (nRef > 0): rate-matched bits, (C, Ncb) rate-recovered LLRs, HARQ buffers
   tests/golden/phy.npz           gold sequence, constellations, LLRs, equaliser, OFDM, FIR bank, LS estimate
   tests/golden/host.npz          Carrier / PDSCH / DMRS index + pilot tables, TBS values, SnrScheduler walks
   tests/golden/channels.npz      CDL / TDL per-slot gains + coefficient matrices for seeded channels
@@ -150,6 +151,53 @@ def coding():
         anchors.append((bg, B, e.numCodeBlocks, e.liftingSize, e.setIndex, e.codeBlockSize))
     out['seg_anchors'] = np.int64(anchors)
     np.savez_compressed(os.path.join(GOLD, 'coding.npz'), **out)
+
+
+def coding_lbrm():
+    """Limited-buffer rate matching (nRef > 0; ldpc.py:1093-1159 rateMatch, :1347-1418 recoverRate): the reference's rate-matched bits
+    and its (C, Ncb) rate-recovered LLRs -- with nRef < N its own decode() then stops on that shape (ldpc.py:1538), so the
+    fixture ends at recoverRate -- plus the HARQ buffers of rv 0 -> 2 soft-combined under LBRM.  VERDICT r5 weak #1."""
+    out = {}
+    rng = np.random.default_rng(2026)
+    cases = [(1, 10000, 22808, 1, 2, 'QPSK', 0, 9000), (1, 10000, 22808, 1, 2, 'QPSK', 2, 9000), (2, 3000, 9000, 1, 2, 'QPSK', 3, 5000),
+             (1, 12000, 26000, 2, 4, '16QAM', 1, 12000), (2, 3817, 12000, 1, 6, '64QAM', 0, 4000), (1, 8425, 30000, 1, 8, '256QAM', 3, 25000),
+             (2, 641, 4000, 1, 2, 'QPSK', 2, 1500)]
+    out['cases'] = np.int64([(c[0], c[1], c[2], c[3], c[4], c[6], c[7]) for c in cases])
+
+    class H:
+        pass
+    for i, (bg, A, G, nl, qm, mod, rv, nref) in enumerate(cases):
+        tb = rng.integers(0, 2, A).astype(np.int8)
+        enc = nr.LdpcEncoder(baseGraphNo=bg, modulation=mod, txLayers=nl, nRef=nref)
+        coded = enc.encode(enc.doSegmentation(enc.appendCrc(tb, '24A')))
+        rm = enc.rateMatch(coded, G, rv=rv)
+        dec = nr.LdpcDecoder(bg, mod, nl, nRef=nref)
+        llr = np.float64(np.float32((1 - 2.0 * rm) * 2.5 + rng.normal(0, 1.6, len(rm))))     # float32-representable: the fixture stores float32
+        h = H()
+        h.decBuffer, h.rv = None, rv
+        rr = dec.recoverRate(llr, A, harq=h)
+        p = f'c{i}_'
+        out[p + 'tb'], out[p + 'llr'] = tb, np.float32(llr)
+        out[p + 'params'] = np.int64([enc.numCodeBlocks, enc.liftingSize, enc.codeBlockSize, enc.numFillerBits, rr.shape[1]])
+        out[p + 'coded'], out[p + 'rm'] = np.packbits(coded.astype(np.uint8)), np.packbits(rm.astype(np.uint8))
+        out[p + 'rr'] = np.where(rr > 1e19, np.inf, rr)             # fillers as inf: LARGE_LLR is the library's business
+    # two transmissions into one limited buffer
+    bg, A, G, nl, qm, mod, nref = 1, 10000, 20900, 1, 4, '16QAM', 14000
+    tb = rng.integers(0, 2, A).astype(np.int8)
+    enc = nr.LdpcEncoder(baseGraphNo=bg, modulation=mod, txLayers=nl, nRef=nref)
+    coded = enc.encode(enc.doSegmentation(enc.appendCrc(tb, '24A')))
+    dec = nr.LdpcDecoder(bg, mod, nl, nRef=nref)
+    h = H()
+    h.decBuffer = None
+    out['harq_tb'], out['harq_params'] = tb, np.int64([bg, A, G, nl, qm, nref])
+    for t, rv in enumerate((0, 2, 3)):
+        rm = enc.rateMatch(coded, G, rv=rv)
+        llr = np.float64(np.float32((1 - 2.0 * rm) + rng.normal(0, 1.2, len(rm))))
+        h.rv = rv
+        dec.recoverRate(llr, A, harq=h)
+        out[f'harq_llr{t}'] = np.float32(llr)
+    out['harq_buf'] = h.decBuffer.copy()                           # after the three transmissions
+    np.savez_compressed(os.path.join(GOLD, 'coding_lbrm.npz'), **out)
 
 
 def phy():
@@ -938,6 +986,7 @@ if __name__ == '__main__':
     copy_matlab()
     matlab_cdl()
     coding()
+    coding_lbrm()
     phy()
     host()
     ptrs()
