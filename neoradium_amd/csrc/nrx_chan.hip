@@ -267,11 +267,7 @@ __device__ __forceinline__ void tdp4_term(const char* __restrict__ q0, const cha
   double wr[W], wi[W];
 #pragma unroll
   for (int m = 0; m < W; ++m) {
-#ifdef NRX_TD_ABLATE_LDS      // timing experiment (wrong results): half of the window reads
-    const int mm = m & ~1;
-#else
     const int mm = m;
-#endif
     const char* qk = (mm & 3) == 0 ? q0 : ((mm & 3) == 1 ? q1 : ((mm & 3) == 2 ? q2 : q3));
     const cd v = *(const cd*)(qk + (mm >> 2) * (int)sizeof(cd));
     wr[m] = v.re;
@@ -282,11 +278,7 @@ __device__ __forceinline__ void tdp4_term(const char* __restrict__ q0, const cha
   for (int j = 0; j < R; ++j) fr[j] = fi[j] = 0.0;
 #pragma unroll
   for (int k = 0; k < TDP_FLEN; ++k) {
-#ifdef NRX_TD_ABLATE_TAPS     // timing experiment (wrong results): no scalar tap loads
-    const double ck = 0.25 + k;
-#else
     const double ck = c[k];
-#endif
 #pragma unroll
     for (int j = 0; j < R; ++j) {   // x[n + j - off - k] = window element 15 + j - k
       fr[j] = fma(ck, wr[TDP_FLEN - 1 + j - k], fr[j]);
@@ -304,12 +296,6 @@ __device__ __forceinline__ void tdp4_term(const char* __restrict__ q0, const cha
   }
 }
 
-#ifdef NRX_TD_CLOCK_PROBE
-__device__ unsigned long long g_td_probe[3];   // developer build: sum of s_memtime / s_memrealtime deltas over workgroups, count
-extern "C" int32_t nrx_debug_td_probe(unsigned long long* out3) {
-  return hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_td_probe), sizeof(unsigned long long) * 3) == hipSuccess ? 0 : -4;
-}
-#endif
 template <int NR, bool FLAT = false>      // FLAT: the groups share the (antenna, path) terms round robin (Nt not a multiple of GROUPS)
 __global__ void __launch_bounds__(TDP_TILE * TDP_GROUPS, 4)   // four waves per SIMD (two workgroups per CU): <= 128 VGPRs
 apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* __restrict__ gains1, int n_paths,
@@ -319,10 +305,6 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
   cd* xs = (cd*)smem;  // [nt][R][Q]
   constexpr int R = TDP_R;
   constexpr int PW = TDP_TILE / 64;      // waves of antenna group 0 = power-sum partials per workgroup
-#ifdef NRX_TD_CLOCK_PROBE
-  unsigned long long pt0, pr0;
-  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(pt0), "=s"(pr0)::"memory");
-#endif
   const int b = blockIdx.y;
   const int set = blockIdx.x / g.tiles_per_set, tile = blockIdx.x % g.tiles_per_set;
   const int n0 = g.start[set] + tile * (TDP_TILE * R);
@@ -440,15 +422,6 @@ apply_td_paths4_kernel(const cd* __restrict__ x, int nt, int64_t ns, const cd* _
       o3[2] = s2;
     }
   }
-#ifdef NRX_TD_CLOCK_PROBE
-  unsigned long long pt1, pr1;
-  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(pt1), "=s"(pr1)::"memory");
-  if (threadIdx.x == 0) {
-    atomicAdd(&g_td_probe[0], pt1 - pt0);
-    atomicAdd(&g_td_probe[1], pr1 - pr0);
-    atomicAdd(&g_td_probe[2], 1ull);
-  }
-#endif
 }
 
 // The same filter in float32 for the float32 waveform chain (the opt-in fast mode; the reference computes in complex128, so this
@@ -1035,28 +1008,6 @@ fold_precoder_kernel(const cd* __restrict__ gains, const cd* __restrict__ F, int
 constexpr int CS_THREADS = 512;
 constexpr int CS_NK = 12;      // subcarriers (one PRB)
 typedef const cd __attribute__((address_space(4))) * cgain_t;      // read-only in this kernel: wave-uniform rows come by scalar loads
-#ifdef NRX_CS_PROBE
-// developer build (tools/archive/probe_chan_setup.py): s_memtime at the phase boundaries of wave 0 of every workgroup, summed:
-// [0] tap matrix to LDS, [1] offset pass, [2] argmax, [3] twiddles, [4] matrix pass, [5] workgroups
-__device__ unsigned long long g_cs_probe[6];
-extern "C" int32_t nrx_debug_cs_probe(unsigned long long* out6, int32_t reset) {
-  if (out6 && hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_cs_probe), sizeof(unsigned long long) * 6) != hipSuccess) return -4;
-  if (reset) {
-    const unsigned long long z[6] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cs_probe), z, sizeof(z)) != hipSuccess) return -4;
-  }
-  return 0;
-}
-#define CS_STAMP(K)                                                                                         \
-  do {                                                                                                      \
-    unsigned long long pt_;                                                                                 \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pt_)::"memory"); \
-    if ((K) >= 0 && threadIdx.x == 0) atomicAdd(&g_cs_probe[(K)], pt_ - cs_prev);                           \
-    cs_prev = pt_;                                                                                          \
-  } while (0)
-#else
-#define CS_STAMP(K) do {} while (0)
-#endif
 template <int P>      // paths: a template parameter so that the per-tap / per-row register arrays are fully unrolled without guards
 __global__ void __launch_bounds__(CS_THREADS)
 chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff, int n_t_total, int nc, int nr, int nt,
@@ -1069,17 +1020,12 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
   __shared__ int besti[CS_THREADS / 64];
   __shared__ int off_s;
   const int b = blockIdx.x, tid = threadIdx.x, n_rt = nr * nt;
-#ifdef NRX_CS_PROBE
-  unsigned long long cs_prev = 0;
-  CS_STAMP(-1);
-#endif
   for (int i = tid; i < P * cl; i += CS_THREADS) {
     const int p = i / cl, l = i - p * cl;
     csT[(size_t)l * P + p] = coeff[i];
   }
   const cd* gb = gains + (size_t)b * n_t_total * n_rt * P;
   __syncthreads();
-  CS_STAMP(0);
   // ---- chanOffset = argmax_l sum_r | sum_{c<nc, t} cir[c][r][t][l] |   (channelmodel.py:345-346; first max): one tap per thread,
   // its coefficients in registers, the gains of a (c, r, t) row wave-uniform
   double bv = -1.0;
@@ -1108,7 +1054,6 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
   }
   // first maximum over the threads (largest value, smallest tap among equals -- np.argmax): inside the wave by shuffles, then
   // over the waves.  (A serial scan of 512 LDS entries by one thread was 84 k cycles of the workgroup's 1.46 M.)
-  CS_STAMP(1);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const double ov = __shfl_xor(bv, o, 64);
@@ -1126,7 +1071,6 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
     off_s = idx;
   }
   __syncthreads();
-  CS_STAMP(2);
   // ---- channel matrix at subcarriers k0 .. k0 + 11 (channelmodel.py:362-400 at those bins: direct DFT of the CIR placed
   // circularly shifted by chanOffset).  The twiddle of (tap, bin) is the same for every row: tabulated once.
   const int o = off_s;
@@ -1143,7 +1087,6 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
     W[i] = w;
   }
   __syncthreads();
-  CS_STAMP(3);
   // one (instant, rx, tx) row and one half of the 12 bins per thread: the row's gains in registers, the CIR value of a tap (computed
   // by both halves, same expression) feeds the thread's 6 bins.  (With all 12 bins per thread the 24 gains, 12 accumulators and a
   // tap's coefficients and twiddles did not fit in the 256 registers of a 512-thread workgroup: 9 gains were re-read from scratch
@@ -1180,11 +1123,6 @@ chan_setup_kernel(const cd* __restrict__ gains, const double* __restrict__ coeff
 #pragma unroll
     for (int k = 0; k < NKH; ++k) H[(((size_t)b * nc + c) * CS_NK + kh + k) * n_rt + rt] = acc[k];
   }
-#ifdef NRX_CS_PROBE
-  __syncthreads();
-  CS_STAMP(4);
-  if (tid == 0) atomicAdd(&g_cs_probe[5], 1ull);
-#endif
 }
 }  // namespace
 

@@ -173,41 +173,6 @@ td_path_spectra_kernel(const double* __restrict__ taps, const int32_t* __restric
 // LDS: NX transform buffers, then the twiddles of passes B (16 x 3) and C (2 x 3): only pass A's live in registers (the prefetched
 // input block needs the others' 24 VGPRs).  During the H set-up the transform buffers hold the set's gains.
 constexpr int OS_TWL = 64;
-#ifndef NRX_OS_ABLATE
-#define NRX_OS_ABLATE 0       // developer timing ablations (wrong results): 1 = one path in the H set-up, 2 = no prefetch of the next block
-#endif
-#ifndef NRX_OS_TW_LDS
-#define NRX_OS_TW_LDS 1       // twiddles of passes B and C from LDS (1) or in registers (0)
-#endif
-#ifndef NRX_OS_PAIRBAR
-#define NRX_OS_PAIRBAR 0      // the passes of ONE transform synchronise its two waves only (progress words in LDS); 0: workgroup barriers
-#endif
-#ifndef NRX_OS_G_LDS
-#define NRX_OS_G_LDS 1        // the set's gains through LDS (1) or by scalar loads (0)
-#endif
-
-// Barrier of the two waves of one transform: a pass of transform f touches buffer f only, and buffer f is touched by waves 2f and
-// 2f + 1 alone, so the five barriers between the passes need not stop the other transforms (whose LDS-write phases then overlap this
-// one's arithmetic).  Arrive = store the barrier's number in this wave's progress word (one lane; the LDS runs a wave's instructions in
-// order, so the word lands behind the pass's writes), wait = poll the partner's word.  The two barriers around the pointwise phase,
-// which reads and writes every buffer, stay workgroup barriers.
-__device__ __forceinline__ void pair_barrier(uint32_t& k, uint32_t own_addr, uint32_t partner_addr) {
-#if NRX_OS_PAIRBAR
-  k += 1;
-  uint32_t kv = k, seen;
-  asm volatile("s_mov_b64 exec, 1\n\t"
-               "ds_write_b32 %[own], %[kv]\n\t"
-               "s_mov_b64 exec, -1\n"
-               "L_pairbar_%=:\n\t"
-               "ds_read_b32 %[seen], %[partner]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               "v_cmp_gt_u32_e32 vcc, %[ks], %[seen]\n\t"
-               "s_cbranch_vccnz L_pairbar_%=\n\t"
-               : [seen] "=&v"(seen) : [own] "v"(own_addr), [kv] "v"(kv), [partner] "v"(partner_addr), [ks] "s"(k) : "vcc", "memory");
-#else
-  __syncthreads();
-#endif
-}
 
 template <int NX>       // Nr = Nt = NX in {1, 2, 4}; 128 * NX threads
 __global__ void __launch_bounds__(128 * NX, 2)
@@ -216,12 +181,6 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* bufs = (cd*)smem;                     // [NX][OS_ELEMS]
   cd* twl = bufs + NX * OS_ELEMS;           // [OS_TWL]
-  // progress words of pair_barrier behind the twiddles: byte addresses of this wave's and its partner's (the other wave of the transform)
-  const uint32_t pb_base = (uint32_t)(sizeof(cd) * ((size_t)NX * OS_ELEMS + OS_TWL));
-  const uint32_t pb_own = pb_base + 4u * (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const uint32_t pb_partner = pb_base + 4u * (uint32_t)(__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) ^ 1);
-  uint32_t pb_k = 0;
-  if ((threadIdx.x & 63) == 0) *(volatile uint32_t*)(smem + pb_own) = 0u;
   constexpr int PP = 8 / NX;                // positions a thread owns in the pointwise phase
   constexpr int WAVES = 2 * NX;
   const int tid = threadIdx.x;
@@ -273,22 +232,14 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
         for (int k = 0; k < PP; ++k) H[r][t][k] = cd(0.0, 0.0);
     {
       const cd* gb = gains1 + ((size_t)b * g.n_sets + set) * NX * NX * n_paths;      // [r][t][p]
-#if NRX_OS_G_LDS
       cd* gl = bufs;
       for (int i = tid; i < NX * NX * n_paths; i += 128 * NX) gl[i] = gb[i];
-#else
-      const cd* gl = gb;
-#endif
       __syncthreads();
       const cd* sp = spec + PP * tid;
       cd c[PP];
 #pragma unroll
       for (int k = 0; k < PP; ++k) c[k] = sp[k];
-#if NRX_OS_ABLATE == 1
-      const int np = 1;
-#else
       const int np = n_paths;
-#endif
       for (int p = 0; p < np; ++p) {
         cd cn[PP];
         const cd* spn = sp + (size_t)(p + 1 < np ? p + 1 : p) * OSN;
@@ -312,13 +263,8 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
     cd* buf = bufs + (size_t)f * OS_ELEMS;
     const int ia = osi(j), ib = os_base_b(j), ic = os_base_c(j);
     const int ip = osi(PP * tid);           // pointwise phase: positions PP*tid .. +PP-1 (inside one 16-block) of every transform
-#if NRX_OS_TW_LDS
     const cd* twb = twl + 3 * (j & 15);
     const cd* twc = twl + 48 + 3 * (j & 1);
-#else
-    const cd twb[3] = {tw[64 * (j & 15)], tw[128 * (j & 15)], tw[256 * (j & 15)]};
-    const cd twc[3] = {tw[512 * (j & 1)], tw[1024 * (j & 1)], tw[2048 * (j & 1)]};
-#endif
     // power sums (Waveform.getRePower, waveform.py:107-117): the nfft samples of the symbol from round(cpLen / 2) on
     const bool want_pow = pow_acc && set < g.n_sets - 1;
     const int poff = (int)rint((double)(n_end - s0 - pow_nfft) * 0.5);
@@ -329,14 +275,12 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = pf[m];
       dif3(v, wa1, wa2, wa4);
-      pair_barrier(pb_k, pb_own, pb_partner);       // (the previous block's inverse pass A has read this transform's buffer)
+      __syncthreads();       // (the previous block's inverse pass A has read this transform's buffer)
 #pragma unroll
       for (int m = 0; m < 8; ++m) buf[ia + 136 * m] = v[m];
-#if NRX_OS_ABLATE != 2
       if (n0 + V < n_end) load8(n0 + V, pf);
       __builtin_amdgcn_sched_barrier(0);
-#endif
-      pair_barrier(pb_k, pb_own, pb_partner);
+      __syncthreads();
       {
         const cd w1 = twb[0], w2 = twb[1], w4 = twb[2];
 #pragma unroll
@@ -345,7 +289,7 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
 #pragma unroll
         for (int m = 0; m < 8; ++m) buf[ib + 17 * m] = v[m];
       }
-      pair_barrier(pb_k, pb_own, pb_partner);
+      __syncthreads();
       {
         const cd w1 = twc[0], w2 = twc[1], w4 = twc[2];
 #pragma unroll
@@ -396,7 +340,7 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
 #pragma unroll
         for (int m = 0; m < 8; ++m) buf[ic + 2 * m] = v[m];
       }
-      pair_barrier(pb_k, pb_own, pb_partner);
+      __syncthreads();
       {
         const cd w1 = twb[0], w2 = twb[1], w4 = twb[2];
 #pragma unroll
@@ -405,7 +349,7 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
 #pragma unroll
         for (int m = 0; m < 8; ++m) buf[ib + 17 * m] = v[m];
       }
-      pair_barrier(pb_k, pb_own, pb_partner);
+      __syncthreads();
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = buf[ia + 136 * m];
       dit3(v, wa1, wa2, wa4);
@@ -423,9 +367,6 @@ apply_td_os_kernel(const cd* __restrict__ x, int ns, const cd* __restrict__ gain
           }
         }
       }
-#if NRX_OS_ABLATE == 2
-      if (n0 + V < n_end) load8(n0 + V, pf);
-#endif
     }
   }
   if (pow_acc) {        // one (sum re, sum im, sum |y|^2) triple per wave, in a fixed order: reproducible, no atomics
@@ -488,7 +429,7 @@ extern "C" int32_t nrx_apply_td_os_f64(const void* x, int32_t n_items, int32_t n
   NRX_REQUIRE(n_items <= 65535, NRX_E_SHAPE, "nrx_apply_td_os: %d items exceed the grid's 65535 (split the batch)", n_items);
   const cd* tw = nrx::fft_twiddle_table((hipStream_t)stream);
   NRX_REQUIRE(tw, NRX_E_HIP, "nrx_apply_td_os: FFT twiddle table unavailable");
-  const size_t lds = sizeof(cd) * ((size_t)n_rx * OS_ELEMS + OS_TWL) + 64;      // (+ 16 progress words; the set's Nr x Nt x n_paths gains fit the transform buffers)
+  const size_t lds = sizeof(cd) * ((size_t)n_rx * OS_ELEMS + OS_TWL);      // (the set's Nr x Nt x n_paths gains fit the transform buffers)
   const dim3 grid(n_sets, n_items);
 #define NRX_OS_CASE(NX)                                                                                                         \
   case NX:                                                                                                                      \

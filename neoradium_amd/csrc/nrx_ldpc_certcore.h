@@ -6,15 +6,6 @@
 #include <type_traits>
 #include "nrx_ldpc_graph.h"
 
-// NRX_CERT_NT=1: the read-back of the parked decoder state (read exactly once) is non-temporal; see NRX_DEC3_NT in nrx_ldpc_dec3.hip.
-#ifndef NRX_CERT_NT
-#define NRX_CERT_NT 0
-#endif
-#if NRX_CERT_NT
-#define NRX_CERT_LD(p) __builtin_nontemporal_load(p)
-#else
-#define NRX_CERT_LD(p) (*(p))
-#endif
 namespace nrx_certcore {
 using namespace nrx_ldpc;
 
@@ -137,11 +128,11 @@ __device__ __forceinline__ bool certify_on_chip(const Params& cp, double lam_all
     constexpr int L = decltype(lc)::value;
     const double* sq = st;
     asm volatile("" : "+v"(sq));
-    n_pm1 = NRX_CERT_LD(&sq[(size_t)(SL::M1 + L) * ZC]);
-    n_pm2 = NRX_CERT_LD(&sq[(size_t)(SL::M2 + L) * ZC]);
-    if constexpr (Y::has_ext(L)) n_rx = NRX_CERT_LD(&sq[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC]);
-    if constexpr (Y::wide(L)) n_word = (uint32_t)__double_as_longlong(NRX_CERT_LD(&sq[(size_t)(SL::WORDS + Y::wide_idx(L)) * ZC]));
-    else n_word = (uint32_t)__double_as_longlong(NRX_CERT_LD(&sq[(size_t)(SL::WORDS + SL::NW + Y::narrow_idx(L) / 2) * ZC]));
+    n_pm1 = (*(&sq[(size_t)(SL::M1 + L) * ZC]));
+    n_pm2 = (*(&sq[(size_t)(SL::M2 + L) * ZC]));
+    if constexpr (Y::has_ext(L)) n_rx = sq[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC];
+    if constexpr (Y::wide(L)) n_word = (uint32_t)__double_as_longlong(sq[(size_t)(SL::WORDS + Y::wide_idx(L)) * ZC]);
+    else n_word = (uint32_t)__double_as_longlong(sq[(size_t)(SL::WORDS + SL::NW + Y::narrow_idx(L) / 2) * ZC]);
     n_fw1 = wrow[(2 * L) * ZC];
     n_fw2 = wrow[(2 * L + 1) * ZC];
   };

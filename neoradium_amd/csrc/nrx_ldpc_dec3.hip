@@ -27,45 +27,13 @@
 #include "nrx_ldpc_certcore.h"
 #include "nrx_common.h"
 
-#ifndef NRX_DEC3_HYB_RC
-#define NRX_DEC3_HYB_RC 12
-#endif
-#ifndef NRX_DEC3_HYB_PF
-#define NRX_DEC3_HYB_PF 2
-#endif
-// NRX_DEC3_NT=1 marks the streamed-once global traffic (the LLRs of the fill, the parked decoder state and its reload) non-temporal, so
-// that it does not push the certificate's slack scratch (nrx_ldpc_certcore.h) out of the XCD's L2.  Measured (tools/r5/nt_experiment.sh,
-// DESIGN.md 4.3): stage-1 traffic of the certified schedule 17.1 -> 16.1 GB, step 24.3 -> 24.5 ms -- the scratch of the workgroups of one
-// XCD (5.5 MB) does not fit its 4 MB L2 either way.  Default off.
-#ifndef NRX_DEC3_NT
-#define NRX_DEC3_NT 0
-#endif
-// NRX_DEC3_SKIPZ=1 (default): a wave whose 64 check rows of the LAST layer all have an extension LLR of exactly 0 leaves that layer out --
+// SKIPZ (see the kernel): a wave whose 64 check rows of the LAST layer all have an extension LLR of exactly 0 leaves that layer out --
 // each of those rows is the exact no-op of DESIGN 4.2a (min1 = 0 at the extension edge: +-0 to every other column), here per wave
 // instead of per layer.  The last transmitted extension column is the one that is partly filled: 48 of 384 rows of layer 14 at the
 // metric configuration (E_r - 34 Zc, no fillers), all in one wave: five of a code block's six waves skip 7 of the 157 edges.  Two copies of the iteration loop (with and
 // without the last layer's body, same barriers) behind a wave-uniform branch: a test per layer inside ONE loop turned the layer's
 // register updates into copies at the join (+112 VALU instructions per iteration).  Whole decodes only (MODE 0): a parked state keeps
 // the posteriors of the extension columns, from which the zero LLR cannot be read back.
-#ifndef NRX_DEC3_SKIPZ
-#define NRX_DEC3_SKIPZ 1
-#endif
-// NRX_DEC3_PREFETCH=1: the elements of the next layer that no layer since the previous barrier has written are read AHEAD of the barrier
-// in front of it (Lay::pre_edge; 56 of the 110 LDS reads of the 11 layers with a barrier in front), so that behind the barrier a wave
-// starts on them at once.  Built, bit-identical, and SLOWER (tools/r5/prefetch_experiment.sh: 32.0 against 31.1 ms per step): behind a
-// barrier the first data is back before the SIMD's three waves have issued their 3 x 18 selects + loads anyway, while a wave now waits
-// for its read-ahead loads in front of the barrier (the last wave's wait delays everyone), and the values live across the barrier cost
-// 12 scratch accesses per iteration instead of 4.  Default off.
-#ifndef NRX_DEC3_PREFETCH
-#define NRX_DEC3_PREFETCH 0
-#endif
-#if NRX_DEC3_NT
-#define NRX_LD_STREAM(p) __builtin_nontemporal_load(p)
-#define NRX_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define NRX_LD_STREAM(p) (*(p))
-#define NRX_ST_STREAM(p, v) (*(p) = (v))
-#endif
 namespace nrx_dec3 {
 using namespace nrx_ldpc;
 
@@ -203,70 +171,13 @@ __device__ __forceinline__ void sel_fma_first(double& x, uint32_t& idx, uint64_t
                : [x] "+v"(x), [idx] "+v"(idx), [seen] "+s"(seen) : [im] "s"(im), [u] "v"(u), [p1] "v"(p1), [p2] "v"(p2), [j] "n"(J) : "scc");
 }
 
-#ifdef NRX_DEC3_PROBE
-// Developer build only (tools/archive/probe_dec3.sh): s_memtime stamps at the phase boundaries of every layer, accumulated per
-// wave in SGPRs and summed here.  [0..3] wide layers (degree > 10), [4..7] narrow layers: pass 1 (LDS reads + t = r - m),
-// min-sum, pass 2 (+ write drain + next layer's mask loads), barrier; [8] waves, [9] layers stamped.
-__device__ unsigned long long g_probe[14];   // [10] fill (+ its barrier), [11] tail (hard decisions / CRC + merge, + its barrier), [12] code-block rounds
-#define PROBE_STAMP(K)                                                                   \
-  do {                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    unsigned long long pt_;                                                              \
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pt_)::"memory");          \
-    const uint32_t lo_ = (uint32_t)pt_;                                                  \
-    if ((K) >= 0) pk_acc[(K)] += lo_ - pk_prev;                                          \
-    pk_prev = lo_;                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-  } while (0)
-#else
-#define PROBE_STAMP(K) do {} while (0)
-#endif
 
 // Wave priority by progress inside a layer.  The SIMD issues one VALU instruction per 4 cycles and, among ready waves of
 // equal priority, always picks the oldest (tools/ubench/issue_probe: three waves of one stream finish at T, 2T, 3T).  With a
 // barrier per layer that leaves the youngest wave to run the end of every layer alone, at its own serial speed.  Lowering
 // a wave's priority as it advances through the layer (3 -> 0) lets the waves that are behind go first, so the three waves
 // of a SIMD reach the barrier together.
-#ifndef NRX_DEC3_PRIO
-#define NRX_DEC3_PRIO 1
-#endif
-#if NRX_DEC3_PRIO == 1
 #define LAYER_PRIO(Q) __builtin_amdgcn_s_setprio(3 - (Q))
-#elif NRX_DEC3_PRIO == 2
-#define LAYER_PRIO(Q) __builtin_amdgcn_s_setprio(Q)
-#else
-#define LAYER_PRIO(Q) do {} while (0)
-#endif
-
-// ---- Barrier of ONE code block's six waves (round 5).  A workgroup holds two code blocks (slots) that share nothing, yet s_barrier
-// makes each wait for the other 11 times per iteration -- and a 384-thread workgroup per code block is not an option (a CU never
-// co-schedules two of them at this register count, profiles/r4_occ_test.txt).  So the layer barriers are done in software per slot:
-// every wave keeps a progress word in LDS (the padding in front of the columns); arriving = storing the barrier's number there (one
-// lane; the LDS executes a wave's instructions in order, so the word lands behind the layer's column writes and no drain is needed),
-// waiting = polling the slot's six words until none is behind.  The other slot's waves keep the SIMDs busy meanwhile.
-#ifndef NRX_DEC3_WSPEC
-#define NRX_DEC3_WSPEC 0      // one copy of the iteration loop per wave index (see iter_loop); default off: measured slower / no faster
-#endif
-#ifndef NRX_DEC3_SLOTBAR
-#define NRX_DEC3_SLOTBAR 0
-#endif
-#ifndef NRX_DEC3_SLOT_SKEW
-#define NRX_DEC3_SLOT_SKEW 0                 // start of slot 1's iteration loop delayed by this many x 64 cycles
-#endif
-constexpr uint32_t SLOTBAR_BASE = 2048;      // byte offset inside the padding: [slot][8] words
-__device__ __forceinline__ void slot_barrier(uint32_t& k, uint32_t own_addr, uint32_t poll_addr) {
-  k += 1;
-  uint32_t kv = k, seen;
-  asm volatile("s_mov_b64 exec, 1\n\t"
-               "ds_write_b32 %[own], %[kv]\n\t"
-               "s_mov_b64 exec, -1\n"
-               "L_slotbar_%=:\n\t"
-               "ds_read_b32 %[seen], %[poll]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               "v_cmp_gt_u32_e32 vcc, %[ks], %[seen]\n\t"
-               "s_cbranch_vccnz L_slotbar_%=\n\t"
-               : [seen] "=&v"(seen) : [own] "v"(own_addr), [kv] "v"(kv), [poll] "v"(poll_addr), [ks] "s"(k) : "vcc", "memory");
-}
 
 template <int BG> constexpr bool ext_shifts_are_zero() {
   using B = G<BG>;
@@ -404,10 +315,6 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   static_assert(Y::plan_rot.ok, "barrier placement leaves a column hazard");
   constexpr int NEXT = Y::n_ext() > 0 ? Y::n_ext() : 1;
 
-  // slot barrier (see slot_barrier): byte addresses of this wave's progress word and of the word this lane polls (wave lane % 6 of the slot)
-  const uint32_t sb_own = SLOTBAR_BASE + 32u * (uint32_t)slot + 4u * (uint32_t)__builtin_amdgcn_readfirstlane(z >> 6);
-  const uint32_t sb_poll = SLOTBAR_BASE + 32u * (uint32_t)slot + 4u * (uint32_t)((z & 63) % (ZC / 64));
-  uint32_t bar_k = 0;
   double m1[B::ROWS], m2[B::ROWS];
   double rext[NEXT];                                       // posterior of each layer's extension column, element z
   uint32_t sgw[Y::n_wide() > 0 ? Y::n_wide() : 1];
@@ -417,7 +324,6 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   double f1 = 0.0;                                         // column 1 handed from a layer to its successor (Lay::fwd1)
   static_assert(RC == RA || (!FUSED && (MODE == 0 || MODE == 8) && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
   static_assert((MODE & 8) == 0 || MODE == 8, "MODE bit 3 goes with a whole decode");
-  constexpr bool WSPEC = NRX_DEC3_WSPEC != 0 && FUSED && MODE == 0 && RC == RA && RA <= 15 && NS == 2 && ZC == 384;
   constexpr bool HYB = RC < RA;
   // MODE bit 3 (whole decodes: the hybrids and the fused entry): the layers beyond the caller's row count (FuseGeom::rows_live) are left
   // out instead of run as no-ops.  A separate instantiation: the test costs 1.5-3 % more VALU instructions per iteration (copies at the
@@ -432,11 +338,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     if (Y::give1(L) && L == B::ROWS - 1) return true;
     return L < n;
   };
-  constexpr bool PREF = NRX_DEC3_PREFETCH != 0 && MODE == 0 && !HYB && !WSPEC && Y::max_pre() > 0;
-  constexpr int NPRE = PREF ? Y::max_pre() : 1;
   constexpr int LAST = B::ROWS - 1;
-  constexpr bool SKIPZ = NRX_DEC3_SKIPZ != 0 && MODE == 0 && !HYB && Y::has_ext(LAST) && !Y::fwd1(LAST) && !Y::give1(LAST) && !Y::fwd1(0);
-  constexpr int PF = NRX_DEC3_HYB_PF;                      // streamed layers fetched ahead
+  constexpr bool SKIPZ = MODE == 0 && !HYB && Y::has_ext(LAST) && !Y::fwd1(LAST) && !Y::give1(LAST) && !Y::fwd1(0);
+  constexpr int PF = 2;                                    // streamed layers fetched ahead (1 / 3 / 4 measured slower, LAB_NOTES 4.1h)
   static_assert(!HYB || (RA - RC > PF && (RA - RC) % PF == 0), "the ring slot of a streamed layer is (L - RC) mod PF in every iteration");
   double pf_m1[PF] = {}, pf_m2[PF] = {}, pf_rx[PF] = {};
   typedef double __attribute__((address_space(1))) * gD;
@@ -450,9 +354,6 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   };
   auto ws_off = [](int L, int a) constexpr -> size_t { return ((size_t)(L - RC) * 3 + a) * ZC * sizeof(double); };
 
-#ifdef NRX_DEC3_PROBE
-  uint32_t pk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pk_prev = 0, pk_layers = 0, pk_rounds = 0;
-#endif
   const int32_t* sel = nullptr;
   {
     const fargs_t fa0 = fuse_args();
@@ -460,7 +361,6 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     if (sel) n_cb = *fa0->n_sel;                            // (wave-uniform; a workgroup beyond the count leaves at once)
   }
   for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
-    PROBE_STAMP(-1);
     const int cbi = cb0 + slot;                             // position in the work list
     int one = 1;
     asm volatile("" : "+s"(one));                          // keeps the per-layer `if (live)` a real branch (see dec2)
@@ -538,31 +438,31 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       const double* st = fuse_args()->state + (size_t)cbq * SL::NF * ZC + zl;
       static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value + 1;
-        Ps[c * ZS + zl] = NRX_LD_STREAM(&st[(size_t)(SL::COL + c - 1) * ZC]);
+        Ps[c * ZS + zl] = *(&st[(size_t)(SL::COL + c - 1) * ZC]);
       });
-      c0 = NRX_LD_STREAM(&st[(size_t)SL::C0 * ZC]);
-      f1 = NRX_LD_STREAM(&st[(size_t)SL::F1 * ZC]);
+      c0 = *(&st[(size_t)SL::C0 * ZC]);
+      f1 = *(&st[(size_t)SL::F1 * ZC]);
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
-        m1[L] = NRX_LD_STREAM(&st[(size_t)(SL::M1 + L) * ZC]);
-        m2[L] = NRX_LD_STREAM(&st[(size_t)(SL::M2 + L) * ZC]);
-        if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = NRX_LD_STREAM(&st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC]);
+        m1[L] = *(&st[(size_t)(SL::M1 + L) * ZC]);
+        m2[L] = *(&st[(size_t)(SL::M2 + L) * ZC]);
+        if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = *(&st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC]);
       });
       static_for<SL::NW>([&](auto i) __attribute__((always_inline)) {
-        sgw[decltype(i)::value] = (uint32_t)__double_as_longlong(NRX_LD_STREAM(&st[(size_t)(SL::WORDS + decltype(i)::value) * ZC]));
+        sgw[decltype(i)::value] = (uint32_t)__double_as_longlong(*(&st[(size_t)(SL::WORDS + decltype(i)::value) * ZC]));
       });
       static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
-        sgn[decltype(i)::value] = (uint32_t)__double_as_longlong(NRX_LD_STREAM(&st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC]));
+        sgn[decltype(i)::value] = (uint32_t)__double_as_longlong(*(&st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC]));
       });
     } else {
       double xs[B::CORE - 2 + NEXT];      // (the hybrid only touches the entries of its on-chip rows)
       static_for<B::CORE - 2>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        xs[c] = NRX_LD_STREAM(&in[addr(c * ZC, 0)]);
+        xs[c] = *(&in[addr(c * ZC, 0)]);
       });
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
-        if constexpr (Y::has_ext(L) && L < RC) xs[B::CORE - 2 + Y::ext_idx(L)] = NRX_LD_STREAM(&in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))]);   // element of row (z + sigma_L)
+        if constexpr (Y::has_ext(L) && L < RC) xs[B::CORE - 2 + Y::ext_idx(L)] = *(&in[addr((Y::ext_col(L) - 2) * ZC, Y::sigma(ILS, ZC, L))]);   // element of row (z + sigma_L)
       });
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (HYB) {       // streamed rows: zero minima, the extension LLR (or 0 beyond the rows that run) straight to the workspace
@@ -616,12 +516,6 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         }
       }
     }
-#if NRX_DEC3_SLOTBAR
-    if constexpr (NS == 2) {                               // this wave's progress word back to zero (the fill's barrier publishes it)
-      if ((z & 63) == 0) *(volatile uint32_t*)((char*)Praw + sb_own) = 0u;
-      bar_k = 0;
-    }
-#endif
     if constexpr (!(FUSED && (MODE & 2))) {
       c0 = 0.0;                                            // punctured column (ldpc.py:1536-1538)
       static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
@@ -658,46 +552,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       wcur[decltype(jc)::value] = wm[B::row_start(0) + decltype(jc)::value];
     });
 
-    PROBE_STAMP(8);
-#if NRX_DEC3_SLOTBAR && NRX_DEC3_SLOT_SKEW > 0
-    // the two slots run the same program from the same barrier and stay in phase: both sit in the bubble behind a layer barrier
-    // (progress-word read, then the next layer's LDS reads) at the same time.  Slot 1 starts late by a fraction of a layer, so that one
-    // slot's bubble falls into the other's arithmetic.
-    if constexpr (NS == 2) { if (slot == 1) __builtin_amdgcn_s_sleep(NRX_DEC3_SLOT_SKEW); }
-#endif
-    // WV = this wave's index inside its code block, or -1 (generic): with the wave known at compile time the wrap-around of an
-    // edge is wave-uniform for every wave but the one whose lanes straddle the column end (64 WV + lane + shift >= Zc), and the
-    // per-lane address select goes (NRX_DEC3_WSPEC: VERDICT r4 #4 -- six copies of the loop, one per wave; measured in DESIGN 4.1).
-    // SL: the copy without the last layer's body (NRX_DEC3_SKIPZ)
-    auto iter_loop = [&](auto wvc, auto slc) __attribute__((always_inline)) {
-    constexpr int WV = decltype(wvc)::value;
+    // SL: the copy of the iteration loop without the last layer's body (see SKIPZ)
+    auto iter_loop = [&](auto slc) __attribute__((always_inline)) {
     constexpr bool SL = decltype(slc)::value;
-    // read-ahead values of the layer that comes next and the LDS byte address each came from (its write-back goes there)
-    double tp[NPRE];
-    uint32_t ap[NPRE];
-    // the read-ahead loads of layer Ln (its wrap masks are in wcur): issued at the end of the layer in front of it
-    auto read_ahead = [&](auto lnc, uint32_t zb, uint32_t zbw, uint32_t zbh, uint32_t zbwh) __attribute__((always_inline)) {
-      constexpr int Ln = decltype(lnc)::value;
-      constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
-      static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int e = B::row_start(Ln) + j;
-        if constexpr (Y::pre_edge(Ln, e)) {
-          constexpr int k = Y::pre_idx(Ln, e);
-          constexpr uint32_t off = 8u * (uint32_t)(B::col(e) * ZS + Y::eff_shift(ILS, ZC, Ln, e));
-          const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
-          if constexpr (off < 65536) { ap[k] = wraps ? zbw : zb; tp[k] = *(const double*)((const char*)Praw + ap[k] + off); }
-          else { ap[k] = wraps ? zbwh : zbh; tp[k] = *(const double*)((const char*)Praw + ap[k] + (off - HI)); }
-        }
-      });
-    };
-    if constexpr (PREF) {
-      if (live) {
-        uint32_t zq0 = zb0;
-        asm volatile("" : "+v"(zq0));
-        read_ahead(std::integral_constant<int, 0>{}, zq0, zq0 - zc8, zq0 + HI, zq0 - zc8 + HI);
-      }
-    }
     for (int it = 0; it < n_iter; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
@@ -740,14 +597,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
               wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
             });
-            if constexpr (PREF && Y::plan_rot.need[Ln]) read_ahead(std::integral_constant<int, Ln>{}, zb, zbw, zbh, zbwh);
           }
         } else if (__builtin_expect(runs, 1)) {
           double t[D];
-#ifdef NRX_DEC3_PROBE
-          PROBE_STAMP((Y::wide((L + B::ROWS - 1) % B::ROWS) ? 3 : 7));   // barrier of the previous layer
-          pk_layers += 1;
-#endif
           // priority steps at about a quarter, a half and three quarters of the layer's VALU work (5 + 4 + 5 per edge)
           constexpr int PQ1 = (7 * D) / 10 < D - 1 ? (7 * D) / 10 : D - 1, PQ2 = D / 2 < 2 ? 2 : D / 2, PQ3 = (3 * D) / 10 < 1 ? 1 : (3 * D) / 10;
           LAYER_PRIO(Y::prio_q(L, 0));
@@ -761,19 +613,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               t[j] = c0;
             } else if constexpr (col == 1 && Y::fwd1(L)) {
               t[j] = f1;
-              if constexpr (PREF && !Y::give1(L)) {         // (this layer writes the column back to LDS: the address of its element)
-                constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
-                const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
-                ad[j] = off < 65536 ? (wraps ? zbw : zb) : (wraps ? zbwh : zbh);
-              }
-            } else if constexpr (PREF && Y::pre_edge(L, E0 + j)) {
-              t[j] = tp[Y::pre_idx(L, E0 + j)];             // read ahead of the barrier by the layer in front
-              ad[j] = ap[Y::pre_idx(L, E0 + j)];
             } else {
               constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
-              constexpr int sh = Y::eff_shift(ILS, ZC, L, E0 + j);
-              constexpr bool w_none = WV >= 0 && 64 * WV + 63 + sh < ZC, w_all = WV >= 0 && 64 * WV + sh >= ZC;
-              const bool wraps = (w_none || w_all) ? w_all : __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
+              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);            // z + shift >= Zc
               if constexpr (off < 65536) { ad[j] = wraps ? zbw : zb; t[j] = *(const double*)((const char*)Praw + ad[j] + off); }
               else { ad[j] = wraps ? zbwh : zbh; t[j] = *(const double*)((const char*)Praw + ad[j] + (off - HI)); }
             }
@@ -798,33 +640,14 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // ---- pass 1b: t_j = r_j - msg_old_j = fma(-u_j, argmin ? pm2 : pm1, r_j)  (ldpc.py:1550-1553); the extension
           // column's r comes from its register
           if constexpr (EXT) t[D - 1] = L < RC ? rext[Y::ext_idx(L)] : crx;
-          if constexpr (!PREF) {
-            uint32_t wrun = word << (top - (D - 1));           // sign of edge 0 at bit 31; doubled per edge
-            static_for<D>([&](auto jc) __attribute__((always_inline)) {
-              constexpr int j = decltype(jc)::value;
-              const double u = unit_of(uv, wrun);
-              if constexpr (j < D - 1) wrun = dbl(wrun);
-              if constexpr (j == PQ1 && Y::prio_q(L, 1) != Y::prio_q(L, 0)) LAYER_PRIO(Y::prio_q(L, 1));
-              t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
-            });
-          } else {
-            // the edges whose value is in a register already first (column 0, a handed-over column 1, the extension column, the
-            // elements read ahead of the barrier), then the ones whose loads were issued behind it; the sign of edge j by its own shift
-            auto early = [](int j) constexpr -> bool {
-              const int col = B::col(E0 + j);
-              return col == 0 || (col == 1 && Y::fwd1(L)) || col >= B::CORE || Y::pre_edge(L, E0 + j);
-            };
-            static_for<2 * D>([&](auto jc) __attribute__((always_inline)) {
-              constexpr int j = decltype(jc)::value % D;
-              constexpr bool first = decltype(jc)::value < D;
-              if constexpr (early(j) == first) {
-                const double u = unit_of(uv, word << (top - (D - 1) + j));
-                t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
-              }
-              if constexpr (!first && j == PQ1 && Y::prio_q(L, 1) != Y::prio_q(L, 0)) LAYER_PRIO(Y::prio_q(L, 1));
-            });
-          }
-          PROBE_STAMP(WIDE ? 0 : 4);
+          uint32_t wrun = word << (top - (D - 1));           // sign of edge 0 at bit 31; doubled per edge
+          static_for<D>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const double u = unit_of(uv, wrun);
+            if constexpr (j < D - 1) wrun = dbl(wrun);
+            if constexpr (j == PQ1 && Y::prio_q(L, 1) != Y::prio_q(L, 0)) LAYER_PRIO(Y::prio_q(L, 1));
+            t[j] = sel_fnma_x<j>(t[j], oidx, u, om1, om2);
+          });
           // ---- min-sum (ldpc.py:1556-1564): two smallest magnitudes by min/max; the signs of the t_j are collected (edge 0
           // ends highest) and their parity is a population count
           static_assert(D >= 2, "a check row has at least two edges");
@@ -868,19 +691,6 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             *wsL(wsb, ws_off(L, 0), zo8) = nm1;
             *wsL(wsb, ws_off(L, 1), zo8) = nm2;
           }
-          PROBE_STAMP(WIDE ? 1 : 5);
-          if constexpr (PREF) {
-            // the masks of the next layer, here: every LDS read of this layer has been consumed (scalar loads return out of order, so
-            // with one of them in flight a wait for LDS data can only be a wait for everything), the write-back goes to the addresses
-            // kept in ad[], and pass 2 is long enough for them to arrive before the read-ahead at its end
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int Lm = (L + 1) % B::ROWS;
-            constexpr int DCm = Y::has_ext(Lm) ? Y::deg(Lm) - 1 : Y::deg(Lm);
-            static_for<DCm>([&](auto jc) __attribute__((always_inline)) {
-              wcur[decltype(jc)::value] = wml[B::row_start(Lm) + decltype(jc)::value];
-            });
-            __builtin_amdgcn_sched_barrier(0);
-          }
           // ---- pass 2: r_j = t_j + msg_new_j = fma(u_j, first argmin ? pm2 : pm1, t_j), written back to the element it was
           // read from.  The FIRST entry equal to min1 gets min2 (np.argmin, ldpc.py:1558-1570).
           uint32_t idx = 0;
@@ -893,16 +703,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
               f1 = t[j];                                    // the next layer takes it from here and writes the column itself
             } else if constexpr (col < B::CORE) {
               constexpr uint32_t off = 8u * (uint32_t)(col * ZS + Y::eff_shift(ILS, ZC, L, E0 + j));
-              constexpr int sh = Y::eff_shift(ILS, ZC, L, E0 + j);
-              constexpr bool w_none = WV >= 0 && 64 * WV + 63 + sh < ZC, w_all = WV >= 0 && 64 * WV + sh >= ZC;
-              if constexpr (PREF) {      // (the address this element was read from)
-                if constexpr (off < 65536) *(double*)((char*)Praw + ad[j] + off) = t[j];
-                else *(double*)((char*)Praw + ad[j] + (off - HI)) = t[j];
-              } else {
-                const bool wraps = (w_none || w_all) ? w_all : __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
-                if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
-                else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
-              }
+              const bool wraps = __builtin_amdgcn_inverse_ballot_w64(wcur[j]);
+              if constexpr (off < 65536) *(double*)((char*)Praw + (wraps ? zbw : zb) + off) = t[j];
+              else *(double*)((char*)Praw + (wraps ? zbwh : zbh) + (off - HI)) = t[j];
             } else {
               if constexpr (L < RC) rext[Y::ext_idx(L)] = t[j];
               else *wsL(wsb, ws_off(L, 2), zo8) = t[j];
@@ -937,15 +740,10 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           // the masks of the next layer: their last use in this layer is behind us
           __builtin_amdgcn_sched_barrier(0);
           constexpr int Ln = (L + 1) % B::ROWS;
-          if constexpr (!PREF) {
-            constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
-            static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
-              wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
-            });
-          } else if constexpr (Y::plan_rot.need[Ln]) {
-            read_ahead(std::integral_constant<int, Ln>{}, zb, zbw, zbh, zbwh);      // ahead of the barrier in front of the next layer
-          }
-          PROBE_STAMP(WIDE ? 2 : 6);
+          constexpr int DCn = Y::has_ext(Ln) ? Y::deg(Ln) - 1 : Y::deg(Ln);
+          static_for<DCn>([&](auto jc) __attribute__((always_inline)) {
+            wcur[decltype(jc)::value] = wml[B::row_start(Ln) + decltype(jc)::value];
+          });
         } else if constexpr (SKIPR) {
           if (live) {      // the layer is left out; the next layer's masks are still wanted
             constexpr int Ln = (L + 1) % B::ROWS;
@@ -956,34 +754,19 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           }
         }
         if constexpr (Y::plan_rot.need[(L + 1) % B::ROWS]) {
-#if NRX_DEC3_SLOTBAR
-          if constexpr (NS == 2) slot_barrier(bar_k, sb_own, sb_poll);
-          else __syncthreads();
-#else
           __syncthreads();
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);   // nothing migrates between layers (register pressure)
       });
     }
     };
-    if constexpr (WSPEC) {
-      switch (__builtin_amdgcn_readfirstlane(z >> 6)) {
-        case 0: iter_loop(std::integral_constant<int, 0>{}, std::false_type{}); break;
-        case 1: iter_loop(std::integral_constant<int, 1>{}, std::false_type{}); break;
-        case 2: iter_loop(std::integral_constant<int, 2>{}, std::false_type{}); break;
-        case 3: iter_loop(std::integral_constant<int, 3>{}, std::false_type{}); break;
-        case 4: iter_loop(std::integral_constant<int, 4>{}, std::false_type{}); break;
-        default: iter_loop(std::integral_constant<int, 5>{}, std::false_type{}); break;
-      }
-    } else if constexpr (SKIPZ) {
-      if (last_zero) iter_loop(std::integral_constant<int, -1>{}, std::true_type{});
-      else iter_loop(std::integral_constant<int, -1>{}, std::false_type{});
+    if constexpr (SKIPZ) {
+      if (last_zero) iter_loop(std::true_type{});
+      else iter_loop(std::false_type{});
     } else {
-      iter_loop(std::integral_constant<int, -1>{}, std::false_type{});
+      iter_loop(std::false_type{});
     }
     __syncthreads();
-    PROBE_STAMP(-1);
 
     // ---- hard decisions of the information columns (ldpc.py:1578-1581)
     if constexpr (!FUSED) {
@@ -1047,25 +830,25 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
           static_for<B::CORE - 1>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value + 1;
-            NRX_ST_STREAM(&st[(size_t)(SL::COL + c - 1) * ZC], Ps[c * ZS + zt]);
+            st[(size_t)(SL::COL + c - 1) * ZC] = Ps[c * ZS + zt];
           });
-          NRX_ST_STREAM(&st[(size_t)SL::F1 * ZC], f1);
+          st[(size_t)SL::F1 * ZC] = f1;
         };
         if (parks) {      // park the state for the continuation launch
           using SL = StateLay<BG, RA>;
           double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
-          NRX_ST_STREAM(&st[(size_t)SL::C0 * ZC], c0);
+          st[(size_t)SL::C0 * ZC] = c0;
           static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
             constexpr int L = decltype(lc)::value;
-            NRX_ST_STREAM(&st[(size_t)(SL::M1 + L) * ZC], m1[L]);
-            NRX_ST_STREAM(&st[(size_t)(SL::M2 + L) * ZC], m2[L]);
-            if constexpr (Y::has_ext(L)) NRX_ST_STREAM(&st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC], rext[Y::ext_idx(L)]);
+            st[(size_t)(SL::M1 + L) * ZC] = m1[L];
+            st[(size_t)(SL::M2 + L) * ZC] = m2[L];
+            if constexpr (Y::has_ext(L)) st[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC] = rext[Y::ext_idx(L)];
           });
           static_for<SL::NW>([&](auto i) __attribute__((always_inline)) {
-            NRX_ST_STREAM(&st[(size_t)(SL::WORDS + decltype(i)::value) * ZC], __longlong_as_double((long long)sgw[decltype(i)::value]));
+            st[(size_t)(SL::WORDS + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgw[decltype(i)::value]);
           });
           static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
-            NRX_ST_STREAM(&st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC], __longlong_as_double((long long)sgn[decltype(i)::value]));
+            st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgn[decltype(i)::value]);
           });
           if (!cert_here) park_columns();
         }
@@ -1095,21 +878,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       }
     }
     __syncthreads();
-#ifdef NRX_DEC3_PROBE
-    PROBE_STAMP(9);
-    pk_rounds += 1;
-#endif
   }
-#ifdef NRX_DEC3_PROBE
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&g_probe[10], (unsigned long long)pk_acc[8]);
-    atomicAdd(&g_probe[11], (unsigned long long)pk_acc[9]);
-    atomicAdd(&g_probe[12], (unsigned long long)pk_rounds);
-    for (int k = 0; k < 8; ++k) atomicAdd(&g_probe[k], (unsigned long long)pk_acc[k]);
-    atomicAdd(&g_probe[8], 1ull);
-    atomicAdd(&g_probe[9], (unsigned long long)pk_layers);
-  }
-#endif
 }
 
 __constant__ WrapTab kWrap1_384_r13 = make_wrap<1, zindex_c(384), 13>();
@@ -1117,7 +886,7 @@ __constant__ WrapTab kWrap1_384_r15 = make_wrap<1, zindex_c(384), 15>();
 __constant__ WrapTab kWrap1_384_r31 = make_wrap<1, zindex_c(384), 31>();
 __constant__ WrapTab kWrap1_384_r46 = make_wrap<1, zindex_c(384), 46>();
 // rows of the hybrid instantiations whose state stays in registers (RA - RC a multiple of the prefetch depth)
-constexpr int HYB_RC46 = NRX_DEC3_HYB_RC, HYB_RC31 = NRX_DEC3_HYB_RC - 1;
+constexpr int HYB_RC46 = 12, HYB_RC31 = 11;      // resident rows of the 46- / 31-row hybrids
 
 struct DevTab { const uint64_t* p[4]; bool ok; };
 
@@ -1425,13 +1194,3 @@ extern "C" int32_t nrx_select_failed(const uint8_t* flags, int32_t n, int32_t* s
   return NRX_OK;
 }
 
-#ifdef NRX_DEC3_PROBE
-extern "C" int32_t nrx_debug_dec3_probe(unsigned long long* out14, int32_t reset) {
-  if (out14 && hipMemcpyFromSymbol(out14, HIP_SYMBOL(nrx_dec3::g_probe), sizeof(unsigned long long) * 14) != hipSuccess) return NRX_E_HIP;
-  if (reset) {
-    const unsigned long long z[14] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(nrx_dec3::g_probe), z, sizeof(z)) != hipSuccess) return NRX_E_HIP;
-  }
-  return NRX_OK;
-}
-#endif

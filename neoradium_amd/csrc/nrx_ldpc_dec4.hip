@@ -509,14 +509,11 @@ static int32_t launch(const double* llr, int n_cb, const nrx_ldpc_cfg* cfg, int 
 // of the K information bits, any lifting size.  <= 15 rows: everything on chip.  More rows: the hybrid instantiations (BG1: the
 // first 31 or all 46 rows, BG2: the first 22 or all 42; the rows beyond n_rows run as exact no-ops on zeroed extension LLRs) with
 // the sparse rows' state in the caller's workspace.  Returns 1 when not covered: the caller runs the workspace kernel.
-#ifndef NRX_DEC4_RC
-#define NRX_DEC4_RC 10
-#endif
 int32_t nrx_ldpc_decode_chipz_launch(const double* llr, int32_t n_cb, const nrx_ldpc_cfg* cfg, int32_t n_iter, int32_t n_rows,
                                      uint8_t* hard, hipStream_t st, void* ws, size_t ws_bytes) {
   using namespace nrx_dec4;
   if (getenv("NRX_LDPC_NOCHIP64") != nullptr || n_rows < 4 || cfg->Zc < 2 || cfg->Zc > ZMAX) return 1;
-  constexpr int RCH = NRX_DEC4_RC;
+  constexpr int RCH = 10;                 // resident rows of the hybrids
   if (n_rows > 15) {
     if (getenv("NRX_LDPC_NOHYBRID") != nullptr) return 1;
     if (cfg->bg == 1) {

@@ -230,40 +230,6 @@ template <int BG, int RA = G<BG>::ROWS> struct Lay {  // compile-time layer fact
     return p;
   }
   static constexpr BarPlanIn plan_rot = make_plan_rot();
-  // ---- Reads ahead of a barrier (nrx_ldpc_dec3.hip, NRX_DEC3_PREFETCH).  Behind a barrier every wave of the workgroup is between
-  // "my writes are out" and "my reads are back": write drain + barrier + LDS read latency with nothing to issue.  The elements of
-  // layer L that NO layer since the previous barrier has written (touched_before) can be read BEFORE the barrier in front of L -- their
-  // last writer is behind an earlier barrier this wave has already passed -- so that behind the barrier the wave starts on them at once
-  // while the loads of the other elements are in flight.
-  static constexpr uint32_t touched_before(int L) {      // LDS columns written since the barrier in front of the stretch that ends before L
-    uint32_t m = 0;
-    int l = (L + B::ROWS - 1) % B::ROWS;
-    for (int i = 0; i < B::ROWS; ++i) {
-      m |= lds_mask(l);
-      if (plan_rot.need[l]) break;
-      l = (l + B::ROWS - 1) % B::ROWS;
-    }
-    return m;
-  }
-  static constexpr bool pre_edge(int L, int e) {         // edge e (of layer L) is read ahead of the barrier in front of L
-    const int c = B::col(e);
-    return plan_rot.need[L] && c >= 1 && c < B::CORE && !(c == 1 && fwd1(L)) && ((touched_before(L) >> c) & 1u) == 0u;
-  }
-  static constexpr int n_pre(int L) {
-    int n = 0;
-    for (int e = B::row_start(L); e < B::row_start(L + 1); ++e) n += pre_edge(L, e) ? 1 : 0;
-    return n;
-  }
-  static constexpr int pre_idx(int L, int e) {           // position of edge e among the layer's read-ahead edges
-    int n = 0;
-    for (int k = B::row_start(L); k < e; ++k) n += pre_edge(L, k) ? 1 : 0;
-    return n;
-  }
-  static constexpr int max_pre() {
-    int m = 0;
-    for (int L = 0; L < B::ROWS; ++L) m = n_pre(L) > m ? n_pre(L) : m;
-    return m;
-  }
   // Priority level (0 = first quarter ... 3 = last) of the point `q4` quarters into layer L, counted over the whole stretch
   // between two barriers of plan_rot (a stretch may span several layers now): work ~ number of edges.
   static constexpr int prio_q(int L, int q4) {

@@ -10,29 +10,10 @@
 // Threads of a symbol-parallel modulator workgroup: the 256 the radix-16 passes of a 4096-point transform occupy.  (512 were
 // used while the fill kept one load per thread in flight; with the loads of a chunk issued together 256 threads cover the
 // latency, and at two waves per SIMD each has the 256 registers that keeping a pass's twiddle loads together needs.)
-#ifndef NRX_MOD_THREADS
-#define NRX_MOD_THREADS 256
-#endif
+#define MOD_THREADS 256
 // elements per thread whose global loads are issued together in the fill phases
 constexpr int FILL_U = 8;
 
-#ifndef NRX_OFDM_ABLATE
-#define NRX_OFDM_ABLATE 0     // developer timing ablations (tools/archive/probe_ofdm.py): 1 = no FFT passes, 2 = no global loads in the fill
-#endif
-#ifdef NRX_OFDM_PROBE
-// Developer build only (tools/archive/probe_ofdm.py): s_memtime stamps at the phase boundaries of the symbol-parallel modulator [0..4]
-// and the demodulator [8..12], summed over waves; [5] / [13] = waves stamped.
-__device__ unsigned long long g_ofdm_probe[16];
-#define OFDM_STAMP(K)                                                              \
-  do {                                                                             \
-    unsigned long long pt_;                                                        \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pt_)::"memory"); \
-    if ((K) >= 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_ofdm_probe[(K)], pt_ - pk_prev); \
-    pk_prev = pt_;                                                                 \
-  } while (0)
-#else
-#define OFDM_STAMP(K) do {} while (0)
-#endif
 
 namespace {
 using nrx::cx;
@@ -135,11 +116,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
                   const int64_t* __restrict__ item_ids, double cp_offset_ratio) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cx<T>* buf = (cx<T>*)smem;
-#ifdef NRX_OFDM_PROBE
-  unsigned long long pk_prev = 0;
-#endif
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-    OFDM_STAMP(-1);
     const int l = task % g.n_sym;
     const int row = task / g.n_sym;  // item * n_ant + antenna
     const int item = row / n_ant;
@@ -159,11 +136,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
       for (int u = 0; u < FILL_U; ++u) {
         const int i = i0 + u * blockDim.x;
         const int64_t s = ts + g.start[l] + off + ((cp - off + i) & (nfft - 1));  // waveform.py:509
-#if NRX_OFDM_ABLATE != 2
         xs[u] = (i < nfft && s < wave_len) ? src[s] : cx<T>(0, 0);
-#else
-        xs[u] = cx<T>((T)s, (T)i);
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       // sigma != null: the received waveform is noiseless and the AWGN of nrx_awgn_* (same generator, same element
@@ -188,13 +161,8 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
         if (i < nfft) buf[nrx::fft_idx(i)] = v;
       }
     }
-    OFDM_STAMP(8);
     __syncthreads();
-    OFDM_STAMP(9);
-#if NRX_OFDM_ABLATE != 1
     nrx::fft_dif_lds(buf, tw, nfft, log2n, false);
-#endif
-    OFDM_STAMP(10);
     cx<TO>* dst = grid + ((size_t)row * g.n_sym + l) * K;
 #pragma unroll 4
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -202,10 +170,6 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
       const cx<T> v = buf[nrx::fft_idx(nrx::fft_bitrev(q, log2n))];
       dst[k] = cx<TO>((TO)v.re, (TO)v.im);
     }
-#ifdef NRX_OFDM_PROBE
-    OFDM_STAMP(11);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_ofdm_probe[13], 1ull);
-#endif
   }
 }
 
@@ -214,7 +178,7 @@ ofdm_demod_kernel(const cx<T>* __restrict__ wave, int64_t wave_stride, int64_t w
 // place and parks its windowed tail in `tails`; ofdm_tail_add_kernel then adds tail l onto head l+1 (head + tail, the
 // order of the sequential kernel, so both produce identical samples).
 template <typename T>
-__global__ void __launch_bounds__(NRX_MOD_THREADS, 2)
+__global__ void __launch_bounds__(MOD_THREADS, 2)
 ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, SymGeom g, int w, int slot_len,
                     cx<T>* __restrict__ wave, int64_t wave_stride, const cx<T>* __restrict__ f, int64_t f_stride, int nl,
                     int ports, const cx<double>* __restrict__ tw, cx<T>* __restrict__ tails, int xcd_pairs) {
@@ -242,10 +206,6 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
   cx<T>* dst = wave + (size_t)row * wave_stride;
   const int pad_lo = (nfft - K + 1) / 2;  // grid.py:543
   const double inv_n = 1.0 / (double)nfft;
-#ifdef NRX_OFDM_PROBE
-  unsigned long long pk_prev = 0;
-  OFDM_STAMP(-1);
-#endif
   // (unrolled by 4: the loads of four iterations are in flight together -- with two 4-wave workgroups per CU a
   //  load-use-load chain of 16 iterations was most of this kernel's time)
   if (f) {
@@ -269,11 +229,7 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
       for (int u = 0; u < FILL_U; ++u) {
         const int i = i0 + u * blockDim.x;
         const int k = ((i + nfft / 2) & (nfft - 1)) - pad_lo;
-#if NRX_OFDM_ABLATE != 2
         xs[u] = (i < nfft && k >= 0 && k < K) ? src[(size_t)l * K + k] : cx<T>(0, 0);
-#else
-        xs[u] = cx<T>((T)k, (T)i);
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -283,13 +239,8 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
       }
     }
   }
-  OFDM_STAMP(0);
   __syncthreads();
-  OFDM_STAMP(1);
-#if NRX_OFDM_ABLATE != 1
   nrx::fft_dif_lds(buf, tw, nfft, log2n, true);
-#endif
-  OFDM_STAMP(2);
   const int cp = g.cp[l], n_l = cp + nfft;
 #pragma unroll 4
   for (int i = threadIdx.x; i < n_l + w; i += blockDim.x) {
@@ -307,10 +258,6 @@ ofdm_mod_sym_kernel(const cx<T>* __restrict__ grid, int K, int nfft, int log2n, 
       dst[pos] = v;
     }
   }
-#ifdef NRX_OFDM_PROBE
-  OFDM_STAMP(3);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&g_ofdm_probe[5], 1ull);
-#endif
 }
 
 template <typename T>
@@ -379,7 +326,7 @@ int32_t mod_entry(const void* grid, int32_t n_rows, int32_t K, int32_t nfft, con
     // precoded: XCD-aware placement of the ports of an (item, symbol) pair (see the kernel)
     const int pairs = f ? (n_rows / ports) * n_sym : 0;
     const int n_wg = f ? ((pairs + 7) / 8) * 8 * ports : n_rows * n_sym;
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NRX_MOD_THREADS), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(MOD_THREADS), lds, (hipStream_t)stream, (const cx<T>*)grid, K, nfft,
                        ilog2(nfft), g, window_len, slot_len, (cx<T>*)wave, wave_stride, (const cx<T>*)f, f_stride, nl,
                        ports, tw, (cx<T>*)tails, pairs);
     if (window_len > 0) {
@@ -447,13 +394,3 @@ extern "C" int32_t nrx_ofdm_modulate_precoded_f64(const void* layers, int32_t n_
 extern "C" int32_t nrx_ofdm_demodulate_f32(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream) { return demod_entry<float>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, nullptr, 0, 0, 0, 0, nullptr, cp_offset_ratio); }
 extern "C" int32_t nrx_ofdm_demodulate_f64(const void* wave, int64_t wave_stride, int64_t wave_len, const int32_t* t_off, int32_t t_off_stride, int32_t n_items, int32_t n_ant, int32_t K, int32_t nfft, const int32_t* cp_lens, int32_t n_sym, double cp_offset_ratio, void* grid, void* stream) { return demod_entry<double>(wave, wave_stride, wave_len, t_off, t_off_stride, n_items, n_ant, K, nfft, cp_lens, n_sym, grid, stream, nullptr, 0, 0, 0, 0, nullptr, cp_offset_ratio); }
 
-#ifdef NRX_OFDM_PROBE
-extern "C" int32_t nrx_debug_ofdm_probe(unsigned long long* out16, int32_t reset) {
-  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ofdm_probe), sizeof(unsigned long long) * 16) != hipSuccess) return NRX_E_HIP;
-  if (reset) {
-    unsigned long long z[16] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ofdm_probe), z, sizeof(z)) != hipSuccess) return NRX_E_HIP;
-  }
-  return NRX_OK;
-}
-#endif

@@ -246,8 +246,8 @@ class PdschLink:
         # folded path gains and the paths' spectra at the K subcarriers (ops.mmse_equalize_paths): no channel matrix is computed at all.
         # NRX_PERFECT_MATRIX=1 keeps the matrix route (getChannelMatrix -> H @ F -> equalize, what details=True always takes).
         self.bin_spec = None
-        if not freqDomain and chanEst == "Perfect" and self.nr in (1, 2, 4) and self.nl <= 4 and \
-                not bool(int(os.environ.get('NRX_PERFECT_MATRIX', '0'))):
+        if not freqDomain and chanEst == "Perfect" and self.nr in (1, 2, 4) and self.nl <= 4 and self.nfft <= 8192 and \
+                not bool(int(os.environ.get('NRX_PERFECT_MATRIX', '0'))):      # (nfft: the spectra kernel's twiddle table, FFT_TW_N)
             self.bin_spec = ops.td_path_spectra_bins(self.taps, self.tap_off, self.K, self.nfft)
         # chanOffset + the first-PRB channel matrix (for the wideband precoder) from the same spectra instead of a DFT over the CIR's
         # taps (ops.chan_setup_paths); NRX_CHAN_SETUP_DFT=1 keeps nrx_chan_setup_f64 (bit-identical to cir + channel_matrix_sub)
@@ -263,7 +263,7 @@ class PdschLink:
         self.slot_len = [int(v[:-1].sum()) for v in self.sym_lens]
         self.subframe_len = int(sum(self.slot_len))
         self._gather = {}
-        self._enc_buf = {}        # codeword -> ((batch size, rows), coded-bit buffer) reused from batch to batch (ops.ldpc_encode out=)
+        self._enc_buf = {}        # codeword -> ((batch size, rows), coded-bit buffer) reused from batch to batch (ops.ldpc_encode _reuse=)
         # run_harq: the decoder launches of a round's new blocks and of its retransmissions on two streams (NRX_HARQ_ONE_STREAM=1: one after
         # the other on the caller's stream; read at construction)
         self.harq_two_streams = not bool(int(os.environ.get('NRX_HARQ_ONE_STREAM', '0')))
@@ -379,12 +379,17 @@ class PdschLink:
                 side = self._side_stream
                 ready, done = torch.cuda.Event(), torch.cuda.Event()
                 ready.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    ok_nw = ops.ldpc_decode_selected(rr, ccfg, self.numIter, rows_new, s_nw, n_nw, dec)
-                    done.record(side)
-                ok_re = ops.ldpc_decode_selected(rr, ccfg, self.numIter, 46 if ccfg.bg == 1 else 42, s_re, n_re, dec)
-                main.wait_event(done)
+                ok_nw = ok_re = False
+                try:        # whatever either launch raises, the caller's stream waits for the side stream before rr / dec can be reused
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        try:
+                            ok_nw = ops.ldpc_decode_selected(rr, ccfg, self.numIter, rows_new, s_nw, n_nw, dec)
+                        finally:
+                            done.record(side)
+                    ok_re = ops.ldpc_decode_selected(rr, ccfg, self.numIter, 46 if ccfg.bg == 1 else 42, s_re, n_re, dec)
+                finally:
+                    main.wait_event(done)
                 if ok_re and ok_nw:
                     return dec
             elif ops.ldpc_decode_selected(rr, ccfg, self.numIter, 46 if ccfg.bg == 1 else 42, s_re, n_re, dec) and \
@@ -484,8 +489,9 @@ class PdschLink:
             enc_rows = cw['rows'] if harq is None else None
             ekey = (n, enc_rows)
             held = self._enc_buf.get(q)
-            coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'], rows=enc_rows, out=held[1] if held and held[0] == ekey else None)
-            self._enc_buf[q] = (ekey, coded)
+            coded = ops.ldpc_encode(ops.ldpc_segment(tb, cw['cfg']), cw['cfg'], rows=enc_rows,
+                                    _reuse=held[1] if held and held[0] == ekey else None)
+            self._enc_buf[q] = (ekey, coded)        # (this link's own buffer: `coded` is not stable from one batch to the next)
             bits = ops.ldpc_rate_match(coded, cw['cfg'], cw['G'], cw['nl'], cw['qm'], rv=0 if harq is None else harq[q][0])
             tx_bits.append(bits)
             if grid is None:    # one codeword: template + scramble + modulate + layer/RE map in one pass over the grid
@@ -538,10 +544,12 @@ class PdschLink:
 
         # ---- Rx
         hest = None
+        got = None
         if self.chanEst == "Perfect" and pp:
             got = ops.mmse_equalize_paths(rxg, gfold, self.bin_spec, off, nv, self.nfft, sym_mask=self.data_sym_mask)
-            if got is None:
-                raise RuntimeError("nrx_mmse_equalize_paths_f64 declined a configuration PdschLink selected it for")
+            if got is None:     # the kernel has no instantiation for this shape: the matrix route (getChannelMatrix -> H @ F -> equalize)
+                _, _, H, F, _ = self._channel_chain(slots, n, slots_dev, precoder=precoder, no_matrix=False)
+        if got is not None:
             eq, sc = got
         elif self.chanEst == "Perfect":
             hest = ops.effective_channel_prg(H, F, self.prg_k2g) if self.prg else ops.effective_channel(H, F)

@@ -56,33 +56,46 @@ def ldpc_segment(tb, cfg, add_tb_crc=True):
     return cbs
 
 
-def ldpc_encode(cbs, cfg, puncture=True, rows=None, out=None):
+def ldpc_encode(cbs, cfg, puncture=True, rows=None, _reuse=None):
     """ldpc.py:1033-1090 encode: (n_cb, K) -> (n_cb, N) (or N+2Zc without puncturing).  ``rows``: only the parity of the
-    first ``rows`` base-graph rows is produced (columns >= 22 + rows (BG1) / 10 + rows (BG2) of the output stay unwritten): for a
-    caller that rate-matches rv 0 into fewer bits than that (``ldpc_active_rows``).  ``out``: a buffer of the result's shape that
-    an earlier call with the SAME ``rows`` returned (a batched caller's per-link buffer): its unwritten columns are zero already
-    and are not cleared again (219 MB per 256 slots at the metric configuration)."""
+    first ``rows`` base-graph rows is produced (columns >= 22 + rows (BG1) / 10 + rows (BG2) of the output are zero): for a
+    caller that rate-matches rv 0 into fewer bits than that (``ldpc_active_rows``).
+    ``_reuse`` is PdschLink's private arrangement, not part of the surface: the (buffer, columns-cleared-from) pair an earlier call
+    with the same shape and ``rows`` returned for that link -- the never-written parity columns were cleared then and nothing but
+    this function writes the buffer, so they are not cleared again (219 MB per 256 slots at the metric configuration)."""
     cbs = _u8(cbs)
     if cbs.dim() != 2 or cbs.shape[1] != cfg.K:
         raise ValueError(f"code blocks must be (n_cb, K={cfg.K}), got {tuple(cbs.shape)}")
     width = cfg.N if puncture else cfg.N + 2 * cfg.Zc
-    reuse = out is not None
+    kb = 22 if cfg.bg == 1 else 10
+    first = min(width, (kb + int(rows) - (2 if puncture else 0)) * cfg.Zc) if rows else width
+    reuse = _reuse is not None
     if reuse:
-        if out.dtype != torch.uint8 or tuple(out.shape) != (cbs.shape[0], width) or not out.is_contiguous() or _dev(out) != _dev(cbs) \
-                or getattr(out, '_nrx_rows', None) != (int(rows) if rows else None):
-            raise ValueError("ldpc_encode: `out` must be the result of an earlier call of the same shape and row count")
+        out = _reuse
+        if not isinstance(out, _EncBuf) or out.dtype != torch.uint8 or tuple(out.shape) != (cbs.shape[0], width) or not out.is_contiguous() \
+                or _dev(out) != _dev(cbs) or out.cleared_from != first:
+            raise ValueError("ldpc_encode: the reused buffer is not the result of an earlier call of the same shape and row count")
     else:
         out = torch.empty((cbs.shape[0], width), dtype=torch.uint8, device=_dev(cbs))
     check(lib().nrx_ldpc_encode(ptr(cbs), cbs.shape[0], C.byref(cfg), 1 if puncture else 0, int(rows or 0), ptr(out), stream()))
     if rows and not reuse:
         # the parity columns of the other rows are not computed: they are ZEROED (a view, a clone or a slice of the result must
         # never expose uninitialised memory), and ldpc_rate_match refuses a transmission that would read them
-        kb = 22 if cfg.bg == 1 else 10
-        first = (kb + int(rows) - (2 if puncture else 0)) * cfg.Zc
         if first < width:
             out[:, first:].zero_()
-    out._nrx_rows = int(rows) if rows else None
+        out = out.as_subclass(_EncBuf)
+        out.cleared_from, out.rows_held = first, int(rows)
     return out
+
+
+class _EncBuf(torch.Tensor):
+    """A coded-bit matrix whose columns >= ``cleared_from`` were zeroed by ldpc_encode (see its ``_reuse``).  The type is the proof:
+    any torch operation on it returns a plain tensor, so only the very object ldpc_encode returned can come back."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
 
 
 def _rv_array(rv, n_tb, dev):
@@ -94,6 +107,7 @@ def _rv_array(rv, n_tb, dev):
 def ldpc_rate_match(coded, cfg, G, nl, qm, rv=0, nref=0):
     """ldpc.py:1093-1159 rateMatch: (n_tb*C, N) -> (n_tb, sum E_r).  ``rv``: int, or an int32 device tensor with
     one redundancy version per transport block (batched HARQ processes)."""
+    part = getattr(coded, 'rows_held', None)               # (a rows-truncated encode's own result, see ldpc_encode)
     coded = _u8(coded)
     if coded.dim() != 2 or coded.shape[1] != cfg.N or coded.shape[0] % cfg.C:
         raise ValueError(f"coded blocks must be (n_tb*C, N={cfg.N}), got {tuple(coded.shape)}")
@@ -101,7 +115,6 @@ def ldpc_rate_match(coded, cfg, G, nl, qm, rv=0, nref=0):
     f = nl * qm
     gout = ((G + f - 1) // f) * f
     dev = _dev(coded)
-    part = getattr(coded, '_nrx_rows', None)
     if part:       # a rows-truncated encode holds the parity of its first rows only: rv 0 without wrap-around may read it
         need = ldpc_active_rows(cfg, max(_lib.ldpc_cb_lens(int(G), cfg.C, nl, qm))) if (not torch.is_tensor(rv) and rv == 0 and nref == 0) \
             else (46 if cfg.bg == 1 else 42)

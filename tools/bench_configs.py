@@ -9,7 +9,7 @@ only reports their throughput and error counters on the GPU):
         with the DMRS-LS estimate (every block fails at any SNR -- in the reference too, tests/golden/e2e_cfg3_*) and once with
         perfect CSI (frequency-domain channel)
 
-    python tools/archive/bench_configs.py [--steps 2]
+    python tools/bench_configs.py [--steps 2]
 """
 import argparse
 import json
@@ -19,7 +19,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 

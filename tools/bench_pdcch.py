@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE cfg4 with a caller: PDCCH blind decoding of whole monitoring occasions (neoradium_amd/pdcch.py).
 
-    python tools/archive/bench_pdcch.py [--occasions 2048] [--cces 16] [--A 64]
+    python tools/bench_pdcch.py [--occasions 2048] [--cces 16] [--A 64]
 
 One occasion = a 16-CCE CORESET carrying one AL-8 and one AL-4 DCI for this UE + noise; all 31 aligned candidates
 (AL 1/2/4/8/16) are demapped, descrambled, rate-recovered and SCL-decoded (list 8) with the RNTI-masked CRC test.
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():

@@ -1,5 +1,5 @@
 """Dev tool (GPU): LLR magnitudes per code block at the metric configuration, and a sample of rate-recovered LLRs + the
-transmitted code blocks for the CPU prototype of the early-termination certificate (tools/archive/cert_proto.py --real).
+transmitted code blocks for the CPU prototype of the early-termination certificate (cert_proto.py of round 4, in the history).
 
     python tools/r4/llr_stats.py [--snr 31] [--slots 4] [--out gpurun_out/llr_sample.npz]
 """

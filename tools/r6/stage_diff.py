@@ -32,8 +32,8 @@ def stage(name, got, ref, what):
     if got.dtype.kind in 'iub' or ref.dtype.kind in 'iub':
         nd = int((got.astype(np.int64) != ref.astype(np.int64)).sum())
         return dict(stage=name, what=what, elements=int(got.size), differing=nd, max_err_in_eps_of_max=0.0 if nd == 0 else None)
-    g = got.astype(np.complex128 if np.iscomplexobj(got) or np.iscomplexobj(ref) else np.float64)
-    r = ref.astype(g.dtype)
+    g = np.ascontiguousarray(got.astype(np.complex128 if np.iscomplexobj(got) or np.iscomplexobj(ref) else np.float64))
+    r = np.ascontiguousarray(ref.astype(g.dtype))
     if np.iscomplexobj(g):
         gv, rv = g.view(np.float64), r.view(np.float64)
     else:
