@@ -127,6 +127,41 @@ __device__ __forceinline__ double vmin(double a, double b) {
   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// One step of the running two-smallest (ldpc.py:1556-1564) with the sign collection IN BETWEEN: a float64 result cannot be read
+// by the instruction (or the second instruction, for a float64 producer) behind it -- the compiler pads such pairs with s_nop 0, 105
+// of them per iteration in this loop when the three min / max of a step stand together and the v_alignbit of all edges follow as a
+// run (round 6: issue slots of the WAVE, not of the SIMD).  As one block the step needs none: max -> (min, alignbit) -> min.
+#define NRX_MS_STEP(T, TH)                          \
+  "v_max_f64 %[tmp], %[a1], |%[" T "]|\n\t"         \
+  "v_min_f64 %[a1], %[a1], |%[" T "]|\n\t"          \
+  "v_alignbit_b32 %[nsg], %[nsg], %[" TH "], 31\n\t" \
+  "v_min_f64 %[a2], %[a2], %[tmp]\n\t"
+__device__ __forceinline__ void minsum_step(double& a1, double& a2, uint32_t& nsg, double t) {
+  double tmp;
+  asm(NRX_MS_STEP("t", "th") : [tmp] "=&v"(tmp), [a1] "+v"(a1), [a2] "+v"(a2), [nsg] "+v"(nsg) : [t] "v"(t), [th] "v"(hi32(t)));
+}
+// ... four steps as one block: between two blocks the compiler cannot see which instruction wrote a1 last and pads again
+__device__ __forceinline__ void minsum_step4(double& a1, double& a2, uint32_t& nsg, double t0, double t1, double t2, double t3) {
+  double tmp;
+  asm(NRX_MS_STEP("t0", "h0") NRX_MS_STEP("t1", "h1") NRX_MS_STEP("t2", "h2") NRX_MS_STEP("t3", "h3")
+      : [tmp] "=&v"(tmp), [a1] "+v"(a1), [a2] "+v"(a2), [nsg] "+v"(nsg)
+      : [t0] "v"(t0), [h0] "v"(hi32(t0)), [t1] "v"(t1), [h1] "v"(hi32(t1)), [t2] "v"(t2), [h2] "v"(hi32(t2)), [t3] "v"(t3), [h3] "v"(hi32(t3)));
+}
+__device__ __forceinline__ void minsum_step2(double& a1, double& a2, uint32_t& nsg, double t0, double t1) {
+  double tmp;
+  asm(NRX_MS_STEP("t0", "h0") NRX_MS_STEP("t1", "h1")
+      : [tmp] "=&v"(tmp), [a1] "+v"(a1), [a2] "+v"(a2), [nsg] "+v"(nsg)
+      : [t0] "v"(t0), [h0] "v"(hi32(t0)), [t1] "v"(t1), [h1] "v"(hi32(t1)));
+}
+#undef NRX_MS_STEP
+// unit_of as an ordered statement ("memory": stores of the caller stay on their side of it): pass 2 puts the LDS write of the edge
+// before between this unit build and the fma that reads it, where the compiler otherwise pads with an s_nop (156 per iteration)
+__device__ __forceinline__ double unit_of_ordered(u32x2& uv, uint32_t signsrc) {
+  uint32_t h;
+  asm volatile("v_and_or_b32 %0, %1, %2, 1.0" : "=v"(h) : "v"(signsrc), "s"(0x80000000u) : "memory");
+  uv.y = h;
+  return __builtin_bit_cast(double, uv);
+}
 // lanes where |t| == a, as a mask in SGPRs (cold path only)
 __device__ __forceinline__ uint64_t cmp_abs_eq(double t, double a) {
   uint64_t m;
@@ -654,12 +689,13 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           double a1 = vmin_abs2(t[0], t[1]);
           double a2 = vmax_abs2(t[0], t[1]);
           uint32_t nsg = __builtin_amdgcn_alignbit(hi32(t[0]) >> 31, hi32(t[1]), 31);
+          // a2 = min(a2, max(a1, |t_j|)); a1 = min(a1, |t_j|); nsg = (nsg << 1) | sign(t_j)  for j = 2 .. D - 1, in blocks of 4 / 2 / 1
           static_for<D - 2>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value + 2;
+            constexpr int i = decltype(jc)::value, j = i + 2, left = D - 2 - (i / 4) * 4;      // edges left at the start of this group of four
             if constexpr (j == PQ2 && Y::prio_q(L, 2) != Y::prio_q(L, 1)) LAYER_PRIO(Y::prio_q(L, 2));
-            a2 = vmin(a2, vmax_abs(a1, t[j]));
-            a1 = vmin_abs(a1, t[j]);
-            nsg = __builtin_amdgcn_alignbit(nsg, hi32(t[j]), 31);      // (nsg << 1) | sign(t_j)
+            if constexpr (i % 4 == 0 && left >= 4) minsum_step4(a1, a2, nsg, t[j], t[j + 1], t[j + 2], t[j + 3]);
+            else if constexpr (left < 4 && i % 4 == 0 && left >= 2) minsum_step2(a1, a2, nsg, t[j], t[j + 1]);
+            else if constexpr (left < 4 && ((left == 1 && i % 4 == 0) || (left == 3 && i % 4 == 2))) minsum_step(a1, a2, nsg, t[j]);
           });
           // QUIRK ldpc.py:1563: min2 = min(min2, |v_argmin + 1e5|) with the SIGNED argmin entry; it can only win where
           // min2 > 5e4 (filler / saturated LLRs): wave-uniform cold path.
@@ -715,10 +751,11 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             static_for<D>([&](auto jc) __attribute__((always_inline)) {
               constexpr int j = D - 1 - decltype(jc)::value;      // last edge first: idx ends at the first index holding the minimum
               if constexpr (decltype(jc)::value == PQ3 && Y::prio_q(L, 3) != Y::prio_q(L, 2)) LAYER_PRIO(Y::prio_q(L, 3));
-              const double u = unit_of(uv, hi32(t[j]));
+              const double u = unit_of_ordered(uv, hi32(t[j]));
+              if constexpr (j < D - 1) put(std::integral_constant<int, j + 1>{});      // (the write of the edge before: between the unit and its use)
               t[j] = sel_fma_x<j>(t[j], idx, a1, u, nm1, nm2);
-              put(std::integral_constant<int, j>{});
             });
+            put(std::integral_constant<int, 0>{});
           } else {
             uint64_t seen = 0;
             static_for<D>([&](auto jc) __attribute__((always_inline)) {

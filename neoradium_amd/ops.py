@@ -78,13 +78,13 @@ def ldpc_encode(cbs, cfg, puncture=True, rows=None, _reuse=None):
     else:
         out = torch.empty((cbs.shape[0], width), dtype=torch.uint8, device=_dev(cbs))
     check(lib().nrx_ldpc_encode(ptr(cbs), cbs.shape[0], C.byref(cfg), 1 if puncture else 0, int(rows or 0), ptr(out), stream()))
-    if rows and not reuse:
+    if not reuse:
         # the parity columns of the other rows are not computed: they are ZEROED (a view, a clone or a slice of the result must
         # never expose uninitialised memory), and ldpc_rate_match refuses a transmission that would read them
         if first < width:
             out[:, first:].zero_()
         out = out.as_subclass(_EncBuf)
-        out.cleared_from, out.rows_held = first, int(rows)
+        out.cleared_from, out.rows_held = first, (int(rows) if rows else None)
     return out
 
 
