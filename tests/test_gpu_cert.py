@@ -147,6 +147,85 @@ def test_fillers_zeros_saturation_and_both_instantiations(dev, tbs, qm, nl, e_bi
                 assert 0 < okn.sum() < okn.size
 
 
+def test_the_sign_and_magnitude_conditions_bind_on_converged_blocks(dev):
+    """(S) / (Q) BIND on blocks whose CRC passes: clean code words at LLR magnitudes of a few thousand -- (B) holds, the
+    largest parity LLR stays under 1e5 / gamma_1 = 4 694 -- converge at once and satisfy the closure condition (M), but their stored
+    messages exceed mcap = 0.75 (1e5 - gamma_1 Lambda_pe): the territory of the +1e5 quirk (ldpc.py:1563).  The complete certificate
+    (flags 0) and the one without (M) (flags 2) refuse every block; without (S) / (Q) (flags 1) every block whose CRC passes stops at
+    the first check.  The same noise at ordinary magnitudes certifies.  Both forms; all bits those of the fixed schedule.
+    (CPU, on the oracle's certificate: tests/test_certificate_cpu.py -- (Q) alone, (S) alone by construction, and the state in which
+    a certificate without (S) stops a block whose bit flips one iteration later.)"""
+    import torch
+    from neoradium_amd import ops, _lib
+    tbs, qm, nl = 25000, 2, 1
+    cfg = _lib.ldpc_config(1, tbs + 24)
+    n_tb = 4
+    rng = np.random.default_rng(77)
+    e_small = (12300 // (nl * qm)) * (nl * qm)
+    G = cfg.C * e_small
+    lens = _lib.ldpc_cb_lens(G, cfg.C, nl, qm)
+    rows = ops.ldpc_active_rows(cfg, max(lens))
+    assert rows <= 15 and ops.ldpc_fused_supported(cfg, nl, qm, G, rows)
+    tb = torch.from_numpy(rng.integers(0, 2, (n_tb, tbs)).astype(np.uint8)).to(dev)
+    bits = ops.ldpc_rate_match(ops.ldpc_encode(ops.ldpc_segment(tb, cfg), cfg), cfg, G, nl, qm).cpu().numpy().astype(np.float64)
+    unit = (1 - 2 * bits) + 0.55 * np.clip(rng.standard_normal(bits.shape), -3.5, 3.5)           # |unit| <= 2.93
+
+    def deint(a):
+        out = np.empty_like(a)
+        off = 0
+        for E in lens:
+            out[:, off:off + E] = a[:, off:off + E].reshape(n_tb, E // qm, qm).transpose(0, 2, 1).reshape(n_tb, E)
+            off += E
+        return torch.from_numpy(out).to(dev)
+
+    n_iter = 30
+    _, gamma1, _ = ops.ldpc_cert_bounds(cfg, rows)
+    top = 0.985e5 / gamma1                                  # largest |LLR| just under 1e5 / gamma_1: (B) holds, mcap = 0.75 * 1.5e3 for a core row
+    unit[:, -1] = np.sign(unit[:, -1]) * 2.93              # (an extension LLR sits AT the largest magnitude: Lambda_pe is what the test says)
+    for scale, big in ((top / 2.93, True), (6.0, False)):
+        xd = deint(scale * unit)
+        tb_ref, ok_ref = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, n_iter, rows=rows)
+        assert bool(ok_ref.all())
+        for in_kernel in (True, False):
+            ex = {}
+            for flags in (0, 1, 2):
+                tb_c, ok_c, e = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (8, 12), n_iter, rows=rows, flags=flags, in_kernel=in_kernel)
+                assert torch.equal(ok_c, ok_ref) and torch.equal(tb_c, tb_ref), (scale, flags, in_kernel)
+                ex[flags] = e.cpu().numpy()
+            if big:
+                assert (ex[0] == 0).all() and (ex[2] == 0).all(), (in_kernel, np.unique(ex[0]), np.unique(ex[2]))      # (S) / (Q) refuse
+                assert (ex[1] == 8).all(), (in_kernel, np.unique(ex[1]))                                              # ... and nothing else does
+            else:
+                assert (ex[0] > 0).all() and np.array_equal(ex[0], ex[1])
+
+
+def test_witness_block_whose_bit_flips_after_every_check_passed(dev):
+    """tests/golden/cert_witness_S.npz (tests/test_certificate_cpu.py states what it is: after iteration 12 every parity check passes,
+    after iteration 13 one information bit has flipped; the ORACLE's certificate without (S) would stop it at 12) through the library
+    (BG1 / Zc 16 / 15 rows, generic certified decoder nrx_ldpc_decode_certified_f64): the float64 decoder reproduces the flip bit for bit;
+    the complete certificate refuses the block (it runs all 13 iterations and carries the fixed schedule's bits); so does the library's
+    certificate without (S) / (Q) -- its two slacks per row (every pm1 message held against the row's strongest demand) are coarser than
+    the oracle's per-edge slacks and do not close here: more conservative, never less; with NO condition (flags 7) the block stops at 12 on
+    bits that are not the fixed schedule's.  (The information bits are random -- no CRC to pass -- so the CRC filter is off, flags bit 2.)"""
+    import os
+    import torch
+    from neoradium_amd import ops, _lib
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'cert_witness_S.npz'))
+    k, ni, zc, rows = int(g['k']), int(g['num_iter']), int(g['zc']), int(g['rows'])
+    cfg = _lib.ldpc_config(1, 22 * zc)
+    assert (cfg.Zc, cfg.C, cfg.F, cfg.K) == (zc, 1, 0, 22 * zc)
+    x = torch.from_numpy(g['llr']).to(dev)
+    fixed = ops.ldpc_decode(x, cfg, ni, rows=rows).cpu().numpy()
+    at_k = ops.ldpc_decode(x, cfg, k, rows=rows).cpu().numpy()
+    weak = int(g['pos']) + 2 * zc
+    assert np.array_equal(at_k, g['info'].astype(np.uint8)) and (fixed != at_k).sum() == 1 and fixed[0, weak] != at_k[0, weak]
+    for flags in (4, 4 | 1):
+        hard, ex = ops.ldpc_decode_certified(x, cfg, ni, [k], rows=rows, flags=flags, max_sweeps=16)
+        assert int(ex[0]) == 0 and np.array_equal(hard.cpu().numpy(), fixed), flags
+    hard, ex = ops.ldpc_decode_certified(x, cfg, ni, [k], rows=rows, flags=7)
+    assert int(ex[0]) == k and np.array_equal(hard.cpu().numpy(), at_k)          # stopped at 12: not the fixed schedule's bits
+
+
 def test_gpu_certificate_against_the_oracle_on_a_slot(dev):
     """One slot at the metric configuration (72 blocks of Zc 384): the blocks the kernel certifies after 8 iterations carry, at 8,
     the bits the ORACLE's full 50-iteration run ends on, and the oracle's own certificate (another search for the slacks, same
