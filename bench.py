@@ -862,10 +862,15 @@ def main():
             # its CRC passes AND the stability certificate holds on its frozen decoder state (nrx_ldpc_certify_f64): every
             # later iteration of the same float64 recursion then provably leaves its hard decisions unchanged, i.e. its bits ARE the
             # reference schedule's.  Checked here on one batch per SNR point block by block against the fixed schedule's bits.
-            ce = build_link(nr, decoder='f64', certifiedExit=(8, 16))
+            ce = build_link(nr, decoder='f64', certifiedExit=(8, 16))      # (round 6: ONE persistent launch, PdschLink's default)
             kt, wt = min(K, 8), max(min(W, 2), 2)
             pts = []
             pay = cfg.cb_len - 24
+            # ... and the staged launches of rounds 4-5 (stage -> select -> stage -> resume) on the bench's own slots, for comparison
+            cs_ = build_link(nr, decoder='f64', certifiedExit=(8, 16), certPersistent=False)
+            sdt, sc_, _ = timed_steps(cs_, ops, B, kt, wt, float(args.snr), slot_base, None, sync, timer_enabled=False)
+            staged_pt = {"value": B * kt / sdt, "unit": "slots/s", "steps": kt, "ms_per_step": sdt / kt * 1e3, "block_errors": int(sc_.cpu().numpy()[0])}
+            del cs_
             # (the certified schedule's speed depends on how many blocks converge, i.e. on the fade the timed slots see: every figure
             #  carries the BLER of its own timed steps, and one point sits on a slot range of about 10 % BLER -- steps 307 ... 314 of this
             #  link at 31 dB, tools/r6/bler_by_step.py, profiles/r6_bler_by_step.json -- beside the bench's own first steps)
@@ -904,7 +909,10 @@ def main():
                             "mismatches": mism, "verdict_mismatches": vmism})
             main_pt = next(q for q in pts if q["snr_db"] == float(args.snr) and q["slots"] == "the bench's own timed slots")
             out["certified_early_exit"] = dict(main_pt, checks_at=list(ce.certStages), num_iter=link.numIter, exact_by_construction=True,
-                                               certificate="nrx_ldpc_stage_certify_decode_merge_f64: the stability certificate in the stage kernel's tail, float32 slack "
+                                               schedule="one persistent launch: code-block slots draw blocks from a device queue and take each through its stages "
+                                                        "(nrx_ldpc_certified_persistent_f64)" if ce.certPersistent else "staged launches",
+                                               persistent_error_word=ops.persistent_error(), staged_launches=staged_pt,
+                                               certificate="nrx_ldpc_certcore.h: the stability certificate in the decoder kernel's tail, float32 slack "
                                                            "sums used through their conservative inflation (DESIGN 4.3; tests/test_gpu_cert.py, tests/test_certificate_cpu.py)",
                                                checked="every code block of every timed step, bits and CRC verdicts, against the fixed schedule on the same slots",
                                                note="opt-in (off by default; the reference has no early stop, ldpc.py:1545): `value` above stays the fixed schedule",

@@ -220,6 +220,19 @@ int32_t nrx_ldpc_certify_f64(const void* state, int32_t n_tb, int32_t llr_len, c
                              int32_t n_rows, const int32_t* sel, const int32_t* n_sel, const uint8_t* cb_ok, const double* lam,
                              int32_t iter_now, int32_t n_iter_total, int32_t max_sweeps, int32_t flags, uint8_t* exit_iter,
                              void* stream);
+/* The certified schedule as ONE launch (round 6; ldpc.py:1495-1619 with the early exit of DESIGN 4.3): every code-block slot of the grid
+ * (one workgroup of two slots per CU) draws blocks from a device queue and takes each through its stages -- stages[0] iterations from the
+ * LLRs, CRC + certificate, stages[1] more, ... the last stage without a certificate -- stopping at the first stage whose CRC passes and
+ * whose frozen state holds the stability certificate: exit_iter[cb] = the iterations it had then, 0 = it ran all sum(stages) of them.  The
+ * two slots of a workgroup never wait for each other; nothing is parked between stages, nothing reloaded from HBM.  Same bits and verdicts
+ * as the staged launches and as the fixed schedule of sum(stages) iterations.  stages: HOST array, 1 <= n_stages <= 4.
+ * state: 2 x (CUs of the device) records of nrx_ldpc_fused_state_bytes(...) bytes (a slot's certificate reads its check-node state back
+ * from there); lam: 2 n_cb doubles; scratch / scratch_bytes as nrx_ldpc_stage_certify_decode_merge_f64; queue: int32[2] on the device,
+ * zeroed by the call -- queue[1] != 0 afterwards means a slot barrier gave up (a bug, never the data): the results are then invalid. */
+int32_t nrx_ldpc_certified_persistent_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
+                                          int32_t qm, const int32_t* stages, int32_t n_stages, int32_t n_rows, uint8_t* tb_out,
+                                          uint8_t* cb_ok, void* state, double* lam, uint8_t* exit_iter, void* scratch,
+                                          size_t scratch_bytes, int32_t* queue, int32_t max_sweeps, int32_t flags, void* stream);
 
 /* The certified early exit for ANY configuration (both base graphs, every lifting size, any row count): ldpc.py:1495-1581 decode of
  * rate-recovered LLRs (n_cb, N) -> hard decisions of the K information bits, with the certificate evaluated after the iterations

@@ -56,6 +56,7 @@ SIGNATURES = {
     'nrx_ldpc_resume_decode_merge_sel_f64': (i32, [i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     'nrx_ldpc_cert_bounds': (i32, [_cfgp, i32, vp]),
     'nrx_ldpc_stage_decode_merge_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'nrx_ldpc_certified_persistent_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, C.POINTER(i32), i32, i32, vp, vp, vp, vp, vp, vp, u64, vp, i32, i32, vp]),
     'nrx_ldpc_stage_certify_decode_merge_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp]),
     'nrx_ldpc_certify_f64': (i32, [vp, i32, i32, _cfgp, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     'nrx_ldpc_decode_certified_ws_bytes': (i64, [_cfgp, i32]),

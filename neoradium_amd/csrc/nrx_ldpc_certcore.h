@@ -87,9 +87,11 @@ __device__ __forceinline__ void wstore(float* p, float v) { __hip_atomic_store(p
 // register file beside the decoder's state -- kept in registers they pushed spills INTO the decoder's iteration loop), flags = 6 LDS
 // words per workgroup.  Returns whether the slot's block holds the certificate.
 typedef const double __attribute__((address_space(3))) * lds_cd;
-template <int BG, int ZI, int RA, bool HASF, int NS>
+// NS = the slots that take part in `bar` together: 2 = the workgroup's two blocks behind workgroup barriers (the stage kernels), 1 = this slot
+// alone behind its own barrier (the persistent schedule: the other slot is somewhere else in its own block).
+template <int BG, int ZI, int RA, bool HASF, int NS, class BarF>
 __device__ __forceinline__ bool certify_on_chip(const Params& cp, double lam_all, double lam_pe, const double* st, double c0, lds_cd Ps,
-                                                float* Wg, int z, int slot, bool want, uint32_t* flags) {
+                                                float* Wg, int z, int slot, bool want, uint32_t* flags, BarF&& bar) {
   using B = GR<BG, RA>;
   using Y = Lay<BG, RA>;
   using SL = StateLay<BG, RA>;
@@ -137,7 +139,7 @@ __device__ __forceinline__ bool certify_on_chip(const Params& cp, double lam_all
     n_fw2 = wrow[(2 * L + 1) * ZC];
   };
   if (active) fetch_row(std::integral_constant<int, 0>{});
-  __syncthreads();
+  bar();
   for (int sweep = 0; sweep < cp.max_sweeps; ++sweep) {
     bool raised = false;
     if (z == 0) { flags[2 * slot] = 0u; flags[2 * slot + 1] = 0u; }
@@ -261,24 +263,25 @@ __device__ __forceinline__ bool certify_on_chip(const Params& cp, double lam_all
       }
       if (active) fetch_row(std::integral_constant<int, (L + 1) % B::ROWS>{});      // (the next row's, of the next sweep after the last row)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __syncthreads();                             // the next row reads the sums this one wrote
+      bar();                                       // the next row reads the sums this one wrote
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       __builtin_amdgcn_sched_barrier(0);
     });
     if (active && raised) atomicOr(&flags[2 * slot], 1u);
     if (active && dead) atomicOr(&flags[2 * slot + 1], 1u);
-    __syncthreads();
+    bar();
     if (active) {
       const bool any_dead = flags[2 * slot + 1] != 0u, any_raised = flags[2 * slot] != 0u;
       if (any_dead) active = false;
       else if (!any_raised) { certified = true; active = false; }
     }
-    __syncthreads();                               // (the flags are reset at the top of the next sweep)
+    bar();                                         // (the flags are reset at the top of the next sweep)
     if (z == 0) flags[4 + slot] = active ? 1u : 0u;
-    __syncthreads();
+    bar();
     uint32_t cont = 0;
-    for (int s = 0; s < NS; ++s) cont |= flags[4 + s];
-    if (cont == 0u) break;                         // (workgroup-uniform)
+    if constexpr (NS == 1) cont = flags[4 + slot];
+    else for (int s = 0; s < NS; ++s) cont |= flags[4 + s];
+    if (cont == 0u) break;                         // (uniform over the waves behind `bar`)
   }
   return certified;
 }

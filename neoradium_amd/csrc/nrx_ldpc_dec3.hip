@@ -214,6 +214,29 @@ __device__ __forceinline__ void sel_fma_first(double& x, uint32_t& idx, uint64_t
 // of a SIMD reach the barrier together.
 #define LAYER_PRIO(Q) __builtin_amdgcn_s_setprio(3 - (Q))
 
+// ---- Barrier of ONE code block's six waves (the persistent certified schedule, MODE bit 4: the two code-block slots of a workgroup run
+// different blocks at different iterations and must not wait for each other; a 384-thread workgroup per code block is not an option, a CU
+// never co-schedules two of them at this register count).  Every wave keeps a progress word in LDS (the padding in front of the
+// columns); arriving = storing the barrier's number there (one lane; the LDS executes a wave's instructions in order, so the word lands
+// behind the wave's column writes and no drain is needed), waiting = polling the slot's six words until none is behind.  A wait that
+// does not end (a bug, never the data) gives up after 2^22 polls and makes every later barrier of the wave fall through: the kernel
+// always terminates, and the caller finds the error word set.
+constexpr uint32_t SLOTBAR_BASE = 2048;      // byte offset inside the padding: [slot][8] progress words
+constexpr uint32_t SLOTQ_BASE = 2048 + 64;   // [slot] the work-list position the slot drew
+__device__ __forceinline__ void slot_barrier(uint32_t& k, uint32_t own_addr, uint32_t poll_addr, bool& aborted) {
+  k += 1;
+  asm volatile("s_mov_b64 exec, 1\n\t"
+               "ds_write_b32 %0, %1\n\t"
+               "s_mov_b64 exec, -1" ::"v"(own_addr), "v"(k) : "memory");
+  if (aborted) return;
+  for (uint32_t spin = 0;; ++spin) {
+    uint32_t seen;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(poll_addr) : "memory");
+    if (__builtin_amdgcn_ballot_w64((int32_t)(k - seen) > 0) == 0) break;
+    if (spin > (1u << 22)) { aborted = true; break; }
+  }
+}
+
 template <int BG> constexpr bool ext_shifts_are_zero() {
   using B = G<BG>;
   for (int ils = 0; ils < 8; ++ils)
@@ -288,6 +311,11 @@ struct FuseArgs {
   float* cert_w;
   uint8_t* exit_iter;
   nrx_certcore::Params cp;
+  // MODE bit 4 (the persistent certified schedule): queue[0] = the next work-list position (zeroed by the caller's launch), queue[1] = error
+  // word (a slot barrier gave up); the iterations of each stage (the certificate is evaluated behind every stage but the last)
+  int32_t* queue;
+  int32_t stage_iters[4];
+  int32_t n_stages;
 };
 // The kernel reads FuseArgs through the kernarg segment pointer at the two places that need it (initial fill, tail)
 // instead of through its parameter: as a parameter its ten scalars and two pointers stay live across the whole layer
@@ -360,6 +388,19 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
   static_assert(RC == RA || (!FUSED && (MODE == 0 || MODE == 8) && RC >= 4 && RC < RA), "the hybrid is built for the unfused entry");
   static_assert((MODE & 8) == 0 || MODE == 8, "MODE bit 3 goes with a whole decode");
   constexpr bool HYB = RC < RA;
+  // MODE bit 4 (with bits 0 and 2): the PERSISTENT certified schedule -- each code-block slot draws blocks from a device queue and takes a
+  // block through all its stages (n iterations, CRC, certificate, go on or stop) before it draws the next; the two slots of a workgroup
+  // never synchronise with each other (slot_barrier), nothing is parked between stages and nothing reloaded.
+  constexpr bool PERS = (MODE & 16) != 0;
+  static_assert(!PERS || (FUSED && NS == 2 && (MODE & 15) == 5 && RC == RA), "the persistent schedule is the stage mode of the fused entry");
+  const uint32_t sb_own = SLOTBAR_BASE + 32u * (uint32_t)slot + 4u * (uint32_t)__builtin_amdgcn_readfirstlane(z >> 6);
+  const uint32_t sb_poll = SLOTBAR_BASE + 32u * (uint32_t)slot + 4u * (uint32_t)((z & 63) % (ZC / 64));
+  uint32_t bar_k = 0;
+  bool aborted = false;
+  auto BAR = [&]() __attribute__((always_inline)) {
+    if constexpr (PERS) slot_barrier(bar_k, sb_own, sb_poll, aborted);
+    else __syncthreads();
+  };
   // MODE bit 3 (whole decodes: the hybrids and the fused entry): the layers beyond the caller's row count (FuseGeom::rows_live) are left
   // out instead of run as no-ops.  A separate instantiation: the test costs 1.5-3 % more VALU instructions per iteration (copies at the
   // joins), which a launch that runs every row need not pay.
@@ -395,8 +436,22 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     sel = fa0->sel;
     if (sel) n_cb = *fa0->n_sel;                            // (wave-uniform; a workgroup beyond the count leaves at once)
   }
-  for (int cb0 = blockIdx.x * NS; cb0 < n_cb; cb0 += gridDim.x * NS) {
-    const int cbi = cb0 + slot;                             // position in the work list
+  if constexpr (PERS) {      // progress words start at zero (the one workgroup barrier of this mode: every wave is here)
+    if ((z & 63) == 0) *(volatile uint32_t*)((char*)Praw + sb_own) = 0u;
+    __syncthreads();
+  }
+  for (int cb0 = blockIdx.x * NS; PERS || cb0 < n_cb; cb0 += gridDim.x * NS) {
+    int cbi = cb0 + slot;                                   // position in the work list
+    if constexpr (PERS) {      // this slot's next block: one lane draws, the slot's barrier hands the position to its six waves
+      if (z == 0) {
+        const int got = aborted ? n_cb : atomicAdd(fuse_args()->queue, 1);
+        *(volatile uint32_t*)((char*)Praw + SLOTQ_BASE + 4u * (uint32_t)slot) = (uint32_t)got;
+      }
+      BAR();
+      cbi = (int)*(volatile uint32_t*)((char*)Praw + SLOTQ_BASE + 4u * (uint32_t)slot);
+      cbi = __builtin_amdgcn_readfirstlane(cbi);
+      if (cbi >= n_cb || aborted) break;
+    }
     int one = 1;
     asm volatile("" : "+s"(one));                          // keeps the per-layer `if (live)` a real branch (see dec2)
     const bool live = cbi < n_cb && one != 0;
@@ -556,7 +611,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       static_for<(Y::n_wide() > 0 ? Y::n_wide() : 1)>([&](auto i) __attribute__((always_inline)) { sgw[decltype(i)::value] = 0u; });
       static_for<(Y::n_narrow() + 1) / 2>([&](auto i) __attribute__((always_inline)) { sgn[decltype(i)::value] = 0u; });
     }
-    __syncthreads();
+    BAR();
     if constexpr (FUSED && (MODE & 4) != 0 && (MODE & 2) == 0) {
       if (z == 0 && live) {
         const double* redd = Praw + 16 + slot * 2 * (ZC / 64);
@@ -588,9 +643,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
     });
 
     // SL: the copy of the iteration loop without the last layer's body (see SKIPZ)
-    auto iter_loop = [&](auto slc) __attribute__((always_inline)) {
+    auto iter_loop = [&](auto slc, int n_it) __attribute__((always_inline)) {
     constexpr bool SL = decltype(slc)::value;
-    for (int it = 0; it < n_iter; ++it) {
+    for (int it = 0; it < n_it; ++it) {
       static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
         constexpr int L = decltype(lc)::value;
         constexpr int E0 = B::row_start(L);
@@ -791,19 +846,30 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           }
         }
         if constexpr (Y::plan_rot.need[(L + 1) % B::ROWS]) {
-          __syncthreads();
+          BAR();
         }
         __builtin_amdgcn_sched_barrier(0);   // nothing migrates between layers (register pressure)
       });
     }
     };
-    if constexpr (SKIPZ) {
-      if (last_zero) iter_loop(std::true_type{});
-      else iter_loop(std::false_type{});
-    } else {
-      iter_loop(std::false_type{});
+    // PERS: the block's stages, one after the other (the certificate behind every stage but the last decides whether it goes on)
+    int iters_done = 0;
+    for (int stage = 0;; ++stage) {
+    int n_it = n_iter;
+    bool last_stage = true;
+    if constexpr (PERS) {
+      const fargs_t fq = fuse_args();
+      n_it = fq->stage_iters[stage];
+      last_stage = stage + 1 >= fq->n_stages;
     }
-    __syncthreads();
+    iters_done += n_it;
+    if constexpr (SKIPZ) {
+      if (last_zero) iter_loop(std::true_type{}, n_it);
+      else iter_loop(std::false_type{}, n_it);
+    } else {
+      iter_loop(std::false_type{}, n_it);
+    }
+    BAR();
 
     // ---- hard decisions of the information columns (ldpc.py:1578-1581)
     if constexpr (!FUSED) {
@@ -845,7 +911,7 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
       });
       uint32_t* red = (uint32_t*)Praw;                      // the padding in front of the columns is never addressed
       if ((zt & 63) == 0) red[slot * (ZC / 64) + (zt >> 6)] = v;
-      __syncthreads();
+      BAR();
       if (zt == 0 && live) {
         uint32_t tot = 0;
         for (int w = 0; w < ZC / 64; ++w) tot = gf2_mulc24<gf2_xpow24(64)>(tot) ^ red[slot * (ZC / 64) + w];
@@ -853,14 +919,14 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
         if constexpr ((MODE & 1) != 0) red[NS * (ZC / 64) + slot] = tot == 0 ? 1u : 0u;
       }
       if constexpr ((MODE & 1) != 0) {
-        __syncthreads();
+        BAR();
         // MODE bit 2: every block parks (whatever its CRC says); where asked for (cert_w != NULL) the stability certificate is evaluated
         // on the spot in between -- posterior columns still in LDS, the check-node state read back from what this lane just parked --
         // and a block that holds it gets its exit iteration (the caller's work list of the next stage leaves it out) and keeps its
         // columns to itself.
         // (the check-node state first: it is all the certificate reads back; the posterior columns follow behind the certificate, and
         //  only for the blocks that have to go on)
-        const bool parks = live && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u);
+        const bool parks = live && !PERS && ((MODE & 4) != 0 || red[NS * (ZC / 64) + slot] == 0u);
         const bool cert_here = (MODE & 4) != 0 && fa->cert_w != nullptr;      // (kernel-uniform)
         auto park_columns = [&]() __attribute__((always_inline)) {
           using SL = StateLay<BG, RA>;
@@ -871,9 +937,9 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           });
           st[(size_t)SL::F1 * ZC] = f1;
         };
-        if (parks) {      // park the state for the continuation launch
+        // the check-node state of this lane to / from a state record (StateLay): where the certificate reads it back
+        auto park_rows = [&](double* st) __attribute__((always_inline)) {
           using SL = StateLay<BG, RA>;
-          double* st = fa->state + (size_t)cb * SL::NF * ZC + zt;
           st[(size_t)SL::C0 * ZC] = c0;
           static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
             constexpr int L = decltype(lc)::value;
@@ -887,9 +953,13 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
           static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
             st[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC] = __longlong_as_double((long long)sgn[decltype(i)::value]);
           });
+        };
+        if (parks) {      // park the state for the continuation launch
+          using SL = StateLay<BG, RA>;
+          park_rows(fa->state + (size_t)cb * SL::NF * ZC + zt);
           if (!cert_here) park_columns();
         }
-        if constexpr ((MODE & 4) != 0) {
+        if constexpr ((MODE & 4) != 0 && !PERS) {
           if (fa->cert_w != nullptr) {             // (kernel-uniform)
             using SL = StateLay<BG, RA>;
             nrx_certcore::Params cp;
@@ -905,16 +975,78 @@ ldpc_dec_chip64_kernel(const double* __restrict__ llr, int n_cb, int n_iter, uin
             __syncthreads();                       // (the CRC flags have been read: the padding words are free again)
             const bool want = live && (crc || (cp.flags & 4) != 0);
             const nrx_certcore::lds_cd Pc = (nrx_certcore::lds_cd)(Praw + ZS + slot * BUF);
+            auto wgbar = []() __attribute__((always_inline)) { __syncthreads(); };
             // (with filler bits the row pass also has to recognise their posteriors: 7 more instructions per edge)
-            const bool settled = fa->g.F > 0 ? nrx_certcore::certify_on_chip<BG, ZI, RA, true, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64))
-                                             : nrx_certcore::certify_on_chip<BG, ZI, RA, false, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64));
+            const bool settled = fa->g.F > 0 ? nrx_certcore::certify_on_chip<BG, ZI, RA, true, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64), wgbar)
+                                             : nrx_certcore::certify_on_chip<BG, ZI, RA, false, NS>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, want, (uint32_t*)(Praw + 64), wgbar);
             if (settled && zt == 0) fa->exit_iter[cb] = (uint8_t)(cp.iter_now < 255 ? cp.iter_now : 255);
             if (parks && !settled) park_columns();
           }
         }
+        if constexpr (PERS) {
+          // The block stops here if this was its last stage, or if its CRC passes and its frozen state holds the certificate; else it
+          // goes on with the next stage's iterations.  The certificate reads the check-node state back from this SLOT's record (with the
+          // state live in registers across it, the certificate's own registers spill into the layer loop), and a block that goes on takes
+          // it back from there.  Nothing else leaves the chip: no parked columns, no resume.
+          using SL = StateLay<BG, RA>;
+          const bool crc = red[NS * (ZC / 64) + slot] != 0u;
+          const int32_t cflags = fa->cp.flags;
+          bool stop = last_stage;
+          if (!last_stage) {
+            // (EVERY block that is not at its last stage leaves its check-node state in the slot's record and takes it back below: one
+            //  definition of the state in front of the next stage's loop, whichever way the block got there, and no state live across the
+            //  certificate)
+            double* stc = fa->state + ((size_t)blockIdx.x * NS + slot) * SL::NF * ZC + zt;
+            park_rows(stc);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (the record is written before anything reads it back)
+            bool settled = false;
+            BAR();                                 // (the CRC flags have been read: the padding words are free again)
+            if (crc || (cflags & 4) != 0) {        // (slot-uniform)
+              nrx_certcore::Params cp;
+              cp.gamma = fa->cp.gamma; cp.gamma1 = fa->cp.gamma1; cp.dmax = fa->cp.dmax; cp.n_iter_total = fa->cp.n_iter_total;
+              cp.max_sweeps = fa->cp.max_sweeps; cp.flags = cflags; cp.iter_now = iters_done;
+              const double* lam = fa->lam;
+              const double la = __hip_atomic_load(lam + 2 * (size_t)cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const double lp = __hip_atomic_load(lam + 2 * (size_t)cb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              float* Wg = fa->cert_w + ((size_t)blockIdx.x * NS + slot) * (size_t)((B::CORE + 2 * B::ROWS) * ZC);
+              const double c0c = stc[(size_t)SL::C0 * ZC];
+              const nrx_certcore::lds_cd Pc = (nrx_certcore::lds_cd)(Praw + ZS + slot * BUF);
+              settled = fa->g.F > 0 ? nrx_certcore::certify_on_chip<BG, ZI, RA, true, 1>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, true, (uint32_t*)(Praw + 64), BAR)
+                                    : nrx_certcore::certify_on_chip<BG, ZI, RA, false, 1>(cp, la, lp, stc, c0c, Pc, Wg, zt, slot, true, (uint32_t*)(Praw + 64), BAR);
+            }
+            if (settled) {
+              if (zt == 0) fa->exit_iter[cb] = (uint8_t)(iters_done < 255 ? iters_done : 255);
+              stop = true;
+            } else {      // take the check-node state back (what this lane wrote itself)
+              const double* sq = stc;
+              asm volatile("" : "+v"(sq));
+              c0 = sq[(size_t)SL::C0 * ZC];
+              static_for<B::ROWS>([&](auto lc) __attribute__((always_inline)) {
+                constexpr int L = decltype(lc)::value;
+                m1[L] = sq[(size_t)(SL::M1 + L) * ZC];
+                m2[L] = sq[(size_t)(SL::M2 + L) * ZC];
+                if constexpr (Y::has_ext(L)) rext[Y::ext_idx(L)] = sq[(size_t)(SL::REXT + Y::ext_idx(L)) * ZC];
+              });
+              static_for<SL::NW>([&](auto i) __attribute__((always_inline)) {
+                sgw[decltype(i)::value] = (uint32_t)__double_as_longlong(sq[(size_t)(SL::WORDS + decltype(i)::value) * ZC]);
+              });
+              static_for<SL::NN>([&](auto i) __attribute__((always_inline)) {
+                sgn[decltype(i)::value] = (uint32_t)__double_as_longlong(sq[(size_t)(SL::WORDS + SL::NW + decltype(i)::value) * ZC]);
+              });
+            }
+          }
+          if (stop) break;
+          BAR();                                   // (the padding words of the tail are free before the next stage's tail writes them)
+          continue;
+        }
       }
     }
-    __syncthreads();
+    break;      // (every other mode: one stage)
+    }
+    BAR();
+  }
+  if constexpr (PERS) {
+    if (aborted && (z & 63) == 0) atomicOr(fuse_args()->queue + 1, 1);
   }
 }
 
@@ -1022,7 +1154,8 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
                                          uint8_t* cb_ok, const int32_t* sel, const int32_t* n_sel, void* stream,
                                          int mode = 0, double* state = nullptr, size_t* state_bytes_per_cb = nullptr,
                                          double* lam = nullptr, int* rows_run = nullptr, float* cert_w = nullptr, size_t cert_w_bytes = 0,
-                                         uint8_t* exit_iter = nullptr, const nrx_certcore::Params* cp = nullptr) {
+                                         uint8_t* exit_iter = nullptr, const nrx_certcore::Params* cp = nullptr,
+                                         int32_t* queue = nullptr, const int32_t* stage_iters = nullptr, int n_stages = 0) {
   using namespace nrx_dec3;
   NRX_REQUIRE(llr && cfg && tb_out && cb_ok, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: NULL buffer");
   NRX_REQUIRE(nl >= 1 && qm >= 1 && llr_len > 0 && n_tb >= 0 && n_iter >= 0, NRX_E_ARG, "nrx_ldpc_recover_decode_merge: bad argument");
@@ -1039,6 +1172,9 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   fa.cert_w = nullptr;
   fa.exit_iter = exit_iter;
   fa.cp = nrx_certcore::Params{};
+  fa.queue = queue;
+  fa.n_stages = n_stages;
+  for (int i = 0; i < 4; ++i) fa.stage_iters[i] = (stage_iters && i < n_stages) ? stage_iters[i] : 0;
   FuseGeom& fg = fa.g;
   fg.C = cfg->C; fg.f = f; fg.qm = qm; fg.F = cfg->F; fg.llr_len = llr_len; fg.cb_len = cfg->cb_len;
   fg.e_small = (gb / cfg->C) * f;
@@ -1078,6 +1214,14 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   }
   constexpr int ZI384 = zindex_c(384);
   hipStream_t st = (hipStream_t)stream;
+  if (mode == 21) {        // the persistent certified schedule: one workgroup per CU, blocks drawn from the queue
+    NRX_REQUIRE(queue && cert_w && n_stages >= 1 && n_stages <= 4, NRX_E_ARG, "nrx_ldpc_certified_persistent: missing queue / scratch / stage plan");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (grid > cus) grid = cus;
+    NRX_REQUIRE(hipMemsetAsync(queue, 0, 2 * sizeof(int32_t), st) == hipSuccess, NRX_E_HIP, "nrx_ldpc_certified_persistent: hipMemsetAsync failed");
+    NRX_REQUIRE(hipMemsetAsync(exit_iter, 0, (size_t)n_cb, st) == hipSuccess, NRX_E_HIP, "nrx_ldpc_certified_persistent: hipMemsetAsync failed");
+  }
 #define NRX_FUSED_LAUNCH(RA_, MODE_) \
   hipLaunchKernelGGL((ldpc_dec_chip64_kernel<1, ZI384, RA_, true, 2, MODE_>), dim3(grid), dim3(768), 0, st, llr, n_cb, n_iter, nullptr, (mtab_t)wt, fa)
   // a whole decode that needs two or more rows fewer than its instantiation has: the copy that leaves them out (one row fewer: the waves
@@ -1086,10 +1230,10 @@ static int32_t recover_decode_merge_impl(const double* llr, int32_t n_tb, int32_
   if (mode == 0 && n_rows <= 11) NRX_FUSED_LAUNCH(13, 8);
   else if (n_rows <= 13) {
     if (mode == 0) NRX_FUSED_LAUNCH(13, 0); else if (mode == 1) NRX_FUSED_LAUNCH(13, 1); else if (mode == 2) NRX_FUSED_LAUNCH(13, 2); else if (mode == 3) NRX_FUSED_LAUNCH(13, 3);
-    else if (mode == 5) NRX_FUSED_LAUNCH(13, 5); else NRX_FUSED_LAUNCH(13, 7);
+    else if (mode == 5) NRX_FUSED_LAUNCH(13, 5); else if (mode == 21) NRX_FUSED_LAUNCH(13, 21); else NRX_FUSED_LAUNCH(13, 7);
   } else {
     if (mode == 0) NRX_FUSED_LAUNCH(15, 0); else if (mode == 1) NRX_FUSED_LAUNCH(15, 1); else if (mode == 2) NRX_FUSED_LAUNCH(15, 2); else if (mode == 3) NRX_FUSED_LAUNCH(15, 3);
-    else if (mode == 5) NRX_FUSED_LAUNCH(15, 5); else NRX_FUSED_LAUNCH(15, 7);
+    else if (mode == 5) NRX_FUSED_LAUNCH(15, 5); else if (mode == 21) NRX_FUSED_LAUNCH(15, 21); else NRX_FUSED_LAUNCH(15, 7);
   }
 #undef NRX_FUSED_LAUNCH
   NRX_CHECK_LAUNCH("nrx_ldpc_recover_decode_merge_f64");
@@ -1174,6 +1318,38 @@ extern "C" int32_t nrx_ldpc_stage_certify_decode_merge_f64(const double* llr, in
   }
   return recover_decode_merge_impl((const double*)state, n_tb, llr_len, cfg, nl, qm, n_iter, n_rows, tb_out, cb_ok, sel, n_sel, stream, 7,
                                    (double*)state, nullptr, lam, nullptr, (float*)scratch, scratch_bytes, exit_iter, &cp);
+}
+
+// The certified schedule as ONE launch (round 6): every code-block slot of the grid (one workgroup of two slots per CU) draws blocks from a
+// device queue and takes each through its stages -- stages[0] iterations from the LLRs, CRC + certificate, stages[1] more, ... the last
+// stage without a certificate -- stopping at the first stage whose CRC passes and whose frozen state holds the stability certificate
+// (exit_iter[cb] = the iterations it had then; 0 = it ran all of them).  The two slots of a workgroup never wait for each other, nothing is
+// parked between stages and nothing reloaded: same bits and verdicts as the staged launches (nrx_ldpc_stage_certify_decode_merge_f64 ->
+// nrx_select_failed -> ...) and as the fixed schedule of sum(stages) iterations.  state: one record of nrx_ldpc_fused_state_bytes(...) per
+// slot of the grid (2 x CUs; where a slot's certificate reads the check-node state back), scratch / scratch_bytes: the slack sums (as the stage
+// entry), lam[2 n_cb], queue: int32[2] on the device (zeroed here; queue[1] != 0 afterwards = a slot barrier gave up: results invalid).
+extern "C" int32_t nrx_ldpc_certified_persistent_f64(const double* llr, int32_t n_tb, int32_t llr_len, const nrx_ldpc_cfg* cfg, int32_t nl,
+                                                     int32_t qm, const int32_t* stages, int32_t n_stages, int32_t n_rows, uint8_t* tb_out,
+                                                     uint8_t* cb_ok, void* state, double* lam, uint8_t* exit_iter, void* scratch,
+                                                     size_t scratch_bytes, int32_t* queue, int32_t max_sweeps, int32_t flags, void* stream) {
+  NRX_REQUIRE(llr && state && lam && exit_iter && scratch && queue && stages, NRX_E_ARG, "nrx_ldpc_certified_persistent: NULL buffer");
+  NRX_REQUIRE(n_stages >= 1 && n_stages <= 4 && max_sweeps >= 1, NRX_E_ARG, "nrx_ldpc_certified_persistent: 1 ... 4 stages");
+  int total = 0;
+  for (int i = 0; i < n_stages; ++i) {
+    NRX_REQUIRE(stages[i] >= 1, NRX_E_ARG, "nrx_ldpc_certified_persistent: a stage needs one iteration or more");
+    total += stages[i];
+  }
+  int rows_run = 0;
+  const int32_t rr = nrx_ldpc_fused_rows_run(cfg, nl, qm, llr_len, n_rows, &rows_run);
+  if (rr) return rr;
+  double b3[3];
+  const int32_t rb = nrx_ldpc_cert_bounds(cfg, rows_run, b3);
+  if (rb) return rb;
+  nrx_certcore::Params cp;
+  cp.gamma = b3[0]; cp.gamma1 = b3[1]; cp.dmax = (int32_t)b3[2]; cp.n_iter_total = total; cp.max_sweeps = max_sweeps < 16 ? max_sweeps : 16; cp.flags = flags;
+  cp.iter_now = 0;
+  return recover_decode_merge_impl(llr, n_tb, llr_len, cfg, nl, qm, total, n_rows, tb_out, cb_ok, nullptr, nullptr, stream, 21, (double*)state,
+                                   nullptr, lam, nullptr, (float*)scratch, scratch_bytes, exit_iter, &cp, queue, stages, n_stages);
 }
 
 // One STAGE of the certified schedule on the fused entry: n_iter iterations of every block (sel == NULL: from the LLRs, which

@@ -106,7 +106,7 @@ def gain_times(tables, slots):
 class PdschLink:
     def __init__(self, pdsch, channel, codeRate, baseGraphNo=1, numIter=20, freqDomain=False, chanEst="LS",
                  decoder="f64", windowing="STD", dev=None, firstPassIter=None, polarInt=False, useMax=True,
-                 skipPuncturedRows=True, waveform="f64", certifiedExit=None, certFlags=0, certSweeps=4, certInKernel=True):
+                 skipPuncturedRows=True, waveform="f64", certifiedExit=None, certFlags=0, certSweeps=4, certInKernel=True, certPersistent=True):
         if waveform not in ("f32", "f64"):
             raise ValueError("waveform must be 'f64' (the reference's complex128 waveforms, default) or 'f32' (time-domain link only: "
                              "Tx grid, OFDM, channel filter and received grid in complex64 -- not the parity path)")
@@ -149,6 +149,9 @@ class PdschLink:
         self.certFlags = int(certFlags)
         self.certSweeps = int(certSweeps)      # relaxation sweeps the certificate may take before it refuses
         self.certInKernel = bool(certInKernel) # the certificate in the stage kernel's tail (default) or as its own launch on the parked states
+        # the whole certified schedule as ONE launch with independent code-block slots (round 6; the default where the certificate sits in
+        # the kernel and there are at most three checks): False = the staged launches (stage -> select -> stage ... -> resume)
+        self.certPersistent = bool(certPersistent) and self.certInKernel and (certifiedExit is None or len(tuple(np.atleast_1d(certifiedExit))) <= 3)
         self.last_exit_iter = None          # (n_cb,) uint8 of the last batch that ran the certified schedule
         if firstPassIter is None:
             self.firstPassIter, self.passStages = None, ()
@@ -588,7 +591,8 @@ class PdschLink:
                 if not fuse:
                     raise ValueError("certifiedExit needs the fused float64 decoder entry (BG1, Zc 384, first transmission, <= 15 rows, max-log LLRs)")
                 got = ops.ldpc_recover_decode_merge_certified(llr, ccfg, cw['nl'], cw['qm'], self.certStages, self.numIter, rows=cw['rows'],
-                                                              flags=self.certFlags, max_sweeps=self.certSweeps, in_kernel=self.certInKernel)
+                                                              flags=self.certFlags, max_sweeps=self.certSweeps, in_kernel=self.certInKernel,
+                                                              persistent=self.certPersistent)
                 fused = None if got is None else got[:2]
                 self.last_exit_iter = None if got is None else got[2]
             elif fuse and self.firstPassIter is not None:     # two passes, both on the fused entry, the failing blocks' list on the device

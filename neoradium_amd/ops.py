@@ -375,7 +375,7 @@ _cert_bufs = {}
 _cert_scratch = {}
 
 
-def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0, max_sweeps=4, flags=0, in_kernel=True):
+def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0, max_sweeps=4, flags=0, in_kernel=True, persistent=False):
     """The CERTIFIED early exit on the fused entry (opt-in; the reference has no early stop, ldpc.py:1545).  ``stages`` = ascending
     iteration counts at which the blocks still running are checked: a block whose CRC24B passes AND whose frozen decoder state holds
     the stability certificate (nrx_ldpc_certify_f64: every later iteration provably leaves its hard decisions unchanged) stops there;
@@ -386,7 +386,10 @@ def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0
     (tests only: bit 0 drops the sign / posterior conditions (S), (Q), bit 1 the closure (M), bit 2 also tries blocks whose CRC fails).
     ``in_kernel`` (default):
     the certificate is evaluated in the stage kernel's tail (nrx_ldpc_stage_certify_decode_merge_f64: a certified block never parks);
-    False: stage, then the stand-alone nrx_ldpc_certify_f64 on the parked states -- the same conditions, another search order."""
+    False: stage, then the stand-alone nrx_ldpc_certify_f64 on the parked states -- the same conditions, another search order.
+    ``persistent`` (round 6): the whole schedule as ONE launch whose code-block slots draw blocks from a device queue and take each
+    through all its stages (nrx_ldpc_certified_persistent_f64): nothing parked, nothing reloaded; ``persistent_error()`` reads the
+    launch's error word afterwards (tests)."""
     if llr.dtype != torch.float64 or llr.dim() != 2 or not (cfg.bg == 1 and cfg.Zc == 384 and cfg.C > 1):
         return None
     llr = llr.contiguous()
@@ -415,6 +418,24 @@ def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0
         raise ValueError("stages must hold at least one iteration count below n_iter")
     L = lib()
     cfgp, r = C.byref(cfg), int(rows or 0)
+    if persistent:
+        # ONE launch: every code-block slot of the grid takes its blocks through all their stages (nrx_ldpc_certified_persistent_f64)
+        plan = [marks[0]] + [b - a for a, b in zip(marks, marks[1:] + [int(n_iter)])]
+        if len(plan) > 4:
+            raise ValueError("the persistent certified schedule takes at most three checks")
+        n_slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+        need = (n_slots // 2) * 2 * (26 + 2 * 15) * 384 * 4
+        scr = _cert_scratch.get(key)
+        if scr is None or scr.numel() < need:
+            scr = _cert_scratch[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        pst = _pers_state.get(key)
+        if pst is None or pst[0].numel() < n_slots * per:
+            pst = _pers_state[key] = (torch.empty(n_slots * per, dtype=torch.uint8, device=dev), torch.zeros(2, dtype=torch.int32, device=dev))
+        arr = (C.c_int32 * len(plan))(*plan)
+        check(L.nrx_ldpc_certified_persistent_f64(ptr(llr), n_tb, G, cfgp, nl, qm, arr, len(plan), r, ptr(tb_out), ptr(cb_ok), ptr(pst[0]),
+                                                  ptr(lam), ptr(exit_iter), ptr(scr), scr.numel(), ptr(pst[1]), int(max_sweeps), int(flags), stream()))
+        _pers_state['last_queue'] = pst[1]
+        return tb_out, cb_ok, exit_iter
     if in_kernel:
         n_wg = min((n_cb + 1) // 2, int(os.environ.get('NRX_CERT_WGS', '256')))      # (developer knob: workgroups of the stage launches = scratch slots)
         need = n_wg * 2 * (26 + 2 * 15) * 384 * 4
@@ -459,6 +480,15 @@ def ldpc_recover_decode_merge_certified(llr, cfg, nl, qm, stages, n_iter, rows=0
                                          int(max_sweeps), int(flags), ptr(exit_iter), stream()))
         done = upto
     return tb_out, cb_ok, exit_iter
+
+
+_pers_state = {}
+
+
+def persistent_error():
+    """The error word of the last persistent certified launch (non-zero = a slot barrier gave up: a bug).  Synchronises."""
+    q = _pers_state.get('last_queue')
+    return 0 if q is None else int(q[1].item())
 
 
 def ldpc_fused_supported(cfg, nl, qm, G, rows):

@@ -20,14 +20,14 @@ def _metric_link(**kw):
     return bench.build_link(nr, decoder="f64", num_iter=50, **kw)
 
 
-@pytest.mark.parametrize("in_kernel", [True, False])
+@pytest.mark.parametrize("in_kernel", ["persistent", True, False])
 def test_certified_blocks_equal_the_fixed_schedule_over_the_waterfall(dev, in_kernel):
     """>= 1e5 code blocks, 29 ... 35 dB (code-block error rate ~0.6 ... 0): transport-block bits and CRC verdicts of the certified
-    schedule identical to the fixed 50-iteration schedule for EVERY block, certified or not -- with the certificate evaluated in the
-    stage kernel's tail (the default) and as its own launch on the parked states."""
+    schedule identical to the fixed 50-iteration schedule for EVERY block, certified or not -- as ONE persistent launch (the default), as
+    staged launches with the certificate in the stage kernel's tail, and with the certificate as its own launch on the parked states."""
     import torch
     fixed = _metric_link()
-    certd = _metric_link(certifiedExit=(8, 14, 24), certInKernel=in_kernel)
+    certd = _metric_link(certifiedExit=(8, 14, 24), certInKernel=bool(in_kernel), certPersistent=in_kernel == "persistent")
     C, pay = fixed.cfg.C, fixed.cfg.cb_len - 24
     total = certified = 0
     hist = {}
@@ -48,6 +48,34 @@ def test_certified_blocks_equal_the_fixed_schedule_over_the_waterfall(dev, in_ke
                 hist[int(v)] = hist.get(int(v), 0) + int(c)
     assert total >= 100000
     assert certified > 0.5 * total and set(hist) >= {0, 8, 14}, hist
+
+
+def test_persistent_schedule_equals_the_staged_launches(dev):
+    """The certified schedule as ONE launch (nrx_ldpc_certified_persistent_f64: code-block slots that draw blocks from a device queue and take
+    each through all its stages behind barriers of their own) against the staged launches with the certificate in the kernel's tail: the
+    same certificate code on the same frozen states, so the same exit iteration for every block, the same bits, the same CRC verdicts --
+    and both equal to the fixed schedule.  Across the waterfall, with one, two and three checks, and on a batch smaller than the grid."""
+    import torch
+    from neoradium_amd import ops
+    fixed = _metric_link()
+    pay = fixed.cfg.cb_len - 24
+    total = 0
+    for stages, snr, slot0, n in (((8, 16), 31.0, 50, 40), ((8,), 29.5, 400, 16), ((6, 10, 18), 33.0, 900, 24), ((8, 16), 35.0, 1300, 3)):
+        staged = _metric_link(certifiedExit=stages, certPersistent=False)
+        pers = _metric_link(certifiedExit=stages)
+        assert pers.certPersistent and not staged.certPersistent
+        _, d0 = fixed.run(slot0, n, snr, seed=5, details="verdicts")
+        _, d1 = staged.run(slot0, n, snr, seed=5, details="verdicts")
+        _, d2 = pers.run(slot0, n, snr, seed=5, details="verdicts")
+        assert ops.persistent_error() == 0, "a slot barrier of the persistent kernel gave up"
+        e1, e2 = staged.last_exit_iter.cpu().numpy(), pers.last_exit_iter.cpu().numpy()
+        assert np.array_equal(e1, e2), (stages, snr, int((e1 != e2).sum()))
+        for d in (d1, d2):
+            assert torch.equal(d0[0][1]['cb_ok'], d[0][1]['cb_ok'])
+            assert torch.equal(d0[0][1]['tb_out'].reshape(-1, pay), d[0][1]['tb_out'].reshape(-1, pay))
+        total += e2.size
+        assert set(np.unique(e2)) <= {0, *stages}
+    assert total > 5000
 
 
 def test_a_broken_certificate_is_caught(dev):
@@ -134,8 +162,10 @@ def test_fillers_zeros_saturation_and_both_instantiations(dev, tbs, qm, nl, e_bi
                 off += E
         xd = deint(x)
         tb_ref, ok_ref = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, n_iter, rows=rows)
-        for in_kernel in (True, False):
-            tb_c, ok_c, ex = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (5, 9, 14), n_iter, rows=rows, in_kernel=in_kernel)
+        for in_kernel in (True, False, "persistent"):
+            tb_c, ok_c, ex = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (5, 9, 14), n_iter, rows=rows, in_kernel=bool(in_kernel),
+                                                                     persistent=in_kernel == "persistent")
+            assert ops.persistent_error() == 0
             assert torch.equal(ok_c, ok_ref) and torch.equal(tb_c, tb_ref), (saturate, in_kernel)
             exn = ex.cpu().numpy().reshape(n_tb, cfg.C)
             okn = ok_ref.cpu().numpy().astype(bool)
@@ -186,10 +216,11 @@ def test_the_sign_and_magnitude_conditions_bind_on_converged_blocks(dev):
         xd = deint(scale * unit)
         tb_ref, ok_ref = ops.ldpc_recover_decode_merge(xd, cfg, nl, qm, n_iter, rows=rows)
         assert bool(ok_ref.all())
-        for in_kernel in (True, False):
+        for in_kernel in (True, False, "persistent"):
             ex = {}
             for flags in (0, 1, 2):
-                tb_c, ok_c, e = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (8, 12), n_iter, rows=rows, flags=flags, in_kernel=in_kernel)
+                tb_c, ok_c, e = ops.ldpc_recover_decode_merge_certified(xd, cfg, nl, qm, (8, 12), n_iter, rows=rows, flags=flags, in_kernel=bool(in_kernel),
+                                                                        persistent=in_kernel == "persistent")
                 assert torch.equal(ok_c, ok_ref) and torch.equal(tb_c, tb_ref), (scale, flags, in_kernel)
                 ex[flags] = e.cpu().numpy()
             if big:

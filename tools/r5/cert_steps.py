@@ -24,12 +24,14 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--stages', type=int, nargs='+', default=[8, 16])
     ap.add_argument('--fixed', action='store_true', help='the fixed 50-iteration schedule instead')
+    ap.add_argument('--persistent', action='store_true', help='the certified schedule as one persistent launch (round 6)')
+    ap.add_argument('--slot0', type=int, default=0, help='first slot (bench.py: 0)')
     a = ap.parse_args()
-    kw = {} if a.fixed else {'certifiedExit': tuple(a.stages)}
+    kw = {} if a.fixed else {'certifiedExit': tuple(a.stages), 'certPersistent': a.persistent}
     link = bench.build_link(nr, decoder='f64', **kw)
-    dt, c, _ = bench.timed_steps(link, ops, a.batch, a.steps, a.warmup, a.snr, 0, None, torch.cuda.synchronize, timer_enabled=False)
+    dt, c, _ = bench.timed_steps(link, ops, a.batch, a.steps, a.warmup, a.snr, a.slot0, None, torch.cuda.synchronize, timer_enabled=False)
     c = c.cpu().numpy()
-    print(json.dumps({"schedule": "fixed" if a.fixed else "certified", "snr_db": a.snr, "steps": a.steps, "batch": a.batch,
+    print(json.dumps({"schedule": "fixed" if a.fixed else ("certified, persistent" if a.persistent else "certified, staged"), "persistent_error": ops.persistent_error(), "snr_db": a.snr, "steps": a.steps, "batch": a.batch,
                       "ms_per_step": 1e3 * dt / a.steps, "slots_per_s": a.batch * a.steps / dt, "block_errors": int(c[0]), "blocks": int(c[1])}), flush=True)
 
 
