@@ -26,8 +26,9 @@ def main():
     ap.add_argument('--fixed', action='store_true', help='the fixed 50-iteration schedule instead')
     ap.add_argument('--persistent', action='store_true', help='the certified schedule as one persistent launch (round 6)')
     ap.add_argument('--slot0', type=int, default=0, help='first slot (bench.py: 0)')
+    ap.add_argument('--flags', type=int, default=0, help='certificate flags (timing experiments: != 0 breaks the certificate)')
     a = ap.parse_args()
-    kw = {} if a.fixed else {'certifiedExit': tuple(a.stages), 'certPersistent': a.persistent}
+    kw = {} if a.fixed else {'certifiedExit': tuple(a.stages), 'certPersistent': a.persistent, 'certFlags': a.flags}
     link = bench.build_link(nr, decoder='f64', **kw)
     dt, c, _ = bench.timed_steps(link, ops, a.batch, a.steps, a.warmup, a.snr, a.slot0, None, torch.cuda.synchronize, timer_enabled=False)
     c = c.cpu().numpy()
