@@ -78,6 +78,32 @@ def test_persistent_schedule_equals_the_staged_launches(dev):
     assert total > 5000
 
 
+def test_persistent_entry_argument_errors(dev):
+    """nrx_ldpc_certified_persistent_f64 refuses what it cannot run, like the staged entries: more than three checks (the ops layer), a
+    stage without iterations, NULL buffers (NRX_E_ARG -> ValueError), and a configuration without a fused instantiation (NRX_E_UNSUPPORTED ->
+    the ops layer returns None and the caller takes the separate stages)."""
+    import ctypes as C
+    import torch
+    from neoradium_amd import ops, _lib
+    cfg = _lib.ldpc_config(1, 25000 + 24)
+    G = cfg.C * 12300
+    llr = torch.zeros((2, G), dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError):
+        ops.ldpc_recover_decode_merge_certified(llr, cfg, 1, 2, (4, 6, 8, 10), 30, rows=15, persistent=True)
+    L = _lib.lib()
+    bad = (C.c_int32 * 2)(8, 0)
+    buf = torch.zeros(64, dtype=torch.uint8, device=dev)
+    rc = L.nrx_ldpc_certified_persistent_f64(_lib.ptr(llr), 2, G, C.byref(cfg), 1, 2, bad, 2, 15, _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf),
+                                             _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf), 64, _lib.ptr(buf), 4, 0, None)
+    assert rc == -1 and 'stage' in _lib.last_error()
+    ok = (C.c_int32 * 2)(8, 8)
+    rc = L.nrx_ldpc_certified_persistent_f64(None, 2, G, C.byref(cfg), 1, 2, ok, 2, 15, _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf),
+                                             _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf), 64, _lib.ptr(buf), 4, 0, None)
+    assert rc == -1
+    cfg2 = _lib.ldpc_config(2, 3000)                       # BG2: no fused instantiation
+    assert ops.ldpc_recover_decode_merge_certified(torch.zeros((1, 9000), dtype=torch.float64, device=dev), cfg2, 1, 2, (4,), 10, persistent=True) is None
+
+
 def test_a_broken_certificate_is_caught(dev):
     """Without its conditions (flags 7: no sign / closure conditions, CRC filter off) everything 'certifies' at the first check
     and blocks that had not converged differ from the fixed schedule: the comparison above would fail."""
