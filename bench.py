@@ -733,7 +733,7 @@ def main():
                           "bound_edge_visits_per_s": peak_rate / (isa['valu'] / BG1_ROW_START[rows_run]) * 64}
         traffic = None
         try:                                              # HBM bytes per launch from the committed PMC passes
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r5_decoder_traffic.json' if f64 else 'r1_decoder_traffic.json')))
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r6_decoder_traffic.json' if f64 else 'r1_decoder_traffic.json')))      # (tools/r6/pmc_traffic.sh fixed, this round's build)
             if (tr.get('rows') == rows_run and side) or (not f64 and rows_run in (15, 16)):
                 traffic = (tr['FETCH_SIZE_KB_per_launch'] * tr.get('fetch_correction', 1.0) + tr['WRITE_SIZE_KB_per_launch']) \
                     * 1024.0 * B / tr['batch_slots']
